@@ -1,0 +1,221 @@
+"""TEST INFRASTRUCTURE - imports the *reference's own* Python modules as the live oracle.
+
+Only usable where the read-only reference tree is mounted (the build container);
+``available()`` is False on the GPU box and every caller must skip.  Nothing here is
+copied from the reference: we put ``<ref>/code`` on sys.path, stub the GUI / GL
+imports the hot path never touches (cv2, pyrender, trimesh, OpenGL, torchgeometry:
+reference utils/utils.py:25-30, fitting.py:33, optimizers/lbfgs_ls.py:9,
+model/VPoser.py:5) and instantiate the reference classes with our synthetic arrays
+(SMPL accepts ``data_struct=``: body_models_scale.py:98,169-180).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF_ROOT = os.environ.get('MVFIT_REFERENCE', '/root/reference')
+_mods = None
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(REF_ROOT, 'code', 'utils', 'fitting.py'))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules.setdefault(name, m)
+    return sys.modules[name]
+
+
+@contextlib.contextmanager
+def _cwd(path):
+    old = os.getcwd()
+    os.chdir(path)
+    try:
+        yield
+    finally:
+        os.chdir(old)
+
+
+def load():
+    """Import the reference modules once; returns a namespace."""
+    global _mods
+    if _mods is not None:
+        return _mods
+    if not available():
+        raise RuntimeError('reference tree not mounted at %s' % REF_ROOT)
+    _stub('cv2')
+    pr = _stub('pyrender')
+    prc = _stub('pyrender.constants', RenderFlags=type('RenderFlags', (), {}))
+    pr.constants = prc
+    _stub('trimesh')
+    gl = _stub('OpenGL')
+    gl.GLUT = _stub('OpenGL.GLUT')
+    _stub('torchgeometry')
+    code = os.path.join(REF_ROOT, 'code')
+    if code not in sys.path:
+        sys.path.insert(0, code)
+    import warnings
+    warnings.filterwarnings('ignore')
+    with _cwd(REF_ROOT):
+        import smplx                                  # noqa  (reference package, shadows nothing here)
+        from smplx import body_models_scale
+        from smplx.utils import Struct
+        import camera as ref_camera
+        import prior as ref_prior
+        from utils import fitting as ref_fitting
+        from utils import utils as ref_utils
+        from optimizers import optim_factory, lbfgs_ls
+        from model import VPoser as ref_vposer
+    ns = types.SimpleNamespace(body_models_scale=body_models_scale, Struct=Struct,
+                               camera=ref_camera, prior=ref_prior, fitting=ref_fitting,
+                               utils=ref_utils, optim_factory=optim_factory,
+                               lbfgs_ls=lbfgs_ls, vposer=ref_vposer)
+    _mods = ns
+    return ns
+
+
+def real_lsp_regressor():
+    """The shipped 14x6890 LSP regressor as (rows, cols, vals) triplets."""
+    R = np.load(os.path.join(REF_ROOT, 'data', 'J_regressor_lsp.npz'))['joint_regressor']
+    r, c = np.nonzero(R)
+    return r.astype(np.int32), c.astype(np.int32), R[r, c].astype(np.float32)
+
+
+class RefProblem:
+    """The reference's model + cameras + loss + closure for ONE problem (B = 1), built the
+    way code/init.py:85-159 and code/utils/non_linear_solver.py:127-192 build them."""
+
+    def __init__(self, model: dict, cams, gt_xy, conf, dtype='float64', use_vposer=False,
+                 vposer_weights=None, prior='l2', gmm=None, fix_shape=False, rho=100.0,
+                 joint_weights=None):
+        import torch
+        ref = load()
+        self.ref = ref
+        self.torch = torch
+        dt = torch.float64 if dtype == 'float64' else torch.float32
+        self.dt = dt
+        self.use_vposer = use_vposer
+        nv = model['v_template'].shape[0]
+        posedirs_v = model['posedirs'].T.reshape(nv, 3, 207)
+        kin = np.stack([np.where(model['parents'] < 0, 2 ** 32 - 1, model['parents']),
+                        np.arange(24)]).astype(np.int64)
+        struct = ref.Struct(f=model['faces'].astype(np.int64), v_template=model['v_template'],
+                            shapedirs=model['shapedirs'], J_regressor=model['J_regressor'],
+                            posedirs=posedirs_v, kintree_table=kin, weights=model['lbs_weights'])
+        mapper = ref.utils.JointMapper(ref.utils.smpl_to_annotation(
+            model_type='smpllsp', pose_format='lsp14'))
+        with _cwd(REF_ROOT):       # relative np.load('data/J_regressor_lsp.npz'), body_models_scale.py:284
+            smpl = ref.body_models_scale.create_scale(
+                'unused', model_type='smpllsp', data_struct=struct, joint_mapper=mapper,
+                create_global_orient=True, create_body_pose=not use_vposer, create_betas=True,
+                create_transl=True, create_scale=True, dtype=dt)
+        # the keypoint regressor under test may differ from the shipped file
+        smpl.joint_regressor = torch.tensor(model['kp_regressor'], dtype=dt)
+        self.smpl = smpl
+        cam_R, cam_t, cam_f, cam_c = cams
+        self.cameras = []
+        for v in range(cam_R.shape[0]):
+            cam = ref.camera.create_camera(
+                focal_length_x=float(cam_f[v]), focal_length_y=float(cam_f[v]),
+                translation=torch.tensor(cam_t[v], dtype=dt).unsqueeze(0),
+                rotation=torch.tensor(cam_R[v], dtype=dt).unsqueeze(0),
+                center=torch.tensor(cam_c[v], dtype=dt).unsqueeze(0), dtype=dt)
+            cam.rotation.requires_grad = False
+            cam.translation.requires_grad = False
+            self.cameras.append(cam)
+        self.vposer = None
+        self.pose_embedding = None
+        if use_vposer:
+            vp = ref.vposer.VPoser(num_neurons=512, latentD=32, data_shape=[1, 23, 3])
+            sd = vp.state_dict()
+            names = dict(fc1_w='bodyprior_dec_fc1.weight', fc1_b='bodyprior_dec_fc1.bias',
+                         fc2_w='bodyprior_dec_fc2.weight', fc2_b='bodyprior_dec_fc2.bias',
+                         out_w='bodyprior_dec_out.weight', out_b='bodyprior_dec_out.bias')
+            for k, n in names.items():
+                sd[n] = torch.tensor(vposer_weights[k])
+            vp.load_state_dict(sd)
+            vp = vp.to(dtype=dt)
+            vp.eval()
+            self.vposer = vp
+            self.pose_embedding = torch.zeros([1, 32], dtype=dt, requires_grad=True)
+        if prior == 'gmm':
+            import pickle
+            import tempfile
+            d = tempfile.mkdtemp()
+            M = gmm['means'].shape[0]
+            with open(os.path.join(d, 'gmm_%02d.pkl' % M), 'wb') as fh:
+                pickle.dump(gmm, fh)
+            body_prior = ref.prior.create_prior('gmm', prior_folder=d, num_gaussians=M, dtype=dt)
+        else:
+            body_prior = ref.prior.create_prior('l2', dtype=dt)
+        shape_prior = ref.prior.create_prior('l2', dtype=dt)
+        angle_prior = ref.prior.create_prior('angle', dtype=dt)
+        self.loss = ref.fitting.create_loss(
+            loss_type='smplify', rho=rho, use_joints_conf=True, body_pose_prior=body_prior,
+            shape_prior=shape_prior, angle_prior=angle_prior, interpenetration=False,
+            dtype=dt, use_3d=False, fix_shape=fix_shape)
+        self.gt_joints = torch.tensor(np.asarray(gt_xy)[:, None, :, :], dtype=dt)   # [V,1,17,2]
+        self.joints_conf = [torch.tensor(np.asarray(conf)[v][None, :], dtype=dt)
+                            for v in range(cam_R.shape[0])]
+        jw = np.ones(17, np.float32) if joint_weights is None else joint_weights
+        self.joint_weights = torch.tensor(jw, dtype=dt).unsqueeze(0)
+        self.monitor = ref.fitting.FittingMonitor(maxiters=30, ftol=1e-9, gtol=1e-9)
+
+    def final_params(self):
+        ps = [p for p in self.smpl.parameters() if p.requires_grad]
+        if self.vposer is not None:
+            ps.append(self.pose_embedding)
+        return ps
+
+    def set_flat(self, x):
+        torch = self.torch
+        off = 0
+        with torch.no_grad():
+            for p in self.final_params():
+                n = p.numel()
+                p.copy_(torch.tensor(np.asarray(x[off:off + n]), dtype=self.dt).view_as(p))
+                off += n
+        assert off == len(x)
+
+    def get_flat(self):
+        return np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in self.final_params()])
+
+    def set_weights(self, wts: dict):
+        self.loss.reset_loss_weights({k: float(v) for k, v in wts.items() if k != 'rho'})
+
+    def make_optimizer(self, maxiters=30):
+        opt, _ = self.ref.optim_factory.create_optimizer(
+            self.final_params(), optim_type='lbfgsls', lr=1.0, maxiters=maxiters)
+        return opt
+
+    def make_closure(self, optimizer):
+        return self.monitor.create_fitting_closure(
+            optimizer, self.smpl, camera=self.cameras, gt_joints=self.gt_joints,
+            joints_conf=self.joints_conf, joint_weights=self.joint_weights, loss=self.loss,
+            create_graph=False, use_vposer=self.use_vposer, vposer=self.vposer,
+            pose_embedding=self.pose_embedding, return_verts=True, return_full_pose=True,
+            use_3d=False)
+
+    def eval_closure(self, x, wts):
+        """loss, grad, vertices, joints at flat params x (the reference's own code path)."""
+        self.set_flat(x)
+        self.set_weights(wts)
+        opt = self.make_optimizer()
+        closure = self.make_closure(opt)
+        loss = closure(backward=True)
+        grad = np.concatenate([
+            (p.grad if p.grad is not None else self.torch.zeros_like(p)).detach().numpy().reshape(-1)
+            for p in self.final_params()])
+        with self.torch.no_grad():
+            bp = self.vposer.decode(self.pose_embedding, output_type='aa').view(1, -1) \
+                if self.use_vposer else None
+            out = self.smpl(return_verts=True, body_pose=bp, return_full_pose=True)
+        return (float(loss), grad, out.vertices[0].detach().numpy(),
+                out.joints[0].detach().numpy())
