@@ -1,0 +1,173 @@
+/*
+ * mvfit.h - C ABI of the MI355X-native multi-view SMPL fitting hot path.
+ *
+ * The reference (boycehbz/MvSMPLfitting) has no FFI on this path except the SDF op; its
+ * seams are Python callables.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference root).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MVFIT_E_* code on failure, never throws;
+ *     mvfit_last_error(ctx) returns a NUL-terminated message owned by the ctx.
+ *   - a ctx is bound to one HIP device and one hipStream_t, is not thread-safe; different
+ *     ctxs are independent.  All calls are asynchronous on the ctx stream except
+ *     mvfit_create / mvfit_sync / mvfit_destroy and the host-copy getters.
+ *   - "dev|host" pointers may be either (copied with hipMemcpyDefault); "dev" pointers must be
+ *     device memory (e.g. a torch CUDA tensor's data_ptr()); all arrays row-major float32
+ *     unless noted.  Caller-owned; nothing is retained beyond the call except by
+ *     mvfit_create, which copies (and re-tiles) the model constants into HBM.
+ *   - flat parameter vector x[D], D = MVFIT_D = 86 + 32:  the reference's final_params order
+ *     (code/utils/non_linear_solver.py:164-170, code/smplx/body_models_scale.py:202-268)
+ *       betas[0:10] global_orient[10:13] body_pose[13:82] transl[82:85] scale[85]
+ *       pose_embedding[86:118]
+ *     With MVFIT_F_VPOSER the body_pose slots are ignored on input (decoded from the
+ *     embedding) and receive zero gradient; without it the embedding slots are ignored.
+ *     MVFIT_F_FIX_SHAPE / MVFIT_F_FIX_SCALE freeze betas / scale (gradient forced to 0:
+ *     code/utils/init_guess.py:205-210).
+ */
+#ifndef MVFIT_H_
+#define MVFIT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVFIT_NUM_JOINTS 24
+#define MVFIT_NUM_BETAS 10
+#define MVFIT_NUM_POSE_BASIS 207
+#define MVFIT_NUM_KP 17
+#define MVFIT_D 118          /* 86 model scalars + 32 latent */
+#define MVFIT_D_MODEL 86
+#define MVFIT_MAX_VIEWS 16
+#define MVFIT_MAX_STAGES 8
+#define MVFIT_HISTORY 100
+
+/* error codes */
+#define MVFIT_OK 0
+#define MVFIT_E_ARG (-1)
+#define MVFIT_E_HIP (-2)
+#define MVFIT_E_STATE (-3)
+#define MVFIT_E_UNSUPPORTED (-4)
+
+/* flags (mvfit_weights.flags) */
+#define MVFIT_F_VPOSER 1u      /* use_vposer: code/utils/fitting.py:166-168,327-329 */
+#define MVFIT_F_PRIOR_GMM 2u   /* body_prior_type 'gmm' (code/prior.py:100-231) instead of 'l2' */
+#define MVFIT_F_FIX_SHAPE 4u   /* fix_shape: code/utils/fitting.py:340, init_guess.py:208-210 */
+#define MVFIT_F_FIX_SCALE 8u   /* fix_scale: init_guess.py:205-207 */
+#define MVFIT_F_SPARSE_VERTS 16u /* evaluate only the vertices the objective reads (same loss /
+                                    gradient; skips the full 6890-vertex pass inside the closure) */
+
+typedef struct mvfit_ctx mvfit_ctx;
+
+/* Host-side description of the body model; replaces the buffers registered by
+ * SMPL.__init__ (code/smplx/body_models_scale.py:197-305). */
+typedef struct mvfit_model {
+    int32_t num_verts;               /* 6890 */
+    int32_t num_faces;               /* 13776 (0 if faces == NULL) */
+    const float* v_template;         /* [Nv,3] */
+    const float* shapedirs;          /* [Nv,3,10]   (beta index fastest) */
+    const float* posedirs;           /* [207, Nv*3] (column = 3*vertex + coord) */
+    const float* J_regressor;        /* [24,Nv] dense */
+    const int32_t* parents;          /* [24], parents[0] = -1 */
+    const float* lbs_weights;        /* [Nv,24] dense */
+    const float* kp_regressor;       /* [14,Nv] dense ('smpllsp' joint_regressor, :283-286) */
+    const int32_t* face_vertex_ids;  /* [5]  (code/smplx/vertex_joint_selector.py:38-43) */
+    const int32_t* joint_map;        /* [17] (code/utils/utils.py:453-457) */
+    const int32_t* faces;            /* [Nf,3] or NULL */
+    /* optional VPoser decoder (code/model/VPoser.py:188-195), NULL if unused */
+    const float* vp_fc1_w; const float* vp_fc1_b;   /* [512,32],[512] */
+    const float* vp_fc2_w; const float* vp_fc2_b;   /* [512,512],[512] */
+    const float* vp_out_w; const float* vp_out_b;   /* [138,512],[138] */
+    /* optional max-mixture prior (code/prior.py:135-160), gmm_M = 0 if unused */
+    int32_t gmm_M;
+    const float* gmm_means;          /* [M,69] */
+    const float* gmm_precisions;     /* [M,69,69] */
+    const float* gmm_nll_weights;    /* [M] */
+} mvfit_model;
+
+/* One stage's loss weights; replaces SMPLifyLoss.reset_loss_weights
+ * (code/utils/fitting.py:270-280) + the per-stage dict of non_linear_solver.py:109-124,177-180. */
+typedef struct mvfit_weights {
+    float data_weight;           /* 500/H, enters squared (fitting.py:315) */
+    float body_pose_weight;      /* enters squared (fitting.py:329,333,337) */
+    float shape_weight;          /* enters squared (fitting.py:342) */
+    float bending_prior_weight;  /* 3.17*body_pose_weight, NOT squared (fitting.py:348) */
+    float coll_loss_weight;      /* SDF term (fitting.py:354,392); 0 = off */
+    float rho;                   /* GMoF rho (code/utils/utils.py:427-438) */
+    uint32_t flags;              /* MVFIT_F_* */
+} mvfit_weights;
+
+/* Optimiser settings; replaces create_optimizer(..., 'lbfgsls') (code/optimizers/optim_factory.py:50-52,
+ * lbfgs_ls.py:199-207) and FittingMonitor(maxiters, ftol, gtol) (code/utils/fitting.py:38-47). */
+typedef struct mvfit_lbfgs_opts {
+    float lr;                /* 1.0 */
+    int32_t max_iter;        /* 30 (max_eval = max_iter*5/4) */
+    int32_t history;         /* <= MVFIT_HISTORY (100) */
+    float tolerance_grad;    /* 1e-5 */
+    float tolerance_change;  /* 1e-9 */
+    int32_t maxiters;        /* outer run_fitting iterations, 30 */
+    float ftol;              /* 1e-9 */
+    float gtol;              /* 1e-9 */
+    int32_t num_stages;      /* <= MVFIT_MAX_STAGES */
+    int32_t max_rounds;      /* safety cap on closure rounds per call (0 = no cap) */
+} mvfit_lbfgs_opts;
+
+/* SMPL.__init__ + .to(device) (body_models_scale.py:98-305, code/init.py:143-151): copies and
+ * re-tiles the constants into HBM.  hip_stream may be NULL (default stream). */
+int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* model);
+void mvfit_destroy(mvfit_ctx* ctx);
+const char* mvfit_last_error(const mvfit_ctx* ctx);
+int mvfit_sync(mvfit_ctx* ctx);
+
+/* The per-frame inputs of create_fitting_closure (code/utils/fitting.py:144-156; shapes from
+ * non_linear_solver.py:77-84, code/init.py:112-131):
+ *   cameras: cam_batched = 0 -> one rig [V,...] shared by all problems; 1 -> [B,V,...].
+ *   gt_xy[B,V,17,2] ; w_conf[B,V,17] = joint_weights * conf (0 for missing views, main.py:49-57).
+ * B = number of independent (subject x frame) problems. */
+int mvfit_set_problems(mvfit_ctx* ctx, int B, int V, int cam_batched,
+                       const float* cam_R /*[.,V,3,3] dev|host*/, const float* cam_t /*[.,V,3]*/,
+                       const float* cam_f /*[.,V]*/, const float* cam_c /*[.,V,2]*/,
+                       const float* gt_xy /*dev|host*/, const float* w_conf /*dev|host*/);
+
+/* One closure evaluation for all B problems: fitting_func(backward=True)
+ * (code/utils/fitting.py:162-203) = SMPL.forward + SMPLifyLoss.forward + backward.
+ *   params[B,MVFIT_D] dev ; loss[B] dev ; grad[B,MVFIT_D] dev or NULL (forward only) ;
+ *   verts[B,Nv,3] dev or NULL ; joints[B,17,3] dev or NULL. */
+int mvfit_closure(mvfit_ctx* ctx, const mvfit_weights* w, const float* params,
+                  float* loss, float* grad, float* verts, float* joints);
+
+/* SMPL.forward only (body_models_scale.py:327-412): vertices (+transl) and the 17 keypoints. */
+int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint32_t flags,
+                   float* verts /*[B,Nv,3] dev*/, float* joints /*[B,17,3] dev or NULL*/);
+
+/* The whole staged fit, device resident: for each stage (non_linear_solver.py:156-211) a fresh
+ * LBFGS (lbfgs_ls.py:256-445, strong-Wolfe :39-167) driven by run_fitting (fitting.py:99-142),
+ * every problem advancing its own state machine, no host synchronisation per closure.
+ *   params[B,MVFIT_D] dev, in/out ; stage_weights[num_stages] host ;
+ *   final_loss[B] dev (run_fitting's return of the last stage; NaN where the reference returns None)
+ *   n_closure[B], n_iter[B] dev int32 (closure evaluations / L-BFGS iterations spent), may be NULL. */
+int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
+              float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
+
+/* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
+ * the last call, measured with hipEvents on the ctx stream; *launches = number measured.
+ * Enable with mvfit_profile(ctx, 1) (adds two event records per launch). */
+int mvfit_profile(mvfit_ctx* ctx, int enable);
+int mvfit_profile_read(mvfit_ctx* ctx, double* vertex_pass_ms_avg, int* launches,
+                       double* step_kernel_ms_avg, int* step_launches);
+
+/* Known-answer test entry for the device L-BFGS state machine (same template as production,
+ * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.
+ *   kind: 0 quad, 1 rosen, 2 gmof ; D <= 128 ; x_inout[D] host ; trace[max_trace,(D+1)] host
+ *   (x_trial, loss per closure) ; segs[nseg+1] parameter-tensor boundaries for the gtol test. */
+int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs, int nseg,
+                    const mvfit_lbfgs_opts* opts, double* x_inout, double* trace, int max_trace,
+                    int* n_closure, double* final_loss);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVFIT_H_ */

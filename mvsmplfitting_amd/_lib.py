@@ -1,0 +1,89 @@
+"""ctypes binding of libmvfit.so (include/mvfit.h).  No fallback: if the HIP library is
+missing or does not load, importing this module raises - the product path never runs on
+anything but the hand-written gfx950 kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmvfit.so')
+
+D = 118
+D_MODEL = 86
+NUM_KP = 17
+MAX_VIEWS = 16
+MAX_STAGES = 8
+
+F_VPOSER = 1
+F_PRIOR_GMM = 2
+F_FIX_SHAPE = 4
+F_FIX_SCALE = 8
+F_SPARSE_VERTS = 16
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ('num_verts', C.c_int32), ('num_faces', C.c_int32),
+        ('v_template', _fp), ('shapedirs', _fp), ('posedirs', _fp), ('J_regressor', _fp),
+        ('parents', _ip), ('lbs_weights', _fp), ('kp_regressor', _fp),
+        ('face_vertex_ids', _ip), ('joint_map', _ip), ('faces', _ip),
+        ('vp_fc1_w', _fp), ('vp_fc1_b', _fp), ('vp_fc2_w', _fp), ('vp_fc2_b', _fp),
+        ('vp_out_w', _fp), ('vp_out_b', _fp),
+        ('gmm_M', C.c_int32), ('gmm_means', _fp), ('gmm_precisions', _fp), ('gmm_nll_weights', _fp),
+    ]
+
+
+class Weights(C.Structure):
+    _fields_ = [('data_weight', C.c_float), ('body_pose_weight', C.c_float),
+                ('shape_weight', C.c_float), ('bending_prior_weight', C.c_float),
+                ('coll_loss_weight', C.c_float), ('rho', C.c_float), ('flags', C.c_uint32)]
+
+
+class LbfgsOpts(C.Structure):
+    _fields_ = [('lr', C.c_float), ('max_iter', C.c_int32), ('history', C.c_int32),
+                ('tolerance_grad', C.c_float), ('tolerance_change', C.c_float),
+                ('maxiters', C.c_int32), ('ftol', C.c_float), ('gtol', C.c_float),
+                ('num_stages', C.c_int32), ('max_rounds', C.c_int32)]
+
+
+EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems',
+           'mvfit_closure', 'mvfit_vertices', 'mvfit_fit', 'mvfit_profile', 'mvfit_profile_read',
+           'mvfit_lbfgs_kat']
+
+
+def load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError('libmvfit.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          'or `make -C mvsmplfitting_amd/csrc` (expected %s)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mvfit_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.POINTER(Model)]
+    lib.mvfit_create.restype = C.c_int
+    lib.mvfit_destroy.argtypes = [vp]
+    lib.mvfit_destroy.restype = None
+    lib.mvfit_last_error.argtypes = [vp]
+    lib.mvfit_last_error.restype = C.c_char_p
+    lib.mvfit_sync.argtypes = [vp]
+    lib.mvfit_sync.restype = C.c_int
+    lib.mvfit_set_problems.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.mvfit_set_problems.restype = C.c_int
+    lib.mvfit_closure.argtypes = [vp, C.POINTER(Weights), vp, vp, vp, vp, vp]
+    lib.mvfit_closure.restype = C.c_int
+    lib.mvfit_vertices.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.mvfit_vertices.restype = C.c_int
+    lib.mvfit_fit.argtypes = [vp, C.POINTER(Weights), C.POINTER(LbfgsOpts), vp, vp, vp, vp]
+    lib.mvfit_fit.restype = C.c_int
+    lib.mvfit_profile.argtypes = [vp, C.c_int]
+    lib.mvfit_profile.restype = C.c_int
+    lib.mvfit_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.mvfit_profile_read.restype = C.c_int
+    lib.mvfit_lbfgs_kat.argtypes = [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(LbfgsOpts),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    lib.mvfit_lbfgs_kat.restype = C.c_int
+    return lib

@@ -1,0 +1,822 @@
+// libmvfit: C ABI (include/mvfit.h) + the per-problem step kernels.
+//
+// Kernels in this file (one workgroup per problem, see closure_device.h / lbfgs_device.h):
+//   prep_kernel        params -> pose operands of the vertex pass
+//   closure_kernel     one closure evaluation (loss, grad, keypoints) - the drop-in closure
+//   fit_step_kernel    one closure round of the device-resident fit: objective + adjoint from the
+//                      vertex-pass output, L-BFGS state-machine advance, pose operands of the next
+//                      trial point
+//   fit_sparse_kernel  the whole fit of one problem in a single launch (objective restricted to the
+//                      vertices it reads; no vertex pass inside the loop)
+//   lbfgs_kat_kernel   float64 instantiation of the state machine on analytic objectives
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "closure_device.h"
+
+namespace mvfit {
+
+hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
+                              hipStream_t stream);
+hipError_t vertex_pass_configure();
+
+constexpr int STEP_NT = 256;
+
+struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
+
+// per-problem optimiser storage in HBM
+struct FitBuffers {
+    LbState* S;          // [B]
+    float* vecs;         // [B][8][128]: x d g pg gprev bg0 bg1 xt
+    float* dirs;         // [B][100][128]
+    float* stps;         // [B][100][128]
+    double* ro;          // [B][100]
+    int* n_done;         // [1]
+};
+
+__device__ __forceinline__ void load_x(ClosureLds& L, const float* src, int tid, int nt) {
+    for (int i = tid; i < DPAD; i += nt) L.x[i] = (i < DV) ? src[i] : 0.f;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, DevPose P, const float* __restrict__ params,
+                                                       int xstride, uint32_t flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    load_x(L, params + (size_t)b * xstride, tid, STEP_NT);
+    pose_prep(M, L, flags, tid, STEP_NT);
+    publish_pose(L, P, b, tid, STEP_NT);
+}
+
+__global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, DevProblems Q, DevWeights W,
+                                                          const float* __restrict__ params,
+                                                          const float* __restrict__ verts,
+                                                          float* __restrict__ loss, float* __restrict__ grad,
+                                                          float* __restrict__ joints) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    load_x(L, params + (size_t)b * DV, tid, STEP_NT);
+    pose_prep(M, L, W.flags, tid, STEP_NT);
+    const float* vb = (verts && !(W.flags & MVFIT_F_SPARSE_VERTS)) ? verts + (size_t)b * M.nv * 3 : nullptr;
+    sparse_forward(M, L, vb, tid, STEP_NT);
+    const bool want_grad = grad != nullptr;
+    const double total = loss_and_keypoint_grad(M, L, Q, b, W, want_grad, tid, STEP_NT);
+    if (tid == 0 && loss) loss[b] = (float)total;
+    if (joints) for (int i = tid; i < NKP * 3; i += STEP_NT) joints[(size_t)b * NKP * 3 + i] = (&L.kp[0][0])[i];
+    if (want_grad) {
+        closure_backward(M, L, W, tid, STEP_NT);
+        for (int i = tid; i < DV; i += STEP_NT) grad[(size_t)b * DV + i] = L.grad[i];
+    }
+}
+
+// keypoints only (mvfit_vertices): gather from the vertex buffer
+__global__ __launch_bounds__(STEP_NT) void joints_kernel(DevModel M, const float* __restrict__ verts,
+                                                         float* __restrict__ joints) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < NKP * 3; i += STEP_NT) {
+        const int k = i / 3, a = i - 3 * k;
+        float s = 0.f;
+        for (int v = 0; v < M.ns; ++v)
+            s = fmaf(M.ksel_sub[k * NS_MAX + v], verts[((size_t)b * M.nv + M.sel_v[v]) * 3 + a], s);
+        joints[(size_t)b * NKP * 3 + i] = s;      // rows of the selection sum to 1 (+transl already in verts)
+    }
+}
+
+__device__ __forceinline__ void lb_load(LbVecs<float>& V, const float* base, int lane) {
+#pragma unroll
+    for (int r = 0; r < LB_NPL; ++r) {
+        const int i = lane + 64 * r;
+        V.x[r] = base[0 * 128 + i]; V.d[r] = base[1 * 128 + i]; V.g[r] = base[2 * 128 + i];
+        V.pg[r] = base[3 * 128 + i]; V.gprev[r] = base[4 * 128 + i]; V.bg0[r] = base[5 * 128 + i];
+        V.bg1[r] = base[6 * 128 + i];
+    }
+}
+__device__ __forceinline__ void lb_store(const LbVecs<float>& V, float* base, int lane) {
+#pragma unroll
+    for (int r = 0; r < LB_NPL; ++r) {
+        const int i = lane + 64 * r;
+        base[0 * 128 + i] = V.x[r]; base[1 * 128 + i] = V.d[r]; base[2 * 128 + i] = V.g[r];
+        base[3 * 128 + i] = V.pg[r]; base[4 * 128 + i] = V.gprev[r]; base[5 * 128 + i] = V.bg0[r];
+        base[6 * 128 + i] = V.bg1[r];
+    }
+}
+
+// initialise the optimiser state of every problem: x = params, first trial point = x
+__global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevPose P, FitBuffers F,
+                                                           const float* __restrict__ params, uint32_t flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* vb = F.vecs + (size_t)b * 8 * 128;
+    for (int i = tid; i < 8 * 128; i += STEP_NT) {
+        const int r = i >> 7, e = i & 127;
+        vb[i] = ((r == 0 || r == 7) && e < DV) ? params[(size_t)b * DV + e] : 0.f;
+    }
+    if (tid == 0) {
+        LbState s;
+        memset(&s, 0, sizeof(s));
+        s.phase = PH_STEP_START;
+        s.H = 1.0;
+        F.S[b] = s;
+    }
+    load_x(L, params + (size_t)b * DV, tid, STEP_NT);
+    pose_prep(M, L, flags, tid, STEP_NT);
+    publish_pose(L, P, b, tid, STEP_NT);
+}
+
+// shared by the two fit kernels: evaluate the closure at L.x, advance the optimiser, leave the
+// next trial point in L.x.  Returns true when the problem is finished.
+__device__ bool fit_round(const DevModel& M, ClosureLds& L, const DevProblems& Q, const StageWeights& SW,
+                          const LbOpts& O, LbState& S, LbVecs<float>& V, const LbHist<float>& H,
+                          const float* verts_b, int b, int tid) {
+    const DevWeights& W = SW.w[S.stage];
+    pose_prep(M, L, W.flags, tid, STEP_NT);
+    sparse_forward(M, L, verts_b, tid, STEP_NT);
+    const double total = loss_and_keypoint_grad(M, L, Q, b, W, true, tid, STEP_NT);
+    closure_backward(M, L, W, tid, STEP_NT);
+    if (tid < 64) {
+        float gnew[LB_NPL], xt[LB_NPL];
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) gnew[r] = L.grad[tid + 64 * r];
+        // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
+        lbfgs_advance<float>(S, V, H, O, (double)(float)total, gnew, xt, tid, DV);
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) L.x[tid + 64 * r] = xt[r];
+        if (tid == 0) { L.sh_stage = S.stage; L.sh_status = S.status; }
+    }
+    __syncthreads();
+    S.stage = L.sh_stage;            // waves 1.. only track the scalars they need
+    S.status = L.sh_status;
+    return S.status != 0;
+}
+
+__global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
+                                                           DevPose P, FitBuffers F,
+                                                           const float* __restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (F.S[b].status != 0) return;                       // uniform per block
+    float* vb = F.vecs + (size_t)b * 8 * 128;
+    load_x(L, vb + 7 * 128, tid, STEP_NT);
+    LbState S = F.S[b];
+    LbVecs<float> V;
+    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * 128, F.stps + (size_t)b * LB_HIST * 128,
+                    F.ro + (size_t)b * LB_HIST};
+    if (tid < 64) lb_load(V, vb, tid);
+    const bool done = fit_round(M, L, Q, SW, O, S, V, H, verts + (size_t)b * M.nv * 3, b, tid);
+    if (tid < 64) {
+        lb_store(V, vb, tid);
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) vb[7 * 128 + tid + 64 * r] = L.x[tid + 64 * r];
+        if (tid == 0) { F.S[b] = S; if (done) atomicAdd(F.n_done, 1); }
+    }
+    __syncthreads();
+    // pose operands of the next trial point (also after the last round: final vertices)
+    const uint32_t flags = SW.w[min(S.stage, O.num_stages - 1)].flags;
+    pose_prep(M, L, flags, tid, STEP_NT);
+    publish_pose(L, P, b, tid, STEP_NT);
+}
+
+__global__ __launch_bounds__(STEP_NT) void fit_sparse_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
+                                                             DevPose P, FitBuffers F, int max_rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (F.S[b].status != 0) return;
+    float* vb = F.vecs + (size_t)b * 8 * 128;
+    load_x(L, vb + 7 * 128, tid, STEP_NT);
+    LbState S = F.S[b];
+    LbVecs<float> V;
+    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * 128, F.stps + (size_t)b * LB_HIST * 128,
+                    F.ro + (size_t)b * LB_HIST};
+    if (tid < 64) lb_load(V, vb, tid);
+    for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
+        if (fit_round(M, L, Q, SW, O, S, V, H, nullptr, b, tid)) break;     // block-uniform
+    }
+    if (tid < 64) {
+        lb_store(V, vb, tid);
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) vb[7 * 128 + tid + 64 * r] = L.x[tid + 64 * r];
+        if (tid == 0) { F.S[b] = S; if (S.status) atomicAdd(F.n_done, 1); }
+    }
+    __syncthreads();
+    pose_prep(M, L, SW.w[min(S.stage, O.num_stages - 1)].flags, tid, STEP_NT);
+    publish_pose(L, P, b, tid, STEP_NT);
+}
+
+__global__ void fit_finish_kernel(FitBuffers F, float* __restrict__ params, float* __restrict__ final_loss,
+                                  int32_t* __restrict__ n_closure, int32_t* __restrict__ n_iter, int B,
+                                  int num_stages) {
+    const int b = blockIdx.x;
+    const float* vb = F.vecs + (size_t)b * 8 * 128;
+    for (int i = threadIdx.x; i < DV; i += blockDim.x) params[(size_t)b * DV + i] = vb[i];
+    if (threadIdx.x == 0) {
+        const LbState& s = F.S[b];
+        if (final_loss) final_loss[b] = (float)s.stage_final[num_stages - 1];
+        if (n_closure) n_closure[b] = s.n_closure;
+        if (n_iter) n_iter[b] = s.n_lbfgs;
+    }
+}
+
+// ------------------------------------------------------------------ float64 known-answer test
+__device__ double kat_eval(int kind, int D, const double* x, double* g) {
+    // mirrors oracle/lbfgs_np.py:kat_objective (serial: one lane)
+    double f = 0.0;
+    if (kind == 0) {
+        for (int i = 0; i < D; ++i) {
+            double c = 1.0 + 99.0 * i / (D - 1), r = x[i] - sin((double)i);
+            f += c * r * r; g[i] = c * r;
+        }
+        f *= 0.5;
+    } else if (kind == 1) {
+        for (int i = 0; i < D; ++i) g[i] = 0.0;
+        for (int i = 0; i < D - 1; ++i) {
+            double a = x[i + 1] - x[i] * x[i], bb = 1.0 - x[i];
+            f += 100.0 * a * a + bb * bb;
+            g[i] += -400.0 * a * x[i] - 2.0 * bb;
+            g[i + 1] += 200.0 * a;
+        }
+    } else {
+        const double rho2 = 1e4;
+        for (int i = 0; i < D; ++i) g[i] = x[i];
+        double q = 0.0;
+        for (int i = 0; i < D; ++i) {
+            int n = (i + 1) % D;
+            double r = 50.0 * (x[i] - sin((double)i)) + 20.0 * sin(3.0 * x[n]);
+            double r2 = r * r;
+            f += rho2 * r2 / (r2 + rho2);
+            q += x[i] * x[i];
+            double dr = 2.0 * r * rho2 * rho2 / ((r2 + rho2) * (r2 + rho2));
+            g[i] += 50.0 * dr;
+            g[n] += dr * 60.0 * cos(3.0 * x[n]);
+        }
+        f += 0.5 * q;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O, double* x_io, double* trace,
+                                                       int max_trace, int* n_closure, double* final_loss,
+                                                       double* dirs, double* stps, double* ro) {
+    __shared__ double xs[128], gs[128];
+    __shared__ double fsh;
+    const int lane = threadIdx.x;
+    LbState S;
+    memset(&S, 0, sizeof(S));
+    S.phase = PH_STEP_START; S.H = 1.0;
+    LbVecs<double> V;
+    LbHist<double> H{dirs, stps, ro};
+#pragma unroll
+    for (int r = 0; r < LB_NPL; ++r) {
+        const int i = lane + 64 * r;
+        V.x[r] = i < D ? x_io[i] : 0.0;
+        V.d[r] = V.g[r] = V.pg[r] = V.gprev[r] = V.bg0[r] = V.bg1[r] = 0.0;
+    }
+    double xt[LB_NPL];
+#pragma unroll
+    for (int r = 0; r < LB_NPL; ++r) xt[r] = V.x[r];
+    int ncl = 0;
+    for (int round = 0; round < 100000; ++round) {
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) xs[lane + 64 * r] = xt[r];
+        __syncthreads();
+        if (lane == 0) fsh = kat_eval(kind, D, xs, gs);
+        __syncthreads();
+        const double f = fsh;
+        if (ncl < max_trace && lane == 0) {
+            for (int i = 0; i < D; ++i) trace[(size_t)ncl * (D + 1) + i] = xs[i];
+            trace[(size_t)ncl * (D + 1) + D] = f;
+        }
+        ncl += 1;
+        double gnew[LB_NPL];
+#pragma unroll
+        for (int r = 0; r < LB_NPL; ++r) gnew[r] = (lane + 64 * r < D) ? gs[lane + 64 * r] : 0.0;
+        __syncthreads();
+        lbfgs_advance<double>(S, V, H, O, f, gnew, xt, lane, D);
+        if (S.status) break;
+    }
+#pragma unroll
+    for (int r = 0; r < LB_NPL; ++r) if (lane + 64 * r < D) x_io[lane + 64 * r] = V.x[r];
+    if (lane == 0) { *n_closure = ncl; *final_loss = S.stage_final[0]; }
+}
+
+}  // namespace mvfit
+
+// ==================================================================================== host side
+using namespace mvfit;
+
+struct mvfit_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevModel M{};
+    std::vector<void*> allocs;
+    int nv = 0;
+    // problems
+    DevProblems Q{};
+    int B = 0, Bpad = 0, V = 0;
+    float *d_camR = nullptr, *d_camt = nullptr, *d_camf = nullptr, *d_camc = nullptr, *d_gt = nullptr, *d_wc = nullptr;
+    // per-problem work buffers
+    DevPose P{};
+    float* d_verts = nullptr;          // [B][nv][3] internal vertex buffer
+    FitBuffers F{};
+    int ksplit = 4;
+    bool has_vposer = false;
+    int gmm_M = 0;
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
+};
+
+static int fail(mvfit_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIP_OK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) return fail(c, MVFIT_E_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+template <typename T>
+static T* dev_upload(mvfit_ctx* c, const std::vector<T>& h) {
+    T* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
+    c->allocs.push_back(d);
+    if (!h.empty()) hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+
+static size_t step_lds() { return sizeof(ClosureLds); }
+
+extern "C" const char* mvfit_last_error(const mvfit_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* m) {
+    if (!out || !m || !m->v_template || !m->shapedirs || !m->posedirs || !m->J_regressor || !m->parents ||
+        !m->lbs_weights || !m->kp_regressor || !m->face_vertex_ids || !m->joint_map || m->num_verts <= 0)
+        return MVFIT_E_ARG;
+    mvfit_ctx* c = new mvfit_ctx();
+    *out = c;
+    c->device = device;
+    HIP_OK(c, hipSetDevice(device));
+    c->stream = (hipStream_t)hip_stream;
+    const int nv = m->num_verts;
+    c->nv = nv;
+    DevModel& M = c->M;
+    M.nv = nv;
+    M.ntiles = (nv + TILE_V - 1) / TILE_V;
+    M.nv_pad = M.ntiles * TILE_V;
+    if (m->parents[0] >= 0) return fail(c, MVFIT_E_ARG, "parents[0] must be -1");
+
+    // ---- blendshape basis, re-tiled in MFMA B-operand order: [tile][coord][group][lane][4] ----
+    // element (tile T, coord k, group g, lane l, q): row p = 2*(4g+q) + (l>>5), vertex v = 32T + (l&31)
+    // rows 0..206 posedirs, 207..216 shapedirs (beta index), rest zero.
+    {
+        std::vector<float> bs((size_t)M.ntiles * 3 * KGROUPS * 64 * 4, 0.f);
+        for (int T = 0; T < M.ntiles; ++T)
+            for (int k = 0; k < 3; ++k)
+                for (int g = 0; g < KGROUPS; ++g)
+                    for (int l = 0; l < 64; ++l)
+                        for (int q = 0; q < 4; ++q) {
+                            const int p = 2 * (4 * g + q) + (l >> 5);
+                            const int v = TILE_V * T + (l & 31);
+                            float val = 0.f;
+                            if (v < nv) {
+                                if (p < 207) val = m->posedirs[(size_t)p * nv * 3 + 3 * v + k];
+                                else if (p < 217) val = m->shapedirs[((size_t)v * 3 + k) * 10 + (p - 207)];
+                            }
+                            bs[((((size_t)T * 3 + k) * KGROUPS + g) * 64 + l) * 4 + q] = val;
+                        }
+        M.bs4 = dev_upload(c, bs);
+        std::vector<float> vtp((size_t)3 * M.nv_pad, 0.f);
+        for (int v = 0; v < nv; ++v)
+            for (int k = 0; k < 3; ++k) vtp[(size_t)k * M.nv_pad + v] = m->v_template[3 * v + k];
+        M.vt_planes = dev_upload(c, vtp);
+        std::vector<float> wt((size_t)M.ntiles * NJ * 32, 0.f);
+        for (int v = 0; v < nv; ++v)
+            for (int j = 0; j < NJ; ++j)
+                wt[((size_t)(v / 32) * NJ + j) * 32 + (v % 32)] = m->lbs_weights[(size_t)v * NJ + j];
+        M.wt_tiles = dev_upload(c, wt);
+    }
+    // ---- joints as an affine function of beta (float64 accumulation on the host) ----
+    {
+        std::vector<float> Jt(NJ * 3), JS(NJ * 3 * 10);
+        for (int j = 0; j < NJ; ++j)
+            for (int a = 0; a < 3; ++a) {
+                double s = 0.0, sl[10] = {0};
+                for (int v = 0; v < nv; ++v) {
+                    const double w = m->J_regressor[(size_t)j * nv + v];
+                    if (w == 0.0) continue;
+                    s += w * m->v_template[3 * v + a];
+                    for (int l = 0; l < 10; ++l) sl[l] += w * m->shapedirs[((size_t)v * 3 + a) * 10 + l];
+                }
+                Jt[j * 3 + a] = (float)s;
+                for (int l = 0; l < 10; ++l) JS[(j * 3 + a) * 10 + l] = (float)sl[l];
+            }
+        M.J_t = dev_upload(c, Jt);
+        M.J_S = dev_upload(c, JS);
+    }
+    // ---- the vertices the objective reads: non-zero columns of the mapped 17 x Nv selection ----
+    {
+        std::vector<double> ksel((size_t)NKP * nv, 0.0);
+        for (int k = 0; k < NKP; ++k) {
+            const int src = m->joint_map[k];
+            if (src < 0 || src >= 19) return fail(c, MVFIT_E_ARG, "joint_map entry out of range");
+            if (src < 14) for (int v = 0; v < nv; ++v) ksel[(size_t)k * nv + v] = m->kp_regressor[(size_t)src * nv + v];
+            else {
+                const int v = m->face_vertex_ids[src - 14];
+                if (v < 0 || v >= nv) return fail(c, MVFIT_E_ARG, "face vertex id out of range");
+                ksel[(size_t)k * nv + v] = 1.0;
+            }
+        }
+        std::vector<int> sel;
+        for (int v = 0; v < nv; ++v) {
+            bool nz = false;
+            for (int k = 0; k < NKP; ++k) nz |= ksel[(size_t)k * nv + v] != 0.0;
+            if (nz) sel.push_back(v);
+        }
+        if ((int)sel.size() > NS_MAX) return fail(c, MVFIT_E_UNSUPPORTED, "keypoint regressor touches %d vertices (max %d)", (int)sel.size(), NS_MAX);
+        M.ns = (int)sel.size();
+        M.nc = 3 * M.ns;
+        M.nc_pad = (M.nc + 3) & ~3;
+        M.sel_v = dev_upload(c, sel);
+        std::vector<float> vts(M.nc_pad, 0.f), pds((size_t)KROWS * M.nc_pad, 0.f), pdsT((size_t)M.nc_pad * KROWS, 0.f),
+            ws((size_t)M.ns * NJ), ks((size_t)NKP * NS_MAX, 0.f);
+        for (int s = 0; s < M.ns; ++s) {
+            const int v = sel[s];
+            for (int a = 0; a < 3; ++a) {
+                const int cidx = 3 * s + a;
+                vts[cidx] = m->v_template[3 * v + a];
+                for (int p = 0; p < 217; ++p) {
+                    const float val = p < 207 ? m->posedirs[(size_t)p * nv * 3 + 3 * v + a]
+                                              : m->shapedirs[((size_t)v * 3 + a) * 10 + (p - 207)];
+                    pds[(size_t)p * M.nc_pad + cidx] = val;
+                    pdsT[(size_t)cidx * KROWS + p] = val;
+                }
+            }
+            for (int j = 0; j < NJ; ++j) ws[(size_t)s * NJ + j] = m->lbs_weights[(size_t)v * NJ + j];
+            for (int k = 0; k < NKP; ++k) ks[(size_t)k * NS_MAX + s] = (float)ksel[(size_t)k * nv + v];
+        }
+        M.vt_sub = dev_upload(c, vts);
+        M.pd_sub = dev_upload(c, pds);
+        M.pd_subT = dev_upload(c, pdsT);
+        M.w_sub = dev_upload(c, ws);
+        M.ksel_sub = dev_upload(c, ks);
+    }
+    // ---- kinematic tree: levels and child lists ----
+    {
+        int depth[NJ];
+        for (int j = 0; j < NJ; ++j) {
+            M.parents[j] = m->parents[j];
+            if (j > 0 && (m->parents[j] < 0 || m->parents[j] >= j)) return fail(c, MVFIT_E_ARG, "parents must be topologically ordered");
+            depth[j] = j == 0 ? 0 : depth[m->parents[j]] + 1;
+        }
+        int maxd = 0;
+        for (int j = 0; j < NJ; ++j) maxd = std::max(maxd, depth[j]);
+        M.nlevels = maxd + 1;
+        int pos = 0;
+        for (int lv = 0; lv <= maxd; ++lv) {
+            M.level_start[lv] = pos;
+            for (int j = 0; j < NJ; ++j) if (depth[j] == lv) M.level_joints[pos++] = j;
+        }
+        M.level_start[maxd + 1] = pos;
+        pos = 0;
+        for (int p = 0; p < NJ; ++p) {
+            M.child_start[p] = pos;
+            for (int j = 1; j < NJ; ++j) if (m->parents[j] == p) M.child_list[pos++] = j;
+        }
+        M.child_start[NJ] = pos;
+    }
+    // ---- VPoser decoder ----
+    if (m->vp_fc1_w) {
+        if (!m->vp_fc1_b || !m->vp_fc2_w || !m->vp_fc2_b || !m->vp_out_w || !m->vp_out_b) return fail(c, MVFIT_E_ARG, "incomplete vposer weights");
+        std::vector<float> w1(m->vp_fc1_w, m->vp_fc1_w + 512 * 32), b1(m->vp_fc1_b, m->vp_fc1_b + 512),
+            w2(m->vp_fc2_w, m->vp_fc2_w + 512 * 512), b2(m->vp_fc2_b, m->vp_fc2_b + 512),
+            w3(m->vp_out_w, m->vp_out_w + 138 * 512), b3(m->vp_out_b, m->vp_out_b + 138);
+        std::vector<float> w1T(32 * 512), w2T(512 * 512), w3T(512 * 144, 0.f);
+        for (int o = 0; o < 512; ++o) for (int i = 0; i < 32; ++i) w1T[i * 512 + o] = w1[o * 32 + i];
+        for (int o = 0; o < 512; ++o) for (int i = 0; i < 512; ++i) w2T[i * 512 + o] = w2[o * 512 + i];
+        for (int o = 0; o < 138; ++o) for (int i = 0; i < 512; ++i) w3T[i * 144 + o] = w3[o * 512 + i];
+        M.vp_w1 = dev_upload(c, w1); M.vp_b1 = dev_upload(c, b1);
+        M.vp_w2 = dev_upload(c, w2); M.vp_b2 = dev_upload(c, b2);
+        M.vp_w3 = dev_upload(c, w3); M.vp_b3 = dev_upload(c, b3);
+        M.vp_w1T = dev_upload(c, w1T); M.vp_w2T = dev_upload(c, w2T); M.vp_w3T = dev_upload(c, w3T);
+        c->has_vposer = true;
+    }
+    // ---- GMM ----
+    if (m->gmm_M > 0) {
+        if (m->gmm_M > 8 || !m->gmm_means || !m->gmm_precisions || !m->gmm_nll_weights) return fail(c, MVFIT_E_ARG, "gmm: M <= 8 and all arrays required");
+        M.gmm_M = m->gmm_M;
+        std::vector<float> mu(m->gmm_means, m->gmm_means + m->gmm_M * 69),
+            pr(m->gmm_precisions, m->gmm_precisions + (size_t)m->gmm_M * 69 * 69), lw(m->gmm_M);
+        for (int i = 0; i < m->gmm_M; ++i) lw[i] = logf(m->gmm_nll_weights[i]);
+        M.gmm_means = dev_upload(c, mu); M.gmm_prec = dev_upload(c, pr); M.gmm_lognw = dev_upload(c, lw);
+        c->gmm_M = m->gmm_M;
+    }
+    for (void* p : c->allocs) if (!p) return fail(c, MVFIT_E_HIP, "device allocation failed");
+    HIP_OK(c, vertex_pass_configure());
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_sparse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipDeviceSynchronize());
+    return MVFIT_OK;
+}
+
+static void free_problem_buffers(mvfit_ctx* c) {
+    void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
+                  c->d_verts, c->F.S, c->F.vecs, c->F.dirs, c->F.stps, c->F.ro, c->F.n_done};
+    for (void* p : ps) if (p) hipFree(p);
+    c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
+    c->P = DevPose{};
+    c->d_verts = nullptr;
+    c->F = FitBuffers{};
+}
+
+extern "C" void mvfit_destroy(mvfit_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_problem_buffers(c);
+    for (void* p : c->allocs) if (p) hipFree(p);
+    for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->ev_step) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+}
+
+extern "C" int mvfit_sync(mvfit_ctx* c) {
+    if (!c) return MVFIT_E_ARG;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, const float* cam_R, const float* cam_t,
+                                  const float* cam_f, const float* cam_c, const float* gt_xy, const float* w_conf) {
+    if (!c) return MVFIT_E_ARG;
+    if (B <= 0 || V <= 0 || V > MVFIT_MAX_VIEWS || !cam_R || !cam_t || !cam_f || !cam_c || !gt_xy || !w_conf)
+        return fail(c, MVFIT_E_ARG, "set_problems: bad argument (B=%d V=%d, V <= %d)", B, V, MVFIT_MAX_VIEWS);
+    HIP_OK(c, hipSetDevice(c->device));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (B != c->B || V != c->V || (cam_batched != 0) != (c->Q.cam_batched != 0)) {
+        free_problem_buffers(c);
+        const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
+        const int Bpad = (B + 31) / 32 * 32;
+        HIP_OK(c, hipMalloc(&c->d_camR, nc * 9 * 4)); HIP_OK(c, hipMalloc(&c->d_camt, nc * 3 * 4));
+        HIP_OK(c, hipMalloc(&c->d_camf, nc * 4)); HIP_OK(c, hipMalloc(&c->d_camc, nc * 2 * 4));
+        HIP_OK(c, hipMalloc(&c->d_gt, (size_t)B * V * NKP * 2 * 4)); HIP_OK(c, hipMalloc(&c->d_wc, (size_t)B * V * NKP * 4));
+        HIP_OK(c, hipMalloc(&c->P.coefT, (size_t)Bpad * KROWS * 4)); HIP_OK(c, hipMalloc(&c->P.Amat, (size_t)Bpad * 288 * 4));
+        HIP_OK(c, hipMalloc(&c->P.tau, (size_t)Bpad * 4 * 4));
+        HIP_OK(c, hipMemset(c->P.coefT, 0, (size_t)Bpad * KROWS * 4));
+        HIP_OK(c, hipMalloc(&c->d_verts, (size_t)B * c->nv * 3 * 4));
+        HIP_OK(c, hipMalloc(&c->F.S, (size_t)B * sizeof(LbState)));
+        HIP_OK(c, hipMalloc(&c->F.vecs, (size_t)B * 8 * 128 * 4));
+        HIP_OK(c, hipMalloc(&c->F.dirs, (size_t)B * LB_HIST * 128 * 4));
+        HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * 128 * 4));
+        HIP_OK(c, hipMalloc(&c->F.ro, (size_t)B * LB_HIST * 8));
+        HIP_OK(c, hipMalloc(&c->F.n_done, 4));
+        c->B = B; c->V = V; c->Bpad = Bpad;
+    }
+    const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
+    HIP_OK(c, hipMemcpyAsync(c->d_camR, cam_R, nc * 9 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_camt, cam_t, nc * 3 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_camf, cam_f, nc * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_camc, cam_c, nc * 2 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_gt, gt_xy, (size_t)B * V * NKP * 2 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_wc, w_conf, (size_t)B * V * NKP * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    c->Q = DevProblems{B, V, cam_batched ? 1 : 0, c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc};
+    return MVFIT_OK;
+}
+
+static int check_flags(mvfit_ctx* c, uint32_t flags) {
+    if ((flags & MVFIT_F_VPOSER) && !c->has_vposer) return fail(c, MVFIT_E_STATE, "MVFIT_F_VPOSER set but the model has no VPoser decoder");
+    if ((flags & MVFIT_F_PRIOR_GMM) && c->gmm_M == 0) return fail(c, MVFIT_E_STATE, "MVFIT_F_PRIOR_GMM set but the model has no GMM");
+    return MVFIT_OK;
+}
+
+static DevWeights to_dev(const mvfit_weights& w) {
+    DevWeights d;
+    d.data_w2 = w.data_weight * w.data_weight;
+    d.pose_w = w.body_pose_weight; d.shape_w = w.shape_weight; d.bend_w = w.bending_prior_weight;
+    d.coll_w = w.coll_loss_weight; d.rho2 = w.rho * w.rho; d.flags = w.flags; d.pad = 0;
+    return d;
+}
+
+static void prof_begin(mvfit_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs) {
+    if (!c->profile || evs.size() >= 4096) return;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, c->stream);
+    evs.emplace_back(a, b);
+}
+static void prof_end(mvfit_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs) {
+    if (!c->profile || evs.empty()) return;
+    hipEventRecord(evs.back().second, c->stream);
+}
+
+static int run_vertex_pass(mvfit_ctx* c, float* verts) {
+    prof_begin(c, c->ev_vp);
+    hipError_t e = launch_vertex_pass(c->M, c->P, c->B, verts, c->ksplit, c->stream);
+    prof_end(c, c->ev_vp);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_vertices(mvfit_ctx* c, const float* params, uint32_t flags, float* verts, float* joints) {
+    if (!c || !params || !verts) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    int rc = check_flags(c, flags);
+    if (rc) return rc;
+    HIP_OK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, params, DV, flags);
+    HIP_OK(c, hipGetLastError());
+    rc = run_vertex_pass(c, verts);
+    if (rc) return rc;
+    if (joints) {
+        hipLaunchKernelGGL(joints_kernel, dim3(c->B), dim3(STEP_NT), 0, c->stream, c->M, verts, joints);
+        HIP_OK(c, hipGetLastError());
+    }
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* params, float* loss, float* grad,
+                             float* verts, float* joints) {
+    if (!c || !w || !params || !loss) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    int rc = check_flags(c, w->flags);
+    if (rc) return rc;
+    if (w->coll_loss_weight > 0.f) return fail(c, MVFIT_E_UNSUPPORTED, "SDF collision term is not built yet (coll_loss_weight must be 0)");
+    HIP_OK(c, hipSetDevice(c->device));
+    float* vbuf = verts ? verts : c->d_verts;
+    const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0;
+    if (!sparse || verts) {
+        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, params, DV, w->flags);
+        HIP_OK(c, hipGetLastError());
+        rc = run_vertex_pass(c, vbuf);
+        if (rc) return rc;
+    }
+    prof_begin(c, c->ev_step);
+    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, to_dev(*w), params,
+                       sparse ? (const float*)nullptr : (const float*)vbuf, loss, grad, joints);
+    prof_end(c, c->ev_step);
+    HIP_OK(c, hipGetLastError());
+    return MVFIT_OK;
+}
+
+static int make_opts(mvfit_ctx* c, const mvfit_lbfgs_opts* o, uint32_t flags, LbOpts& O) {
+    if (o->max_iter <= 0 || o->history <= 0 || o->history > MVFIT_HISTORY || o->maxiters <= 0 || o->num_stages <= 0 ||
+        o->num_stages > MVFIT_MAX_STAGES)
+        return fail(c, MVFIT_E_ARG, "bad lbfgs options");
+    O.lr = o->lr; O.tol_grad = o->tolerance_grad; O.tol_change = o->tolerance_change; O.ftol = o->ftol; O.gtol = o->gtol;
+    O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
+    O.num_stages = o->num_stages;
+    // parameter tensors that take part in the gtol test (fitting.py:115-116): requires_grad ones
+    int n = 0;
+    auto add = [&](int lo, int hi) { O.seg_lo[n] = lo; O.seg_hi[n] = hi; ++n; };
+    if (!(flags & MVFIT_F_FIX_SHAPE)) add(X_BETAS, X_GO);
+    add(X_GO, X_BP);
+    if (!(flags & MVFIT_F_VPOSER)) add(X_BP, X_TR);
+    add(X_TR, X_SC);
+    if (!(flags & MVFIT_F_FIX_SCALE)) add(X_SC, X_EMB);
+    if (flags & MVFIT_F_VPOSER) add(X_EMB, DV);
+    O.nseg = n;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfgs_opts* o, float* params,
+                         float* final_loss, int32_t* n_closure, int32_t* n_iter) {
+    if (!c || !sw || !o || !params) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    HIP_OK(c, hipSetDevice(c->device));
+    StageWeights SW;
+    memset(&SW, 0, sizeof(SW));
+    if (o->num_stages <= 0 || o->num_stages > MVFIT_MAX_STAGES) return fail(c, MVFIT_E_ARG, "num_stages");
+    for (int s = 0; s < o->num_stages; ++s) {
+        int rc = check_flags(c, sw[s].flags);
+        if (rc) return rc;
+        if (sw[s].flags != sw[0].flags) return fail(c, MVFIT_E_ARG, "flags must be identical for all stages");
+        if (sw[s].coll_loss_weight > 0.f) return fail(c, MVFIT_E_UNSUPPORTED, "SDF collision term is not built yet");
+        SW.w[s] = to_dev(sw[s]);
+    }
+    LbOpts O;
+    int rc = make_opts(c, o, sw[0].flags, O);
+    if (rc) return rc;
+    const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0;
+    const int B = c->B;
+    HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
+    hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, c->F, params, sw[0].flags);
+    HIP_OK(c, hipGetLastError());
+    int* h_done = nullptr;
+    HIP_OK(c, hipHostMalloc(&h_done, 4));
+    *h_done = 0;
+    int rounds = 0;
+    const int cap = o->max_rounds > 0 ? o->max_rounds : (o->num_stages * o->maxiters * (O.max_eval + 30) + 8);
+    if (sparse) {
+        while (rounds < cap) {
+            const int chunk = 4096;
+            hipLaunchKernelGGL(fit_sparse_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F, chunk);
+            HIP_OK(c, hipGetLastError());
+            rounds += chunk;
+            HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(c, hipStreamSynchronize(c->stream));
+            if (*h_done >= B) break;
+        }
+    } else {
+        const int batch = 32;      // rounds enqueued between two looks at the done counter
+        while (rounds < cap) {
+            for (int r = 0; r < batch; ++r) {
+                rc = run_vertex_pass(c, c->d_verts);
+                if (rc) { hipHostFree(h_done); return rc; }
+                prof_begin(c, c->ev_step);
+                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F,
+                                   (const float*)c->d_verts);
+                prof_end(c, c->ev_step);
+            }
+            HIP_OK(c, hipGetLastError());
+            rounds += batch;
+            HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(c, hipStreamSynchronize(c->stream));
+            if (*h_done >= B) break;
+        }
+    }
+    const bool finished = *h_done >= B;
+    hipHostFree(h_done);
+    hipLaunchKernelGGL(fit_finish_kernel, dim3(B), dim3(128), 0, c->stream, c->F, params, final_loss, n_closure, n_iter, B,
+                       o->num_stages);
+    HIP_OK(c, hipGetLastError());
+    if (!finished) return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished", cap);
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_profile(mvfit_ctx* c, int enable) {
+    if (!c) return MVFIT_E_ARG;
+    c->profile = enable != 0;
+    return MVFIT_OK;
+}
+
+static double drain(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, int* n) {
+    double tot = 0.0;
+    int cnt = 0;
+    for (auto& e : evs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++cnt; }
+        hipEventDestroy(e.first); hipEventDestroy(e.second);
+    }
+    evs.clear();
+    *n = cnt;
+    return cnt ? tot / cnt : 0.0;
+}
+
+extern "C" int mvfit_profile_read(mvfit_ctx* c, double* vp_ms, int* launches, double* step_ms, int* step_launches) {
+    if (!c) return MVFIT_E_ARG;
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    int n1 = 0, n2 = 0;
+    double a = drain(c->ev_vp, &n1), b = drain(c->ev_step, &n2);
+    if (vp_ms) *vp_ms = a;
+    if (launches) *launches = n1;
+    if (step_ms) *step_ms = b;
+    if (step_launches) *step_launches = n2;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs, int nseg, const mvfit_lbfgs_opts* o,
+                               double* x_inout, double* trace, int max_trace, int* n_closure, double* final_loss) {
+    if (!o || !x_inout || D <= 1 || D > 128 || nseg < 1 || nseg > 8 || !segs) return MVFIT_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return MVFIT_E_HIP;
+    LbOpts O;
+    O.lr = o->lr; O.tol_grad = o->tolerance_grad; O.tol_change = o->tolerance_change; O.ftol = o->ftol; O.gtol = o->gtol;
+    O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
+    O.num_stages = 1; O.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) { O.seg_lo[i] = segs[i]; O.seg_hi[i] = segs[i + 1]; }
+    double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro;
+    int* dn;
+    const size_t tb = (size_t)std::max(max_trace, 1) * (D + 1) * 8;
+    if (hipMalloc(&dx, 128 * 8) || hipMalloc(&dtrace, tb) || hipMalloc(&dfl, 8) || hipMalloc(&dn, 4) ||
+        hipMalloc(&ddirs, LB_HIST * 128 * 8) || hipMalloc(&dstps, LB_HIST * 128 * 8) || hipMalloc(&dro, LB_HIST * 8))
+        return MVFIT_E_HIP;
+    hipMemcpy(dx, x_inout, D * 8, hipMemcpyHostToDevice);
+    hipMemset(dtrace, 0, tb);
+    hipLaunchKernelGGL(lbfgs_kat_kernel, dim3(1), dim3(64), 0, 0, kind, D, O, dx, dtrace, max_trace, dn, dfl, ddirs, dstps, dro);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(x_inout, dx, D * 8, hipMemcpyDeviceToHost);
+    if (trace && max_trace > 0) hipMemcpy(trace, dtrace, tb, hipMemcpyDeviceToHost);
+    if (n_closure) hipMemcpy(n_closure, dn, 4, hipMemcpyDeviceToHost);
+    if (final_loss) hipMemcpy(final_loss, dfl, 8, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dtrace); hipFree(dfl); hipFree(dn); hipFree(ddirs); hipFree(dstps); hipFree(dro);
+    return e == hipSuccess ? MVFIT_OK : MVFIT_E_HIP;
+}

@@ -1,0 +1,240 @@
+"""Host-side handle on libmvfit: one ``MvFit`` = one mvfit_ctx = one GPU + one stream.
+
+PyTorch is used only as the device-memory container (tensors' ``data_ptr()`` cross the C ABI);
+every number is produced by the HIP kernels in mvsmplfitting_amd/csrc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+D = _lib.D
+D_MODEL = _lib.D_MODEL
+
+# slices of the flat parameter vector (include/mvfit.h)
+SL = dict(betas=(0, 10), global_orient=(10, 13), body_pose=(13, 82), transl=(82, 85),
+          scale=(85, 86), pose_embedding=(86, 118))
+
+# reference cfg_files/fit_smpl.yaml:40-68
+YAML_POSE_W = (404.0, 404.0, 57.4, 4.78)
+YAML_SHAPE_W = (100.0, 50.0, 10.0, 5.0)
+
+
+class MvFitError(RuntimeError):
+    pass
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def stage_weights(image_height: float, flags: int = 0, rho: float = 100.0,
+                  pose_w=YAML_POSE_W, shape_w=YAML_SHAPE_W, coll_w=None):
+    """Per-stage weights exactly as non_linear_solver builds them (reference
+    code/utils/non_linear_solver.py:109-124,148-150,177-180): data_weight = 500/H,
+    bending = 3.17 * body_pose_weight."""
+    out = []
+    for s in range(len(pose_w)):
+        out.append(dict(data_weight=500.0 / image_height, body_pose_weight=pose_w[s],
+                        shape_weight=shape_w[s], bending_prior_weight=3.17 * pose_w[s],
+                        coll_loss_weight=0.0 if coll_w is None else coll_w[s], rho=rho, flags=flags))
+    return out
+
+
+class MvFit:
+    def __init__(self, model: dict, vposer: dict | None = None, gmm=None, device: int = 0):
+        """model: dict from mvsmplfitting_amd.synthetic.make_body_model (or real SMPL arrays with the
+        same keys); vposer: decoder weight dict; gmm: (means, precisions, nll_weights)."""
+        if not torch.cuda.is_available():
+            raise MvFitError('MvFit needs a HIP device (torch.cuda.is_available() is False); '
+                             'there is no CPU fallback')
+        self._lib = _lib.load()
+        self.device = torch.device('cuda', device)
+        self.nv = int(model['v_template'].shape[0])
+        keep = []
+
+        def fp(a):
+            a = _f32(a)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_float))
+
+        def ip(a):
+            a = _i32(a)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_int32))
+        m = _lib.Model()
+        m.num_verts = self.nv
+        m.num_faces = int(model['faces'].shape[0]) if model.get('faces') is not None else 0
+        m.v_template = fp(model['v_template'])
+        m.shapedirs = fp(model['shapedirs'])
+        m.posedirs = fp(model['posedirs'])
+        m.J_regressor = fp(model['J_regressor'])
+        m.parents = ip(model['parents'])
+        m.lbs_weights = fp(model['lbs_weights'])
+        m.kp_regressor = fp(model['kp_regressor'])
+        m.face_vertex_ids = ip(model['face_vertex_ids'])
+        m.joint_map = ip(model['joint_map'])
+        m.faces = ip(model['faces']) if model.get('faces') is not None else None
+        if vposer is not None:
+            m.vp_fc1_w = fp(vposer['fc1_w']); m.vp_fc1_b = fp(vposer['fc1_b'])
+            m.vp_fc2_w = fp(vposer['fc2_w']); m.vp_fc2_b = fp(vposer['fc2_b'])
+            m.vp_out_w = fp(vposer['out_w']); m.vp_out_b = fp(vposer['out_b'])
+        if gmm is not None:
+            means, prec, nllw = gmm
+            m.gmm_M = int(means.shape[0])
+            m.gmm_means = fp(means); m.gmm_precisions = fp(prec); m.gmm_nll_weights = fp(nllw)
+        self.has_vposer = vposer is not None
+        self.has_gmm = gmm is not None
+        ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = self._lib.mvfit_create(C.byref(ctx), device, C.c_void_p(stream), C.byref(m))
+        self._ctx = ctx
+        self._check(rc)
+        self.B = 0
+        self.V = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.mvfit_last_error(self._ctx)
+            raise MvFitError('libmvfit error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.mvfit_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _dev(self, a, shape=None):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(_f32(a))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None:
+            assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+        return t
+
+    @staticmethod
+    def _weights(w: dict) -> _lib.Weights:
+        return _lib.Weights(w['data_weight'], w['body_pose_weight'], w['shape_weight'],
+                            w['bending_prior_weight'], w.get('coll_loss_weight', 0.0),
+                            w.get('rho', 100.0), int(w.get('flags', 0)))
+
+    def sync(self):
+        self._check(self._lib.mvfit_sync(self._ctx))
+
+    # ------------------------------------------------------------------ inputs
+    def set_problems(self, cams, gt_xy, w_conf):
+        """cams = (R[V,3,3] | [B,V,3,3], t, f, c); gt_xy[B,V,17,2]; w_conf[B,V,17]."""
+        cam_R, cam_t, cam_f, cam_c = cams
+        gt = self._dev(gt_xy)
+        B, V = int(gt.shape[0]), int(gt.shape[1])
+        wc = self._dev(w_conf, (B, V, 17))
+        batched = 1 if np.ndim(cam_R) == 4 else 0
+        R, t, f, c = self._dev(cam_R), self._dev(cam_t), self._dev(cam_f), self._dev(cam_c)
+        self._check(self._lib.mvfit_set_problems(
+            self._ctx, B, V, batched, R.data_ptr(), t.data_ptr(), f.data_ptr(), c.data_ptr(),
+            gt.data_ptr(), wc.data_ptr()))
+        self.B, self.V = B, V
+
+    # ------------------------------------------------------------------ compute
+    def closure(self, params, weights: dict, want_grad=True, want_verts=False, want_joints=False):
+        """One closure evaluation of all B problems.  params [B,118] (tensor or array).
+        Returns dict(loss[B], grad[B,118]?, verts[B,Nv,3]?, joints[B,17,3]?) of CUDA tensors."""
+        x = self._dev(params, (self.B, D))
+        out = dict(loss=torch.empty(self.B, device=self.device, dtype=torch.float32))
+        grad = torch.empty(self.B, D, device=self.device) if want_grad else None
+        verts = torch.empty(self.B, self.nv, 3, device=self.device) if want_verts else None
+        joints = torch.empty(self.B, 17, 3, device=self.device) if want_joints else None
+        w = self._weights(weights)
+        self._check(self._lib.mvfit_closure(
+            self._ctx, C.byref(w), x.data_ptr(), out['loss'].data_ptr(),
+            grad.data_ptr() if want_grad else None, verts.data_ptr() if want_verts else None,
+            joints.data_ptr() if want_joints else None))
+        if want_grad:
+            out['grad'] = grad
+        if want_verts:
+            out['verts'] = verts
+        if want_joints:
+            out['joints'] = joints
+        return out
+
+    def vertices(self, params, flags=0):
+        x = self._dev(params, (self.B, D))
+        verts = torch.empty(self.B, self.nv, 3, device=self.device)
+        joints = torch.empty(self.B, 17, 3, device=self.device)
+        self._check(self._lib.mvfit_vertices(self._ctx, x.data_ptr(), flags, verts.data_ptr(),
+                                             joints.data_ptr()))
+        return verts, joints
+
+    def fit(self, params, stages, lr=1.0, max_iter=30, history=100, tolerance_grad=1e-5,
+            tolerance_change=1e-9, maxiters=30, ftol=1e-9, gtol=1e-9, max_rounds=0):
+        """Device-resident staged fit.  params [B,118] -> (params_out tensor, stats dict)."""
+        x = self._dev(params, (self.B, D)).clone()
+        arr = (_lib.Weights * len(stages))(*[self._weights(s) for s in stages])
+        o = _lib.LbfgsOpts(lr, max_iter, history, tolerance_grad, tolerance_change, maxiters, ftol,
+                           gtol, len(stages), max_rounds)
+        final = torch.empty(self.B, device=self.device)
+        ncl = torch.empty(self.B, device=self.device, dtype=torch.int32)
+        nit = torch.empty(self.B, device=self.device, dtype=torch.int32)
+        rc = self._lib.mvfit_fit(self._ctx, arr, C.byref(o), x.data_ptr(), final.data_ptr(),
+                                 ncl.data_ptr(), nit.data_ptr())
+        self._check(rc)
+        return x, dict(final_loss=final, n_closure=ncl, n_iter=nit)
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, enable=True):
+        self._check(self._lib.mvfit_profile(self._ctx, 1 if enable else 0))
+
+    def profile_read(self):
+        a, b = C.c_double(), C.c_double()
+        n1, n2 = C.c_int(), C.c_int()
+        self._check(self._lib.mvfit_profile_read(self._ctx, C.byref(a), C.byref(n1), C.byref(b),
+                                                 C.byref(n2)))
+        return dict(vertex_pass_ms=a.value, vertex_pass_launches=n1.value,
+                    step_ms=b.value, step_launches=n2.value)
+
+
+def pack_params(betas=None, global_orient=None, body_pose=None, transl=None, scale=None,
+                pose_embedding=None, B=1):
+    """Assemble [B,118] float32 from per-tensor arrays (missing ones: zeros, scale ones)."""
+    x = np.zeros((B, D), np.float32)
+    x[:, 85] = 1.0
+    for name, val in (('betas', betas), ('global_orient', global_orient), ('body_pose', body_pose),
+                      ('transl', transl), ('scale', scale), ('pose_embedding', pose_embedding)):
+        if val is not None:
+            a, b = SL[name]
+            x[:, a:b] = np.asarray(val, np.float32).reshape(B, b - a)
+    return x
+
+
+def lbfgs_kat(kind: int, D_: int, segs, x0, max_trace=80, device=0, **opts):
+    """Run the float64 device L-BFGS on an analytic objective (include/mvfit.h:mvfit_lbfgs_kat)."""
+    lib = _lib.load()
+    o = _lib.LbfgsOpts(opts.get('lr', 1.0), opts.get('max_iter', 30), opts.get('history', 100),
+                       opts.get('tolerance_grad', 1e-5), opts.get('tolerance_change', 1e-9),
+                       opts.get('maxiters', 30), opts.get('ftol', 1e-9), opts.get('gtol', 1e-9), 1, 0)
+    x = np.ascontiguousarray(x0, np.float64).copy()
+    trace = np.zeros((max_trace, D_ + 1), np.float64)
+    sg = _i32(segs)
+    n = C.c_int()
+    fl = C.c_double()
+    rc = lib.mvfit_lbfgs_kat(device, kind, D_, sg.ctypes.data_as(C.POINTER(C.c_int32)), len(sg) - 1,
+                             C.byref(o), x.ctypes.data_as(C.POINTER(C.c_double)),
+                             trace.ctypes.data_as(C.POINTER(C.c_double)), max_trace, C.byref(n),
+                             C.byref(fl))
+    if rc != 0:
+        raise MvFitError('mvfit_lbfgs_kat failed: %d' % rc)
+    return x, trace[:min(n.value, max_trace)], n.value, fl.value

@@ -1,0 +1,66 @@
+"""GPU: the device L-BFGS state machine (float64 instantiation) against trajectories recorded
+from the reference optimiser, and the staged device fit against reference fits."""
+import os
+
+import numpy as np
+import pytest
+
+from mvsmplfitting_amd import _lib
+from mvsmplfitting_amd import synthetic as syn
+from mvsmplfitting_amd.engine import lbfgs_kat, stage_weights as eng_stage_weights
+from oracle import lbfgs_np as ln
+from tests.gpu_helpers import make_engine, to118
+from tests.helpers import GOLD, body_model
+
+pytestmark = pytest.mark.gpu
+KAT = dict(np.load(os.path.join(GOLD, 'lbfgs_kat.npz')))
+KIND = dict(quad=0, rosen=1, gmof=2)
+
+
+@pytest.mark.parametrize('kind', ['quad', 'rosen', 'gmof'])
+@pytest.mark.parametrize('D', [49, 86])
+def test_device_lbfgs_follows_reference(kind, D):
+    key = '%s_%d' % (kind, D)
+    _, x0 = ln.kat_objective(kind, D)
+    xf, trace, ncl, final = lbfgs_kat(KIND[kind], D, [0, 10, 13, D], x0, max_trace=80)
+    ref = KAT[key + '_trace']
+    n = min(len(ref), len(trace), 40)
+    for i in range(n):
+        assert np.abs(trace[i][:D] - ref[i][:D]).max() < 1e-7, (key, i)
+        assert abs(trace[i][D] - ref[i][D]) <= 1e-7 * max(1.0, abs(ref[i][D]))
+    if kind != 'rosen':
+        assert ncl == int(KAT[key + '_n'])
+        assert np.abs(xf - KAT[key + '_xf']).max() < 1e-9
+        assert abs(final - float(KAT[key + '_final'])) < 1e-8
+    else:   # rounding amplification on the stiff chain: same optimum, similar effort
+        assert abs(ncl - int(KAT[key + '_n'])) <= 25
+        assert np.abs(xf - KAT[key + '_xf']).max() < 1e-3
+
+
+@pytest.mark.parametrize('name,use_vp', [('l2', False), ('vposer', True)])
+@pytest.mark.parametrize('sparse', [False, True])
+def test_device_fit_against_reference_fit(name, use_vp, sparse):
+    g = dict(np.load(os.path.join(GOLD, 'fit_%s.npz' % name)))
+    model = body_model()
+    vpw = syn.make_vposer_decoder() if use_vp else None
+    eng = make_engine(model, vpw)
+    cams = (g['cam_R'], g['cam_t'], g['cam_f'], g['cam_c'])
+    B = g['x0'].shape[0]
+    eng.set_problems(cams, g['gt_xy'], g['conf'])
+    x0 = np.stack([to118(g['x0'][b], use_vp) for b in range(B)]).astype(np.float32)
+    flags = (_lib.F_VPOSER if use_vp else 0) | (_lib.F_SPARSE_VERTS if sparse else 0)
+    stages = eng_stage_weights(1536.0, flags=flags)
+    xf, st = eng.fit(x0, stages)
+    final = st['final_loss'].cpu().numpy().astype(np.float64)
+    ncl = st['n_closure'].cpu().numpy()
+    ref_final = g['final']
+    ref_ncl = g['ncl'].sum(1)
+    # trajectories are chaotic w.r.t. rounding: assert same quality, similar effort
+    assert np.all(np.isfinite(final))
+    assert np.all(final <= 1.25 * ref_final + 1.0), (final, ref_final)
+    assert np.all(ncl > 0.25 * ref_ncl) and np.all(ncl < 4 * ref_ncl), (ncl, ref_ncl)
+    # the returned loss is the objective at (about) the returned parameters
+    w = dict(stages[-1])
+    chk = eng.closure(xf, w, want_grad=False)['loss'].cpu().numpy()
+    assert np.all(chk <= final * (1 + 1e-3) + 1e-3)
+    eng.close()
