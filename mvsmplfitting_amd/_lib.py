@@ -56,6 +56,10 @@ EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'm
 
 
 def load():
+    # libmvfit.so is linked against libamdhip64.so.7; PyTorch ships its own copy under the same
+    # SONAME.  Exactly one HIP runtime may live in the process (tensors and kernels must share a
+    # context), so torch's is loaded first and the dynamic loader binds libmvfit to it.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise ImportError('libmvfit.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
                           'or `make -C mvsmplfitting_amd/csrc` (expected %s)' % LIB_PATH)

@@ -28,6 +28,13 @@ hipError_t vertex_pass_configure();
 
 constexpr int STEP_NT = 256;
 
+#ifdef MVFIT_TIMING
+__device__ long long g_dbg[16];
+#define DBG_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[k] += clock64() - t_last; if (threadIdx.x == 0) t_last = clock64(); } while (0)
+#else
+#define DBG_T(k) do { } while (0)
+#endif
+
 struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
 
 // per-problem optimiser storage in HBM
@@ -138,10 +145,17 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, const DevProblems& Q
                           const LbOpts& O, LbState& S, LbVecs<float>& V, const LbHist<float>& H,
                           const float* verts_b, int b, int tid) {
     const DevWeights& W = SW.w[S.stage];
+#ifdef MVFIT_TIMING
+    long long t_last = clock64();
+#endif
     pose_prep(M, L, W.flags, tid, STEP_NT);
+    DBG_T(0);
     sparse_forward(M, L, verts_b, tid, STEP_NT);
+    DBG_T(1);
     const double total = loss_and_keypoint_grad(M, L, Q, b, W, true, tid, STEP_NT);
+    DBG_T(2);
     closure_backward(M, L, W, tid, STEP_NT);
+    DBG_T(3);
     if (tid < 64) {
         float gnew[LB_NPL], xt[LB_NPL];
 #pragma unroll
@@ -152,6 +166,10 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, const DevProblems& Q
         for (int r = 0; r < LB_NPL; ++r) L.x[tid + 64 * r] = xt[r];
         if (tid == 0) { L.sh_stage = S.stage; L.sh_status = S.status; }
     }
+    DBG_T(4);
+#ifdef MVFIT_TIMING
+    if (blockIdx.x == 0 && tid == 0) { g_dbg[5] += 1; g_dbg[6] += S.hist_len; }
+#endif
     __syncthreads();
     S.stage = L.sh_stage;            // waves 1.. only track the scalars they need
     S.status = L.sh_status;
@@ -762,6 +780,15 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     if (!finished) return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished", cap);
     return MVFIT_OK;
 }
+
+#ifdef MVFIT_TIMING
+extern "C" int mvfit_debug_timing(long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16);
+    if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 extern "C" int mvfit_profile(mvfit_ctx* c, int enable) {
     if (!c) return MVFIT_E_ARG;

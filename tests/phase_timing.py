@@ -1,0 +1,26 @@
+"""Developer tool: per-phase shader-clock breakdown of the step kernel (needs a -DMVFIT_TIMING build)."""
+import sys, os, ctypes as C, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
+import numpy as np, torch
+from mvsmplfitting_amd import _lib, synthetic as syn
+from mvsmplfitting_amd.engine import MvFit, stage_weights
+B, V = 32, 8
+model = syn.make_body_model(0); cams = syn.make_camera_ring(V)
+eng = MvFit(model, vposer=syn.make_vposer_decoder())
+lib = eng._lib
+fr = syn.make_frames(B); xgt = np.zeros((B,118), np.float32)
+for k,(a,b) in dict(betas=(0,10), global_orient=(10,13), body_pose=(13,82), transl=(82,85), scale=(85,86)).items(): xgt[:,a:b] = fr[k]
+eng.set_problems(cams, np.zeros((B,V,17,2),np.float32), np.ones((B,V,17),np.float32))
+_, joints = eng.vertices(xgt)
+gt, conf = syn.make_observations(joints.cpu().numpy(), cams); eng.set_problems(cams, gt, conf)
+x0 = np.zeros((B,118), np.float32); x0[:,85]=1
+buf = (C.c_longlong*16)()
+for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
+    lib.mvfit_debug_timing(buf, 1)
+    xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
+    lib.mvfit_debug_timing(buf, 1)
+    n = max(buf[5],1)
+    names = ['pose_prep','sparse_fwd','loss','backward','lbfgs']
+    print(name, 'rounds(block0)=%d avg hist=%.1f' % (n, buf[6]/n), ' '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(5)), 'cycles/round; total=%.0f' % (sum(buf[i] for i in range(5))/n))
