@@ -161,7 +161,7 @@ int mvfit_profile_read(mvfit_ctx* ctx, double* vertex_pass_ms_avg, int* launches
 
 /* Known-answer test entry for the device L-BFGS state machine (same template as production,
  * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.
- *   kind: 0 quad, 1 rosen, 2 gmof ; D <= 128 ; x_inout[D] host ; trace[max_trace,(D+1)] host
+ *   kind: 0 quad, 1 rosen, 2 gmof ; D <= 96 ; x_inout[D] host ; trace[max_trace,(D+1)] host
  *   (x_trial, loss per closure) ; segs[nseg+1] parameter-tensor boundaries for the gtol test. */
 int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs, int nseg,
                     const mvfit_lbfgs_opts* opts, double* x_inout, double* trace, int max_trace,

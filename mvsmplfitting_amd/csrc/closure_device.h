@@ -1,4 +1,7 @@
-// One closure evaluation for ONE problem, executed by one workgroup with all intermediates in LDS.
+// One closure evaluation for ONE problem, executed by one 512-thread workgroup with every
+// intermediate AND every small model constant in LDS; the only global traffic inside a closure
+// is the streamed blendshape basis of the objective's vertices (fwd: pd_sub, bwd: pd_subT) and,
+// when enabled, the VPoser / GMM weights.
 //
 // Forward = SMPL.forward (reference code/smplx/body_models_scale.py:327-412, code/smplx/lbs.py:135-222)
 // restricted to the vertices the objective reads, + SMPLifyLoss.forward
@@ -7,52 +10,71 @@
 // Backward = the hand-derived adjoint that replaces total_loss.backward() (fitting.py:190-192);
 // it is the transcription of oracle/closure_np.py:_backward, which matches the reference's
 // autograd to 1e-16 in float64.
+//
+// Latency structure (the closure is ~0.3 MFLOP: what costs is dependent latency, not work):
+//   E1  Rodrigues + J(beta) + blendshape coefficients + relative transforms     (all threads)
+//   E2  wave 0: kinematic chain, level by level, 12 lanes per joint, no s_barrier
+//       waves 1-7: stream pd_sub (k-split partial sums)                         [overlapped]
+//   E3  v_posed, skinning transform rows, skinned positions                     (thread per coordinate)
+//   E4  thread per (view, keypoint): keypoint, projection, GMoF, d/d keypoint; priors on wave 4;
+//       DPP wave reductions -> LDS
+//   E5  g_x, g_vposed                                                            (thread per coordinate)
+//   E6  g_A = W^T [g_x v_posed^T | g_x]: 16-lane row per joint, DPP butterfly
+//   E7  wave 0: chain adjoint; waves 1-7: stream pd_subT (g_coef partials)      [overlapped]
+//   E8  g_R assembly, g_J, g_beta; E9 Rodrigues adjoint + pose priors; flat gradient
 #pragma once
 #include "mvfit_device.h"
 
 namespace mvfit {
 
 struct ClosureLds {
-    float x[DPAD];
+    ModelLds M;                     // model constants (copied once per launch)
+    // per-problem observations (copied once per launch)
+    float camR[MVFIT_MAX_VIEWS][9];
+    float camt[MVFIT_MAX_VIEWS][3];
+    float camf[MVFIT_MAX_VIEWS];
+    float camc[MVFIT_MAX_VIEWS][2];
+    float gt[MVFIT_MAX_VIEWS * NKP * 2];
+    float wc[MVFIT_MAX_VIEWS * NKP];
+    // state of one evaluation
+    __attribute__((aligned(16))) float x[DPAD];
     float theta[72];
-    float beta[12];
-    float tau[4];
-    float scale;
-    float gscale;
-    float loss_terms[6];            // data, pose, shape, angle, (coll), total
-    int flags_dropped;              // bit0: pose prior dropped, bit1: angle prior dropped
-    int gmm_sel;
-    int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
     float R[NJ][9];
-    float ang[NJ];
+    float rod[NJ][3];               // angle, sin, cos
     float J[NJ][3];
     float Rm[NJ][9];
     float tm[NJ][3];
     float Gr[NJ][9];
     float Gt[NJ][3];
-    float A[NJ][12];
+    __attribute__((aligned(16))) float A[NJ][12];
     float coef[KROWS];
     float vposed[NC_MAX];
     float xs[NC_MAX];
-    float T[NS_MAX][12];
+    __attribute__((aligned(16))) float T[NS_MAX][12];
     float kp[NKP][3];
     float gkp_part[MVFIT_MAX_VIEWS][NKP][3];
-    float gkp[NKP][3];
     float gx[NC_MAX];
-    float gvp[NC_MAX];
-    float gAr[NJ][9];
-    float gAt[NJ][3];
+    __attribute__((aligned(16))) float gvp[NC_MAX];
     float gGr[NJ][9];
     float gGt[NJ][3];
     float gJ[NJ][3];
     float gRm[NJ][9];
     float gtm[NJ][3];
     float gR[NJ][9];
-    float gcoef[KROWS];
     float gtheta[72];
     float gbeta[12];
     float gtau[4];
-    float grad[DPAD];
+    float gscale;
+    float loss_terms[6];            // data, pose, shape, angle, (coll), total
+    int flags_dropped;              // bit0: pose prior dropped, bit1: angle prior dropped
+    int gmm_sel;
+    int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
+    double total;
+    double red_d[STEP_NW];          // per-wave partial of the data term
+    float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
+    __attribute__((aligned(16))) float grad[DPAD];
+    // scratch for k-split partial sums: max(8 * nc_pad, 8 * KROWS)
+    __attribute__((aligned(16))) float scratch[8 * NC_MAX];
     // VPoser activations (decoder fwd/bwd)
     float vp_pre1[512];
     float vp_pre2[512];
@@ -60,14 +82,40 @@ struct ClosureLds {
     float vp_g[512];
     float vp_o[144];
     float vp_go[144];
-    float vp_cache[23][32];
+    float vp_cache[23][25];
     // GMM
+    float gmm_d[72];
     float gmm_t[8][72];
     float gmm_ll[8];
-    // scratch for k-split partial sums: max(nks * nc_pad, nks * KROWS)
-    float scratch[4096];
-    double red[16];
+    // L-BFGS: ro = 1/(y.s) per history slot, scalar state and working vectors (only wave 0 touches
+    // them, and only between two closure evaluations: kept here so that they cost no registers
+    // while the closure runs); in the single-launch fit the (s, y) ring follows this struct.
+    float lb_ro[LB_HIST];
+    DevWeights sw[MVFIT_MAX_STAGES];          // per-stage weights and optimiser options: read from LDS inside the
+    __attribute__((aligned(16))) LbOpts opts; // round loop so that they do not pin ~100 SGPRs across it
+    __attribute__((aligned(16))) LbState lbS;
+    __attribute__((aligned(16))) float lbV[LB_NVEC][LB_D];
 };
+
+// copy the launch-constant part of the LDS image: model block + this problem's observations
+__device__ __forceinline__ void lds_load_constants(ClosureLds& L, const DevModel& M, const DevProblems& Q, int b,
+                                                   int tid) {
+    {
+        const int4* src = reinterpret_cast<const int4*>(M.mlds);
+        int4* dst = reinterpret_cast<int4*>(&L.M);
+        constexpr int n16 = sizeof(ModelLds) / 16;
+        static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds must be a multiple of 16 bytes");
+        for (int i = tid; i < n16; i += STEP_NT) dst[i] = src[i];
+    }
+    const int V = Q.V;
+    const size_t cb = Q.cam_batched ? (size_t)b * V : 0;
+    for (int i = tid; i < V * 9; i += STEP_NT) (&L.camR[0][0])[i] = Q.cam_R[cb * 9 + i];
+    for (int i = tid; i < V * 3; i += STEP_NT) (&L.camt[0][0])[i] = Q.cam_t[cb * 3 + i];
+    for (int i = tid; i < V; i += STEP_NT) L.camf[i] = Q.cam_f[cb + i];
+    for (int i = tid; i < V * 2; i += STEP_NT) (&L.camc[0][0])[i] = Q.cam_c[cb * 2 + i];
+    for (int i = tid; i < V * NKP * 2; i += STEP_NT) L.gt[i] = Q.gt_xy[(size_t)b * V * NKP * 2 + i];
+    for (int i = tid; i < V * NKP; i += STEP_NT) L.wc[i] = Q.w_conf[(size_t)b * V * NKP + i];
+}
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {   // c = a b
 #pragma unroll
@@ -77,36 +125,75 @@ __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* 
             c[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
 }
 
+// Rodrigues (lbs.py:269-300): angle = ||r + 1e-8||, k = r / angle, R = I + sin K + (1 - cos) K^2
+__device__ __forceinline__ void rodrigues(const float* r, float* R, float* rod) {
+    const float rx = r[0], ry = r[1], rz = r[2];
+    const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+    const float a = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float kx = rx / a, ky = ry / a, kz = rz / a;
+    float sn, cs;
+    sincosf(a, &sn, &cs);
+    const float oc = 1.0f - cs;
+    // K = [[0,-kz,ky],[kz,0,-kx],[-ky,kx,0]] ; K^2 = k k^T - |k|^2 I
+    const float kk = kx * kx + ky * ky + kz * kz;
+    R[0] = 1.f + oc * (kx * kx - kk); R[1] = -sn * kz + oc * kx * ky;   R[2] = sn * ky + oc * kx * kz;
+    R[3] = sn * kz + oc * kx * ky;    R[4] = 1.f + oc * (ky * ky - kk); R[5] = -sn * kx + oc * ky * kz;
+    R[6] = -sn * ky + oc * kx * kz;   R[7] = sn * kx + oc * ky * kz;    R[8] = 1.f + oc * (kz * kz - kk);
+    rod[0] = a; rod[1] = sn; rod[2] = cs;
+}
+
 // ---------------------------------------------------------------------------------------------
 // VPoser decoder forward (VPoser.py:218-232,165-174,263-273,29-156) for one latent, block-wide.
+// Weight rows are streamed with the whole block; every GEMV output is k-split over lanes.
 // ---------------------------------------------------------------------------------------------
-__device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid, int nt) {
-    // h1 = lrelu(W1 z + b1)
+__device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
+    constexpr int nt = STEP_NT;
+    // h1 = lrelu(W1 z + b1): one output per thread
     for (int o = tid; o < 512; o += nt) {
         float s = M.vp_b1[o];
-        const float* w = M.vp_w1 + o * 32;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) s = fmaf(w[i], L.x[X_EMB + i], s);
+        const float4* w = reinterpret_cast<const float4*>(M.vp_w1 + o * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = w[i];
+            s = fmaf(v.x, L.x[X_EMB + 4 * i], s); s = fmaf(v.y, L.x[X_EMB + 4 * i + 1], s);
+            s = fmaf(v.z, L.x[X_EMB + 4 * i + 2], s); s = fmaf(v.w, L.x[X_EMB + 4 * i + 3], s);
+        }
         L.vp_pre1[o] = s;
         L.vp_h[o] = s > 0.f ? s : 0.2f * s;
     }
     __syncthreads();
-    // h2 = lrelu(W2 h1 + b2): w2T[i][o] so consecutive threads read consecutive o
+    // h2 = lrelu(W2 h1 + b2): w2T[i][o], thread o, consecutive threads read consecutive o
     for (int o = tid; o < 512; o += nt) {
-        float s = M.vp_b2[o];
-#pragma unroll 8
-        for (int i = 0; i < 512; ++i) s = fmaf(M.vp_w2T[i * 512 + o], L.vp_h[i], s);
-        L.vp_pre2[o] = s;
+        float s0 = M.vp_b2[o], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < 512; i += 4) {
+            s0 = fmaf(M.vp_w2T[(i + 0) * 512 + o], L.vp_h[i + 0], s0);
+            s1 = fmaf(M.vp_w2T[(i + 1) * 512 + o], L.vp_h[i + 1], s1);
+            s2 = fmaf(M.vp_w2T[(i + 2) * 512 + o], L.vp_h[i + 2], s2);
+            s3 = fmaf(M.vp_w2T[(i + 3) * 512 + o], L.vp_h[i + 3], s3);
+        }
+        L.vp_pre2[o] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     for (int o = tid; o < 512; o += nt) { float s = L.vp_pre2[o]; L.vp_h[o] = s > 0.f ? s : 0.2f * s; }
     __syncthreads();
-    for (int o = tid; o < 138; o += nt) {
-        float s = M.vp_b3[o];
-#pragma unroll 8
-        for (int i = 0; i < 512; ++i) s = fmaf(M.vp_w3T[i * 144 + o], L.vp_h[i], s);
-        L.vp_o[o] = s;
+    // out = W3 h2 + b3: 144 padded outputs x 3 k-slices (432 threads)
+    {
+        const int o = tid % 144, ks = tid / 144;
+        if (ks < 3) {
+            const int i0 = ks * 171, i1 = min(512, i0 + 171);
+            float s0 = 0.f, s1 = 0.f;
+            int i = i0;
+            for (; i + 1 < i1; i += 2) {
+                s0 = fmaf(M.vp_w3T[i * 144 + o], L.vp_h[i], s0);
+                s1 = fmaf(M.vp_w3T[(i + 1) * 144 + o], L.vp_h[i + 1], s1);
+            }
+            if (i < i1) s0 = fmaf(M.vp_w3T[i * 144 + o], L.vp_h[i], s0);
+            L.scratch[ks * 144 + o] = s0 + s1;
+        }
     }
+    __syncthreads();
+    for (int o = tid; o < 138; o += nt) L.vp_o[o] = M.vp_b3[o] + ((L.scratch[o] + L.scratch[144 + o]) + L.scratch[288 + o]);
     __syncthreads();
     // per joint: Gram-Schmidt -> R^T rows -> quaternion (4-way branch) -> axis-angle
     for (int j = tid; j < 23; j += nt) {
@@ -151,7 +238,8 @@ __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid, int nt
 }
 
 // g_z += (d body_pose / d z)^T g_body_pose   (transcription of oracle vposer_decode_bwd)
-__device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid, int nt) {
+__device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
+    constexpr int nt = STEP_NT;
     for (int j = tid; j < 23; j += nt) {
         const float* C = L.vp_cache[j];
         const float n1 = C[0], d = C[4], n2 = C[5];
@@ -224,246 +312,323 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid, int n
         for (int c = 0; c < 3; ++c) { go[2 * c] = (gb1[c] - b1[c] * pa) / n1; go[2 * c + 1] = ga2[c]; }
     }
     __syncthreads();
-    // g_h2 = W3^T g_o ; through lrelu
+    // g_h2 = W3^T g_o ; through lrelu.  w3[o][i]: thread i, consecutive threads consecutive addresses
     for (int i = tid; i < 512; i += nt) {
-        float s = 0.f;
-#pragma unroll 6
-        for (int o = 0; o < 138; ++o) s = fmaf(M.vp_w3[o * 512 + i], L.vp_go[o], s);
-        L.vp_g[i] = s * (L.vp_pre2[i] > 0.f ? 1.0f : 0.2f);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 3
+        for (int o = 0; o < 138; o += 2) {
+            s0 = fmaf(M.vp_w3[o * 512 + i], L.vp_go[o], s0);
+            s1 = fmaf(M.vp_w3[(o + 1) * 512 + i], L.vp_go[o + 1], s1);
+        }
+        L.vp_g[i] = (s0 + s1) * (L.vp_pre2[i] > 0.f ? 1.0f : 0.2f);
     }
     __syncthreads();
     // g_h1 = W2^T g_pre2 : w2[o][i], consecutive threads i -> consecutive addresses
     for (int i = tid; i < 512; i += nt) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < 512; ++o) s = fmaf(M.vp_w2[o * 512 + i], L.vp_g[o], s);
-        L.vp_h[i] = s * (L.vp_pre1[i] > 0.f ? 1.0f : 0.2f);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int o = 0; o < 512; o += 4) {
+            s0 = fmaf(M.vp_w2[(o + 0) * 512 + i], L.vp_g[o + 0], s0);
+            s1 = fmaf(M.vp_w2[(o + 1) * 512 + i], L.vp_g[o + 1], s1);
+            s2 = fmaf(M.vp_w2[(o + 2) * 512 + i], L.vp_g[o + 2], s2);
+            s3 = fmaf(M.vp_w2[(o + 3) * 512 + i], L.vp_g[o + 3], s3);
+        }
+        L.vp_h[i] = ((s0 + s1) + (s2 + s3)) * (L.vp_pre1[i] > 0.f ? 1.0f : 0.2f);
     }
     __syncthreads();
-    for (int i = tid; i < 32; i += nt) {
+    // g_z = W1^T g_pre1: 32 outputs x 16 k-slices, DPP row reduction (lane&15 = slice)
+    {
+        const int i = tid >> 4, ks = tid & 15;        // 512 threads = 32 outputs x 16 slices
         float s = 0.f;
-        for (int o = 0; o < 512; ++o) s = fmaf(M.vp_w1[o * 32 + i], L.vp_h[o], s);
-        L.grad[X_EMB + i] += s;
+        for (int o = ks; o < 512; o += 16) s = fmaf(M.vp_w1[o * 32 + i], L.vp_h[o], s);
+        s = row16_sum(s);
+        if (ks == 0) L.grad[X_EMB + i] += s;
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// pose_prep: x -> theta, R, J, kinematic chain, skinning transforms A, blendshape coefficients.
-// lbs.py:183-205,269-370 + body_models_scale.py:377
+// E1: x -> theta, R, J, blendshape coefficients, relative transforms.   lbs.py:183-195,269-348
+// Every thread derives what it needs straight from x (Rodrigues is recomputed per output element)
+// so the phase has no internal barrier.  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
-__device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid, int nt) {
+__device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     if (flags & MVFIT_F_VPOSER) {
-        vposer_forward(M, L, tid, nt);
+        vposer_forward(M, L, tid);
+        if (tid < 3) L.theta[tid] = L.x[X_GO + tid];
+        __syncthreads();
     } else {
-        for (int i = tid; i < 69; i += nt) L.theta[3 + i] = L.x[X_BP + i];
-    }
-    if (tid < 3) { L.theta[tid] = L.x[X_GO + tid]; L.tau[tid] = L.x[X_TR + tid]; }
-    if (tid < 10) L.beta[tid] = L.x[X_BETAS + tid];
-    if (tid == 0) L.scale = L.x[X_SC];
-    __syncthreads();
-    // Rodrigues (lbs.py:269-300): theta=||r+1e-8||, k=r/theta
-    if (tid < NJ) {
-        const float rx = L.theta[3 * tid], ry = L.theta[3 * tid + 1], rz = L.theta[3 * tid + 2];
-        const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
-        const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-        const float kx = rx / a, ky = ry / a, kz = rz / a;
-        float sn, cs;
-        sincosf(a, &sn, &cs);
-        const float oc = 1.0f - cs;
-        // K = [[0,-kz,ky],[kz,0,-kx],[-ky,kx,0]] ; K^2 = k k^T - |k|^2 I
-        const float kk = kx * kx + ky * ky + kz * kz;
-        float* R = L.R[tid];
-        R[0] = 1.f + oc * (kx * kx - kk); R[1] = -sn * kz + oc * kx * ky;   R[2] = sn * ky + oc * kx * kz;
-        R[3] = sn * kz + oc * kx * ky;    R[4] = 1.f + oc * (ky * ky - kk); R[5] = -sn * kx + oc * ky * kz;
-        R[6] = -sn * ky + oc * kx * kz;   R[7] = sn * kx + oc * ky * kz;    R[8] = 1.f + oc * (kz * kz - kk);
-        L.ang[tid] = a;
-    }
-    // J = J_t + J_S beta   (== J_regressor (v_template + shapedirs beta), lbs.py:179-183)
-    for (int i = tid; i < NJ * 3; i += nt) {
-        float s = M.J_t[i];
-        const float* js = M.J_S + i * 10;
-#pragma unroll
-        for (int l = 0; l < 10; ++l) s = fmaf(js[l], L.x[X_BETAS + l], s);
-        (&L.J[0][0])[i] = s;
-    }
-    __syncthreads();
-    // blendshape coefficients: pose_feature (lbs.py:192), betas, zero pad
-    for (int p = tid; p < KROWS; p += nt) {
-        float v = 0.f;
-        if (p < 207) { int e = p % 9; v = L.R[1 + p / 9][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
-        else if (p < 217) v = L.beta[p - 207];
-        L.coef[p] = v;
-    }
-    // relative transforms (lbs.py:341-348)
-    for (int i = tid; i < NJ * 12; i += nt) {
-        const int j = i / 12, e = i - j * 12;
-        if (e < 9) L.Rm[j][e] = (j == 0 ? L.scale : 1.0f) * L.R[j][e];
-        else { const int a = e - 9; const int pa = M.parents[j]; L.tm[j][a] = L.J[j][a] - (j > 0 ? L.J[pa][a] : 0.f); }
-    }
-    __syncthreads();
-    // chain, level by level (lbs.py:349-355)
-    for (int i = tid; i < 12; i += nt) { if (i < 9) L.Gr[0][i] = L.Rm[0][i]; else L.Gt[0][i - 9] = L.tm[0][i - 9]; }
-    __syncthreads();
-    for (int lv = 1; lv < M.nlevels; ++lv) {
-        const int n = (M.level_start[lv + 1] - M.level_start[lv]) * 12;
-        for (int i = tid; i < n; i += nt) {
-            const int j = M.level_joints[M.level_start[lv] + i / 12], e = i % 12;
-            const int pa = M.parents[j];
-            if (e < 9) {
-                const int a = e / 3, b = e % 3;
-                L.Gr[j][e] = L.Gr[pa][a * 3] * L.Rm[j][b] + L.Gr[pa][a * 3 + 1] * L.Rm[j][3 + b] + L.Gr[pa][a * 3 + 2] * L.Rm[j][6 + b];
-            } else {
-                const int a = e - 9;
-                L.Gt[j][a] = L.Gr[pa][a * 3] * L.tm[j][0] + L.Gr[pa][a * 3 + 1] * L.tm[j][1] + L.Gr[pa][a * 3 + 2] * L.tm[j][2] + L.Gt[pa][a];
-            }
-        }
+        if (tid < 72) L.theta[tid] = L.x[X_GO + tid];      // global_orient | body_pose are contiguous in x
         __syncthreads();
     }
-    // A_j = [Gr_j | Gt_j - Gr_j J_j]  (lbs.py:365-368), rows of 4
-    for (int i = tid; i < NJ * 12; i += nt) {
-        const int j = i / 12, e = i - j * 12, a = e >> 2, c = e & 3;
+    if (tid < KROWS) {
+        // blendshape coefficients: pose_feature (lbs.py:192), betas, zero pad
+        const int p = tid;
+        float v = 0.f;
+        if (p < 207) {
+            const int j = 1 + p / 9, e = p % 9;
+            float R[9], rod[3];
+            rodrigues(&L.theta[3 * j], R, rod);
+            float sel = R[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
+            v = sel - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        } else if (p < 217) {
+            v = L.x[X_BETAS + p - 207];
+        }
+        L.coef[p] = v;
+    } else {
+        // relative transforms (lbs.py:341-348) + the cached R / J the adjoint needs
+        const int i = tid - KROWS;                 // 0..287
+        const int j = i / 12, e = i - j * 12;
+        if (e < 9) {
+            float R[9], rod[3];
+            rodrigues(&L.theta[3 * j], R, rod);
+            float sel = R[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
+            L.R[j][e] = sel;
+            L.Rm[j][e] = (j == 0 ? L.x[X_SC] : 1.0f) * sel;
+            if (e < 3) L.rod[j][e] = rod[e];
+        } else {
+            // J = J_t + J_S beta   (== J_regressor (v_template + shapedirs beta), lbs.py:179-183)
+            const int a = e - 9;
+            const int pa = L.M.parents[j];
+            float s = L.M.J_t[3 * j + a];
+#pragma unroll
+            for (int l = 0; l < 10; ++l) s = fmaf(L.M.J_S[3 * j + a][l], L.x[X_BETAS + l], s);
+            float sp = 0.f;
+            if (j > 0) {
+                sp = L.M.J_t[3 * pa + a];
+#pragma unroll
+                for (int l = 0; l < 10; ++l) sp = fmaf(L.M.J_S[3 * pa + a][l], L.x[X_BETAS + l], sp);
+            }
+            L.J[j][a] = s;
+            L.tm[j][a] = s - sp;
+        }
+    }
+    __syncthreads();
+}
+
+// kinematic chain, level by level (lbs.py:349-355), then A_j = [Gr_j | Gt_j - Gr_j J_j] (lbs.py:365-368).
+// Executed by ONE wave: 12 lanes per joint, up to 5 joints of a level at a time, LDS hand-off
+// between levels without s_barrier.
+__device__ void chain_forward_wave(ClosureLds& L, int lane) {
+    if (lane < 12) { if (lane < 9) L.Gr[0][lane] = L.Rm[0][lane]; else L.Gt[0][lane - 9] = L.tm[0][lane - 9]; }
+    wave_lds_fence();
+    const int q = lane / 12, e = lane - 12 * q;
+    const int nlevels = L.M.nlevels;
+    for (int lv = 1; lv < nlevels; ++lv) {
+        const int ls = L.M.level_start[lv], le = L.M.level_start[lv + 1];
+        for (int base = ls; base < le; base += 5) {
+            if (q < 5 && base + q < le) {
+                const int j = L.M.level_joints[base + q];
+                const int pa = L.M.parents[j];
+                if (e < 9) {
+                    const int a = e / 3, b = e - 3 * a;
+                    L.Gr[j][e] = L.Gr[pa][a * 3] * L.Rm[j][b] + L.Gr[pa][a * 3 + 1] * L.Rm[j][3 + b] + L.Gr[pa][a * 3 + 2] * L.Rm[j][6 + b];
+                } else {
+                    const int a = e - 9;
+                    L.Gt[j][a] = L.Gr[pa][a * 3] * L.tm[j][0] + L.Gr[pa][a * 3 + 1] * L.tm[j][1] + L.Gr[pa][a * 3 + 2] * L.tm[j][2] + L.Gt[pa][a];
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+    for (int i = lane; i < NJ * 12; i += 64) {
+        const int j = i / 12, ee = i - j * 12, a = ee >> 2, c = ee & 3;
         float v;
         if (c < 3) v = L.Gr[j][a * 3 + c];
         else v = L.Gt[j][a] - (L.Gr[j][a * 3] * L.J[j][0] + L.Gr[j][a * 3 + 1] * L.J[j][1] + L.Gr[j][a * 3 + 2] * L.J[j][2]);
-        L.A[j][e] = v;
+        L.A[j][ee] = v;
     }
+}
+
+// k-split partial sums of v_posed = v_template + coef . pd_sub  (lbs.py:179,192-203 on the selected
+// vertices).  Threads [t0, t0 + nthreads) take part; partials land in L.scratch[ks][nc_pad].
+__device__ __forceinline__ int fwd_slices(int nc_pad, int nthreads) { return max(1, min(nthreads / (nc_pad >> 2), 8)); }
+
+__device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+    const int nc_pad = L.M.nc_pad;
+    const int ncq = nc_pad >> 2;                   // float4 column groups
+    const int nks = fwd_slices(nc_pad, nthreads);
+    const int rps = (KROWS / 4 + nks - 1) / nks * 4;   // rows per slice, multiple of 4
+    const int cq = t % ncq, ks = t / ncq;
+    if (ks >= nks) return;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    const int r0 = ks * rps, r1 = min(KROWS, r0 + rps);
+    const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + cq;
+    int p = r0;
+#pragma unroll 4
+    for (; p + 1 < r1; p += 2) {
+        const float4 v0 = src[(size_t)p * ncq];
+        const float4 v1 = src[(size_t)(p + 1) * ncq];
+        const float c0 = L.coef[p], c1 = L.coef[p + 1];
+        acc0.x = fmaf(c0, v0.x, acc0.x); acc0.y = fmaf(c0, v0.y, acc0.y);
+        acc0.z = fmaf(c0, v0.z, acc0.z); acc0.w = fmaf(c0, v0.w, acc0.w);
+        acc1.x = fmaf(c1, v1.x, acc1.x); acc1.y = fmaf(c1, v1.y, acc1.y);
+        acc1.z = fmaf(c1, v1.z, acc1.z); acc1.w = fmaf(c1, v1.w, acc1.w);
+    }
+    if (p < r1) {
+        const float4 v0 = src[(size_t)p * ncq];
+        const float c0 = L.coef[p];
+        acc0.x = fmaf(c0, v0.x, acc0.x); acc0.y = fmaf(c0, v0.y, acc0.y);
+        acc0.z = fmaf(c0, v0.z, acc0.z); acc0.w = fmaf(c0, v0.w, acc0.w);
+    }
+    float4* dst = reinterpret_cast<float4*>(L.scratch + ks * nc_pad + 4 * cq);
+    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+}
+
+// E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
+// from_pass != nullptr: v_posed / xs of the selected vertices come from the vertex pass (full mode).
+__device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* vposed_pass, const float* xs_pass,
+                               int tid) {
+    const int nc = L.M.nc, nc_pad = L.M.nc_pad;
+    const int nks = fwd_slices(nc_pad, STEP_NT - 64);
+    if (tid < 64) chain_forward_wave(L, tid);
+    else if (vposed_pass == nullptr) contraction_forward(M, L, tid - 64, STEP_NT - 64);
+    float vp_in = 0.f, xs_in = 0.f;
+    if (vposed_pass != nullptr && tid < nc) { vp_in = vposed_pass[tid]; xs_in = xs_pass[tid]; }
     __syncthreads();
-}
-
-// write the operands of the vertex pass for problem b
-__device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid, int nt) {
-    float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
-    for (int p = tid; p < KROWS; p += nt) ct[p * 32] = L.coef[p];
-    for (int i = tid; i < NJ * 12; i += nt) P.Amat[(size_t)b * 288 + i] = (&L.A[0][0])[i];
-    if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.tau[tid];
-}
-
-// ---------------------------------------------------------------------------------------------
-// Objective-relevant vertices: v_posed_s (always needed by the adjoint) and, when the full
-// vertex pass did not run (or for the sparse mode), the skinned positions xs.
-// ---------------------------------------------------------------------------------------------
-__device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* verts_b, int tid, int nt) {
-    const int ncq = M.nc_pad >> 2;                 // float4 column groups
-    const int nks = max(1, min(min(nt / ncq, 8), 4096 / M.nc_pad));   // k-slices
-    const int rps = (KROWS + nks - 1) / nks;       // rows per slice
-    {
-        const int cq = tid % ncq, ks = tid / ncq;
-        if (ks < nks) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int r0 = ks * rps, r1 = min(KROWS, r0 + rps);
-            const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + cq;
+    // thread per coordinate c = 3 s + a: T row a of vertex s, v_posed[c], xs[c]
+    if (tid < nc) {
+        const int c = tid, s = c / 3, a = c - 3 * s;
+        float4 tr = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-            for (int p = r0; p < r1; ++p) {
-                const float4 v = src[(size_t)p * ncq];
-                const float c = L.coef[p];
-                acc.x = fmaf(c, v.x, acc.x); acc.y = fmaf(c, v.y, acc.y);
-                acc.z = fmaf(c, v.z, acc.z); acc.w = fmaf(c, v.w, acc.w);
-            }
-            float* dst = L.scratch + ks * M.nc_pad + 4 * cq;
-            dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
+        for (int j = 0; j < NJ; ++j) {
+            const float w = L.M.wT[j][s];
+            const float4 av = *reinterpret_cast<const float4*>(&L.A[j][4 * a]);
+            tr.x = fmaf(w, av.x, tr.x); tr.y = fmaf(w, av.y, tr.y);
+            tr.z = fmaf(w, av.z, tr.z); tr.w = fmaf(w, av.w, tr.w);
         }
-    }
-    // skinning transforms of the selected vertices: T_s = sum_j W[s][j] A_j  (lbs.py:209-213)
-    for (int i = tid; i < M.ns * 12; i += nt) {
-        const int s = i / 12, e = i - s * 12;
-        const float* w = M.w_sub + s * NJ;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc = fmaf(w[j], L.A[j][e], acc);
-        L.T[s][e] = acc;
-    }
-    __syncthreads();
-    for (int c = tid; c < M.nc; c += nt) {
-        float s = M.vt_sub[c];
-        for (int k = 0; k < nks; ++k) s += L.scratch[k * M.nc_pad + c];
-        L.vposed[c] = s;
-    }
-    __syncthreads();
-    for (int c = tid; c < M.nc; c += nt) {
-        const int s = c / 3, a = c - 3 * s;
-        if (verts_b) {
-            // full mode: the objective reads the vertex pass output (vertices already hold +transl)
-            L.xs[c] = verts_b[(size_t)M.sel_v[s] * 3 + a] - L.tau[a];
+        *reinterpret_cast<float4*>(&L.T[s][4 * a]) = tr;
+        if (vposed_pass != nullptr) {
+            L.vposed[c] = vp_in;
+            L.xs[c] = xs_in;
         } else {
-            const float* T = L.T[s] + 4 * a;
-            L.xs[c] = T[0] * L.vposed[3 * s] + T[1] * L.vposed[3 * s + 1] + T[2] * L.vposed[3 * s + 2] + T[3];
+            float vp[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = L.M.vt_sub[3 * s + b];
+                for (int k = 0; k < nks; ++k) v += L.scratch[k * nc_pad + 3 * s + b];
+                vp[b] = v;
+            }
+            L.vposed[c] = vp[a];
+            L.xs[c] = tr.x * vp[0] + tr.y * vp[1] + tr.z * vp[2] + tr.w;
         }
     }
     __syncthreads();
-    // 17 keypoints = selection rows . xs + transl  (body_models_scale.py:393-403)
-    for (int i = tid; i < NKP * 3; i += nt) {
-        const int k = i / 3, a = i - 3 * k;
-        const float* row = M.ksel_sub + k * NS_MAX;
-        float s = 0.f;
-        for (int v = 0; v < M.ns; ++v) s = fmaf(row[v], L.xs[3 * v + a], s);
-        L.kp[k][a] = s + L.tau[a];
-    }
-    __syncthreads();
-}
-
-// block-wide deterministic sum of one double per thread -> every thread gets the result
-__device__ __forceinline__ double block_sum(double v, double* red, int tid, int nt) {
-    v = wave_sum(v);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    const int nw = (nt + 63) >> 6;
-    for (int w = 0; w < nw; ++w) s += red[w];
-    __syncthreads();
-    return s;
 }
 
 // ---------------------------------------------------------------------------------------------
-// SMPLifyLoss.forward (fitting.py:290-415, no SDF term) + gradient w.r.t. keypoints / priors.
-// Returns the total loss (same value in every thread).
+// E4: SMPLifyLoss.forward (fitting.py:290-415, no SDF term) + gradient w.r.t. keypoints / priors.
+// Returns the total loss (same value in every thread).  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
-__device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, const DevProblems& Q, int b,
-                                         const DevWeights& W, bool want_grad, int tid, int nt) {
-    const int V = Q.V;
-    const size_t cb = Q.cam_batched ? (size_t)b * V : 0;
+__device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V, const DevWeights& W,
+                                         bool want_grad, int tid) {
+    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
+    const bool use_gmm = !use_vp && (W.flags & MVFIT_F_PRIOR_GMM);
+    const int wave = tid >> 6;
+    const int ndata = V * NKP;                 // <= 272: waves 0 .. 4
+    const int ndw = (ndata + 63) >> 6;         // waves holding data-term threads
     double part = 0.0;
-    for (int i = tid; i < V * NKP; i += nt) {
-        const int v = i / NKP, k = i - v * NKP;
-        const float* Rc = Q.cam_R + (cb + v) * 9;
-        const float* tc = Q.cam_t + (cb + v) * 3;
-        const float f = Q.cam_f[cb + v];
-        const float cx = Q.cam_c[(cb + v) * 2], cy = Q.cam_c[(cb + v) * 2 + 1];
-        const float X = L.kp[k][0], Y = L.kp[k][1], Z = L.kp[k][2];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (tid < ndata) {
+        const int v = tid / NKP, k = tid - v * NKP;
+        // keypoint k = selection row . xs + transl  (body_models_scale.py:393-403)
+        float X = 0.f, Y = 0.f, Z = 0.f;
+        for (int t = L.M.kp_start[k]; t < L.M.kp_start[k + 1]; ++t) {
+            const int s = L.M.kp_s[t];
+            const float w = L.M.kp_w[t];
+            X = fmaf(w, L.xs[3 * s], X); Y = fmaf(w, L.xs[3 * s + 1], Y); Z = fmaf(w, L.xs[3 * s + 2], Z);
+        }
+        X += L.x[X_TR]; Y += L.x[X_TR + 1]; Z += L.x[X_TR + 2];
+        if (v == 0) { L.kp[k][0] = X; L.kp[k][1] = Y; L.kp[k][2] = Z; }
+        const float* Rc = L.camR[v];
+        const float* tc = L.camt[v];
+        const float f = L.camf[v];
+        const float cx = L.camc[v][0], cy = L.camc[v][1];
         const float px = Rc[0] * X + Rc[1] * Y + Rc[2] * Z + tc[0];            // camera.py:106-110
         const float py = Rc[3] * X + Rc[4] * Y + Rc[5] * Z + tc[1];
         const float pz = Rc[6] * X + Rc[7] * Y + Rc[8] * Z + tc[2];
         const float u = f * (px / pz) + cx, w_ = f * (py / pz) + cy;            // camera.py:112-116
-        const size_t gi = ((size_t)b * V + v) * NKP + k;
-        const float rx = Q.gt_xy[gi * 2] - u, ry = Q.gt_xy[gi * 2 + 1] - w_;
-        const float wc = Q.w_conf[gi];
-        const float w2 = wc * wc;
+        const float rx = L.gt[tid * 2] - u, ry = L.gt[tid * 2 + 1] - w_;
+        const float wcf = L.wc[tid];
+        const float w2 = wcf * wcf;
         const float rx2 = rx * rx, ry2 = ry * ry;
         const float gmx = W.rho2 * (rx2 / (rx2 + W.rho2)), gmy = W.rho2 * (ry2 / (ry2 + W.rho2));   // utils.py:435-438
-        part += (double)(w2 * (gmx + gmy));
+        part = (double)(w2 * (gmx + gmy));
         if (want_grad) {
             const float dx = rx2 + W.rho2, dy = ry2 + W.rho2;
             const float gu = -w2 * W.data_w2 * (2.f * rx * W.rho2 * W.rho2 / (dx * dx));
             const float gv = -w2 * W.data_w2 * (2.f * ry * W.rho2 * W.rho2 / (dy * dy));
             const float gpx = f * gu / pz, gpy = f * gv / pz;
             const float gpz = -f * (gu * px + gv * py) / (pz * pz);
-            L.gkp_part[v][k][0] = Rc[0] * gpx + Rc[3] * gpy + Rc[6] * gpz;
-            L.gkp_part[v][k][1] = Rc[1] * gpx + Rc[4] * gpy + Rc[7] * gpz;
-            L.gkp_part[v][k][2] = Rc[2] * gpx + Rc[5] * gpy + Rc[8] * gpz;
+            g0 = Rc[0] * gpx + Rc[3] * gpy + Rc[6] * gpz;
+            g1 = Rc[1] * gpx + Rc[4] * gpy + Rc[7] * gpz;
+            g2 = Rc[2] * gpx + Rc[5] * gpy + Rc[8] * gpz;
+            L.gkp_part[v][k][0] = g0; L.gkp_part[v][k][1] = g1; L.gkp_part[v][k][2] = g2;
         }
     }
-    const double l_data = block_sum(part, L.red, tid, nt) * (double)W.data_w2;    // fitting.py:311-316
-    // ---- priors (few terms: one wave's worth of threads) ----
-    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
-    double pp = 0.0;     // body_pose^2 (or z^2) partial
-    for (int i = tid; i < (use_vp ? 32 : 69); i += nt) {
-        const float v = use_vp ? L.x[X_EMB + i] : L.theta[3 + i];
-        pp += (double)v * (double)v;
+    if (wave < ndw) {
+        // whole-wave reductions (wave-uniform branch: every lane takes part, idle lanes add zeros)
+        const double pd = wave64_sum(part);
+        if ((tid & 63) == 0) L.red_d[wave] = pd;
+        if (want_grad) {
+            const float s0 = wave64_sum(g0), s1 = wave64_sum(g1), s2 = wave64_sum(g2);
+            if ((tid & 63) == 0) { L.red_f[wave][0] = s0; L.red_f[wave][1] = s1; L.red_f[wave][2] = s2; }
+        }
+    } else if (wave == STEP_NW - 1) {
+        // priors on the last wave: |body_pose|^2 or |z|^2, |beta|^2, angle prior
+        const int lane = tid & 63;
+        double pp = 0.0, bb = 0.0, an = 0.0;
+        if (use_vp) { if (lane < 32) { const double v = (double)L.x[X_EMB + lane]; pp = v * v; } }
+        else {
+            { const double v = (double)L.theta[3 + lane]; pp = v * v; }
+            if (lane < 5) { const double v = (double)L.theta[3 + 64 + lane]; pp += v * v; }
+        }
+        if (lane < 10) { const double v = (double)L.x[X_BETAS + lane]; bb = v * v; }
+        if (lane < 4) {
+            // angle prior (prior.py:73-89): exp(pose[idx]*sgn)^2 on full_pose[3:66] idx 52,55,9,12
+            const int idx = lane == 0 ? 52 : lane == 1 ? 55 : lane == 2 ? 9 : 12;
+            const float sg = lane == 0 ? 1.f : -1.f;
+            const float e0 = expf(sg * L.theta[3 + idx]);
+            an = (double)(e0 * e0);
+        }
+        const double spp = wave64_sum(pp), sbb = wave64_sum(bb), san = wave64_sum(an);
+        if (lane == 0) { L.red_d[STEP_NW - 1] = spp; L.red_d[STEP_NW - 2] = sbb; L.red_d[STEP_NW - 3] = san; }
     }
-    const double sq = block_sum(pp, L.red, tid, nt);
-    double bb = 0.0;
-    for (int i = tid; i < 10; i += nt) bb += (double)L.beta[i] * (double)L.beta[i];
-    const double sqb = block_sum(bb, L.red, tid, nt);
+    if (use_gmm) {
+        // merged_log_likelihood (prior.py:181-196): min_m 0.5 d^T P_m d - log nll_w_m ; t_m = P_m d_m
+        const int Mg = M.gmm_M;
+        __syncthreads();
+        // thread per (m, r, quarter): 8*69*... use 16-lane rows: row = (m, r), lanes split the 69 columns
+        const int rowi = tid >> 4, l16 = tid & 15;
+        for (int mr = rowi; mr < Mg * 69; mr += STEP_NT / 16) {
+            const int m = mr / 69, r = mr - m * 69;
+            const float* prow = M.gmm_prec + ((size_t)m * 69 + r) * 72;
+            const float* mu = M.gmm_means + m * 69;
+            float s = 0.f;
+            for (int c = l16; c < 69; c += 16) s = fmaf(prow[c], L.theta[3 + c] - mu[c], s);
+            s = row16_sum(s);
+            if (l16 == 0) L.gmm_t[m][r] = s;
+        }
+        __syncthreads();
+        if (tid < 16 * Mg) {
+            const int m = tid >> 4;
+            const float* mu = M.gmm_means + m * 69;
+            float qd = 0.f;
+            for (int r = l16; r < 69; r += 16) qd = fmaf(L.gmm_t[m][r], L.theta[3 + r] - mu[r], qd);
+            qd = row16_sum(qd);
+            if (l16 == 0) L.gmm_ll[m] = 0.5f * qd - M.gmm_lognw[m];
+        }
+    }
+    __syncthreads();
+    // ---- every thread: combine (fixed order) ----
+    double l_data = 0.0;
+    for (int w = 0; w < ndw; ++w) l_data += L.red_d[w];
+    l_data *= (double)W.data_w2;                                               // fitting.py:311-316
+    const double sq = L.red_d[STEP_NW - 1], sqb = L.red_d[STEP_NW - 2], san = L.red_d[STEP_NW - 3];
     const double wp2 = (double)W.pose_w * (double)W.pose_w;
     double l_pose;
     int dropped = 0;
@@ -471,28 +636,10 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, const
         l_pose = sq * wp2;                                                    // fitting.py:327-329
     } else {
         double P;
-        if (W.flags & MVFIT_F_PRIOR_GMM) {
-            // merged_log_likelihood (prior.py:181-196): min_m 0.5 d^T P_m d - log nll_w_m
-            const int Mg = M.gmm_M;
-            for (int i = tid; i < Mg * 69; i += nt) {
-                const int m = i / 69, r = i - m * 69;
-                const float* prow = M.gmm_prec + ((size_t)m * 69 + r) * 69;
-                const float* mu = M.gmm_means + m * 69;
-                float s = 0.f;
-                for (int c = 0; c < 69; ++c) s = fmaf(prow[c], L.theta[3 + c] - mu[c], s);
-                L.gmm_t[m][r] = s;
-            }
-            __syncthreads();
-            if (tid < Mg) {
-                const float* mu = M.gmm_means + tid * 69;
-                float qd = 0.f;
-                for (int r = 0; r < 69; ++r) qd = fmaf(L.gmm_t[tid][r], L.theta[3 + r] - mu[r], qd);
-                L.gmm_ll[tid] = 0.5f * qd - M.gmm_lognw[tid];
-            }
-            __syncthreads();
+        if (use_gmm) {
             int sel = 0;
             float best = L.gmm_ll[0];
-            for (int m = 1; m < Mg; ++m) if (L.gmm_ll[m] < best) { best = L.gmm_ll[m]; sel = m; }
+            for (int m = 1; m < M.gmm_M; ++m) if (L.gmm_ll[m] < best) { best = L.gmm_ll[m]; sel = m; }
             if (tid == 0) L.gmm_sel = sel;
             P = (double)best;
         } else {
@@ -504,173 +651,221 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, const
     }
     double l_shape = 0.0;
     if (!(W.flags & MVFIT_F_FIX_SHAPE)) l_shape = sqb * (double)W.shape_w * (double)W.shape_w;   // :339-342
-    // angle prior (prior.py:73-89): exp(pose[idx]*sgn)^2 on full_pose[3:66] idx 52,55,9,12
-    double l_angle;
-    {
-        const float e0 = expf(L.theta[3 + 52]), e1 = expf(-L.theta[3 + 55]);
-        const float e2 = expf(-L.theta[3 + 9]), e3 = expf(-L.theta[3 + 12]);
-        l_angle = ((double)(e0 * e0) + (double)(e1 * e1) + (double)(e2 * e2) + (double)(e3 * e3)) * (double)W.bend_w;
-        if ((float)l_angle > 1e4f && !use_vp) { l_angle = 0.0; dropped |= 2; }   // fitting.py:349-350
-    }
+    double l_angle = san * (double)W.bend_w;
+    if ((float)l_angle > 1e4f && !use_vp) { l_angle = 0.0; dropped |= 2; }     // fitting.py:349-350
     const double total = l_data + l_pose + l_shape + l_angle;
     if (tid == 0) {
         L.loss_terms[0] = (float)l_data; L.loss_terms[1] = (float)l_pose; L.loss_terms[2] = (float)l_shape;
         L.loss_terms[3] = (float)l_angle; L.loss_terms[5] = (float)total;
         L.flags_dropped = dropped;
+        L.total = total;
     }
-    __syncthreads();
-    if (want_grad) {
-        for (int i = tid; i < NKP * 3; i += nt) {
-            const int k = i / 3, a = i - 3 * k;
-            float s = 0.f;
-            for (int v = 0; v < V; ++v) s += L.gkp_part[v][k][a];
-            L.gkp[k][a] = s;
-        }
-        __syncthreads();
+    if (want_grad && tid < 3) {
+        float s = 0.f;
+        for (int w = 0; w < ndw; ++w) s += L.red_f[w][tid];
+        L.gtau[tid] = s;                                                       // g_tau = sum_k g_kp
     }
     return total;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward)
-// ---------------------------------------------------------------------------------------------
-__device__ void closure_backward(const DevModel& M, ClosureLds& L, const DevWeights& W, int tid, int nt) {
-    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
-    // gx = Ksel^T g_kp ; g_tau = sum_k g_kp
-    for (int c = tid; c < M.nc; c += nt) {
-        const int s = c / 3, a = c - 3 * s;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < NKP; ++k) acc = fmaf(M.ksel_sub[k * NS_MAX + s], L.gkp[k][a], acc);
-        L.gx[c] = acc;
-    }
-    if (tid < 3) {
-        float s = 0.f;
-        for (int k = 0; k < NKP; ++k) s += L.gkp[k][tid];
-        L.gtau[tid] = s;
-    }
-    __syncthreads();
-    // g_vposed = Tr^T gx ; g_Ar, g_At
-    for (int c = tid; c < M.nc_pad; c += nt) {
-        float v = 0.f;
-        if (c < M.nc) {
-            const int s = c / 3, bq = c - 3 * s;
-            v = L.T[s][0 + bq] * L.gx[3 * s] + L.T[s][4 + bq] * L.gx[3 * s + 1] + L.T[s][8 + bq] * L.gx[3 * s + 2];
-        }
-        L.gvp[c] = v;
-    }
-    for (int i = tid; i < NJ * 12; i += nt) {
-        const int j = i / 12, e = i - j * 12;
-        float acc = 0.f;
-        if (e < 9) {
-            const int a = e / 3, bq = e - 3 * a;
-            for (int s = 0; s < M.ns; ++s) acc = fmaf(M.w_sub[s * NJ + j] * L.gx[3 * s + a], L.vposed[3 * s + bq], acc);
-            L.gAr[j][e] = acc;
-        } else {
-            const int a = e - 9;
-            for (int s = 0; s < M.ns; ++s) acc = fmaf(M.w_sub[s * NJ + j], L.gx[3 * s + a], acc);
-            L.gAt[j][a] = acc;
-        }
-    }
-    __syncthreads();
-    // A_j = [Gr_j | Gt_j - Gr_j J_j]
-    for (int i = tid; i < NJ * 12; i += nt) {
-        const int j = i / 12, e = i - j * 12;
-        if (e < 9) { const int a = e / 3, bq = e - 3 * a; L.gGr[j][e] = L.gAr[j][e] - L.gAt[j][a] * L.J[j][bq]; }
-        else { const int a = e - 9; L.gGt[j][a] = L.gAt[j][a];
-               L.gJ[j][a] = -(L.Gr[j][0 + a] * L.gAt[j][0] + L.Gr[j][3 + a] * L.gAt[j][1] + L.Gr[j][6 + a] * L.gAt[j][2]); }
-    }
-    // g_coef = PD_sub . g_vposed  (transposed contraction, k-split over columns)
-    {
-        const int npq = KROWS >> 2;                 // 56 float4 row groups
-        const int ncs = max(1, min(nt / npq, 16));   // column slices
-        const int cps = (M.nc_pad + ncs - 1) / ncs;
-        const int pq = tid % npq, cs = tid / npq;
-        if (cs < ncs) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int c0 = cs * cps, c1 = min(M.nc_pad, c0 + cps);
-            const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
-#pragma unroll 8
-            for (int c = c0; c < c1; ++c) {
-                const float4 v = src[(size_t)c * npq];
-                const float g = L.gvp[c];
-                acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y);
-                acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
-            }
-            float* dst = L.scratch + cs * KROWS + 4 * pq;
-            dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
-        }
-        __syncthreads();
-        for (int p = tid; p < KROWS; p += nt) {
-            float s = 0.f;
-            for (int k = 0; k < ncs; ++k) s += L.scratch[k * KROWS + p];
-            L.gcoef[p] = s;
-        }
-    }
-    __syncthreads();
-    // kinematic chain, deepest parents first: children lists give a fixed summation order
-    for (int lv = M.nlevels - 2; lv >= 0; --lv) {
-        const int n = (M.level_start[lv + 1] - M.level_start[lv]) * 12;
-        for (int i = tid; i < n; i += nt) {
-            const int p = M.level_joints[M.level_start[lv] + i / 12], e = i % 12;
-            float acc = 0.f;
-            for (int ci = M.child_start[p]; ci < M.child_start[p + 1]; ++ci) {
-                const int c = M.child_list[ci];
-                if (e < 9) {
-                    const int a = e / 3, bq = e - 3 * a;
-                    acc += L.gGr[c][a * 3] * L.Rm[c][bq * 3] + L.gGr[c][a * 3 + 1] * L.Rm[c][bq * 3 + 1] +
-                           L.gGr[c][a * 3 + 2] * L.Rm[c][bq * 3 + 2] + L.gGt[c][a] * L.tm[c][bq];
-                } else {
-                    acc += L.gGt[c][e - 9];
+// chain adjoint by ONE wave, deepest parents first: 12 lanes per parent joint.
+__device__ void chain_backward_wave(ClosureLds& L, int lane) {
+    const int q = lane / 12, e = lane - 12 * q;
+    const int nlevels = L.M.nlevels;
+    for (int lv = nlevels - 2; lv >= 0; --lv) {
+        const int ls = L.M.level_start[lv], le = L.M.level_start[lv + 1];
+        for (int base = ls; base < le; base += 5) {
+            if (q < 5 && base + q < le) {
+                const int p = L.M.level_joints[base + q];
+                float acc = 0.f;
+                for (int ci = L.M.child_start[p]; ci < L.M.child_start[p + 1]; ++ci) {
+                    const int c = L.M.child_list[ci];
+                    if (e < 9) {
+                        const int a = e / 3, bq = e - 3 * a;
+                        acc += L.gGr[c][a * 3] * L.Rm[c][bq * 3] + L.gGr[c][a * 3 + 1] * L.Rm[c][bq * 3 + 1] +
+                               L.gGr[c][a * 3 + 2] * L.Rm[c][bq * 3 + 2] + L.gGt[c][a] * L.tm[c][bq];
+                    } else {
+                        acc += L.gGt[c][e - 9];
+                    }
                 }
+                if (e < 9) L.gGr[p][e] += acc; else L.gGt[p][e - 9] += acc;
             }
-            if (e < 9) L.gGr[p][e] += acc; else L.gGt[p][e - 9] += acc;
         }
-        __syncthreads();
+        wave_lds_fence();
     }
-    for (int i = tid; i < NJ * 12; i += nt) {
-        const int j = i / 12, e = i - j * 12;
+    // g_Rm = Gr_parent^T g_Gr ; g_tm = Gr_parent^T g_Gt   (root: identity)
+    for (int i = lane; i < NJ * 12; i += 64) {
+        const int j = i / 12, ee = i - j * 12;
         if (j == 0) {
-            if (e < 9) L.gRm[0][e] = L.gGr[0][e]; else L.gtm[0][e - 9] = L.gGt[0][e - 9];
+            if (ee < 9) L.gRm[0][ee] = L.gGr[0][ee]; else L.gtm[0][ee - 9] = L.gGt[0][ee - 9];
         } else {
-            const int pa = M.parents[j];
-            if (e < 9) { const int a = e / 3, bq = e - 3 * a;
-                L.gRm[j][e] = L.Gr[pa][a] * L.gGr[j][bq] + L.Gr[pa][3 + a] * L.gGr[j][3 + bq] + L.Gr[pa][6 + a] * L.gGr[j][6 + bq]; }
-            else { const int a = e - 9;
+            const int pa = L.M.parents[j];
+            if (ee < 9) { const int a = ee / 3, bq = ee - 3 * a;
+                L.gRm[j][ee] = L.Gr[pa][a] * L.gGr[j][bq] + L.Gr[pa][3 + a] * L.gGr[j][3 + bq] + L.Gr[pa][6 + a] * L.gGr[j][6 + bq]; }
+            else { const int a = ee - 9;
                 L.gtm[j][a] = L.Gr[pa][a] * L.gGt[j][0] + L.Gr[pa][3 + a] * L.gGt[j][1] + L.Gr[pa][6 + a] * L.gGt[j][2]; }
         }
     }
+}
+
+// g_coef partials = pd_subT . g_vposed, column-split; threads [0, nthreads) -> L.scratch[cs][KROWS]
+__device__ __forceinline__ int bwd_slices(int nthreads) { return max(1, min(nthreads / (KROWS >> 2), 8)); }
+
+__device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+    constexpr int npq = KROWS >> 2;                 // 56 float4 row groups
+    const int nc_pad = L.M.nc_pad;
+    const int ncs = bwd_slices(nthreads);
+    const int cps = (nc_pad / 4 + ncs - 1) / ncs * 4;
+    const int pq = t % npq, cs = t / npq;
+    if (cs >= ncs) return;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    const int c0 = cs * cps, c1 = min(nc_pad, c0 + cps);
+    const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
+    int c = c0;
+#pragma unroll 4
+    for (; c + 1 < c1; c += 2) {
+        const float4 v0 = src[(size_t)c * npq];
+        const float4 v1 = src[(size_t)(c + 1) * npq];
+        const float g0 = L.gvp[c], g1 = L.gvp[c + 1];
+        acc0.x = fmaf(g0, v0.x, acc0.x); acc0.y = fmaf(g0, v0.y, acc0.y);
+        acc0.z = fmaf(g0, v0.z, acc0.z); acc0.w = fmaf(g0, v0.w, acc0.w);
+        acc1.x = fmaf(g1, v1.x, acc1.x); acc1.y = fmaf(g1, v1.y, acc1.y);
+        acc1.z = fmaf(g1, v1.z, acc1.z); acc1.w = fmaf(g1, v1.w, acc1.w);
+    }
+    if (c < c1) {
+        const float4 v0 = src[(size_t)c * npq];
+        const float g0 = L.gvp[c];
+        acc0.x = fmaf(g0, v0.x, acc0.x); acc0.y = fmaf(g0, v0.y, acc0.y);
+        acc0.z = fmaf(g0, v0.z, acc0.z); acc0.w = fmaf(g0, v0.w, acc0.w);
+    }
+    float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
+    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward).
+// Ends with __syncthreads; L.grad holds the flat gradient.
+// ---------------------------------------------------------------------------------------------
+__device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
+    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
+    const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
+    // ---- E5: g_x = Ksel^T g_kp (g_kp summed over views here) ; g_vposed = Tr^T g_x ----
+    if (tid < nc_pad) {
+        float v = 0.f;
+        if (tid < nc) {
+            const int s = tid / 3, bq = tid - 3 * s;
+            float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+            for (int t = L.M.vs_start[s]; t < L.M.vs_start[s + 1]; ++t) {
+                const int k = L.M.vs_k[t];
+                const float w = L.M.vs_w[t];
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                for (int vv = 0; vv < V; ++vv) { a0 += L.gkp_part[vv][k][0]; a1 += L.gkp_part[vv][k][1]; a2 += L.gkp_part[vv][k][2]; }
+                gx0 = fmaf(w, a0, gx0); gx1 = fmaf(w, a1, gx1); gx2 = fmaf(w, a2, gx2);
+            }
+            v = L.T[s][0 + bq] * gx0 + L.T[s][4 + bq] * gx1 + L.T[s][8 + bq] * gx2;
+            L.gx[tid] = bq == 0 ? gx0 : (bq == 1 ? gx1 : gx2);
+        }
+        L.gvp[tid] = v;
+    }
     __syncthreads();
-    // g_J, g_R, g_scale
-    for (int i = tid; i < NJ * 3; i += nt) {
-        const int j = i / 3, a = i - 3 * j;
-        float s = L.gJ[j][a] + L.gtm[j][a];
-        for (int ci = M.child_start[j]; ci < M.child_start[j + 1]; ++ci) s -= L.gtm[M.child_list[ci]][a];
-        L.gJ[j][a] = s;
+    // ---- E6: g_A = sum_s W[s][j] [g_x v_posed^T | g_x]: 16-lane row per joint, lanes stride s ----
+    if (tid < NJ * 16) {
+        const int j = tid >> 4, g = tid & 15;
+        float acc[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+        for (int s = g; s < ns; s += 16) {
+            const float w = L.M.wT[j][s];
+            const float g0 = w * L.gx[3 * s], g1 = w * L.gx[3 * s + 1], g2 = w * L.gx[3 * s + 2];
+            const float v0 = L.vposed[3 * s], v1 = L.vposed[3 * s + 1], v2 = L.vposed[3 * s + 2];
+            acc[0] = fmaf(g0, v0, acc[0]); acc[1] = fmaf(g0, v1, acc[1]); acc[2] = fmaf(g0, v2, acc[2]);
+            acc[3] = fmaf(g1, v0, acc[3]); acc[4] = fmaf(g1, v1, acc[4]); acc[5] = fmaf(g1, v2, acc[5]);
+            acc[6] = fmaf(g2, v0, acc[6]); acc[7] = fmaf(g2, v1, acc[7]); acc[8] = fmaf(g2, v2, acc[8]);
+            acc[9] += g0; acc[10] += g1; acc[11] += g2;
+        }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = row16_sum(acc[e]);
+        if (g == 0) {
+            // A_j = [Gr_j | Gt_j - Gr_j J_j]:  g_Gt = g_At ; g_Gr = g_Ar - g_At J^T ; g_J = -Gr^T g_At
+            const float J0 = L.J[j][0], J1 = L.J[j][1], J2 = L.J[j][2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                L.gGr[j][3 * a + 0] = acc[3 * a + 0] - acc[9 + a] * J0;
+                L.gGr[j][3 * a + 1] = acc[3 * a + 1] - acc[9 + a] * J1;
+                L.gGr[j][3 * a + 2] = acc[3 * a + 2] - acc[9 + a] * J2;
+                L.gGt[j][a] = acc[9 + a];
+                L.gJ[j][a] = -(L.Gr[j][0 + a] * acc[9] + L.Gr[j][3 + a] * acc[10] + L.Gr[j][6 + a] * acc[11]);
+            }
+        }
     }
-    for (int i = tid; i < NJ * 9; i += nt) {
-        const int j = i / 9, e = i - 9 * j;
-        L.gR[j][e] = (j == 0) ? L.scale * L.gRm[0][e] : (L.gRm[j][e] + L.gcoef[9 * (j - 1) + e]);
-    }
-    if (tid == 0) {
+    __syncthreads();
+    // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
+    if (tid < 64) chain_backward_wave(L, tid);
+    else contraction_backward(M, L, tid - 64, STEP_NT - 64);
+    const int ncs = bwd_slices(STEP_NT - 64);
+    __syncthreads();
+    // ---- E8: g_R, g_scale, g_J -> g_beta ----
+    if (tid < NJ * 9) {
+        const int j = tid / 9, e = tid - 9 * j;
+        float v;
+        if (j == 0) v = L.x[X_SC] * L.gRm[0][e];
+        else {
+            float gc = 0.f;
+            for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + e];
+            v = L.gRm[j][e] + gc;
+        }
+        L.gR[j][e] = v;
+    } else if (tid >= 256 && tid < 256 + 160) {
+        // g_beta[l] = g_coef[207 + l] + sum_i J_S[i][l] g_J[i]  (+ shape prior): 16 lanes per l
+        const int l = (tid - 256) >> 4, g = tid & 15;
+        float s = 0.f;
+        for (int i = g; i < NJ * 3; i += 16) {
+            const int j = i / 3, a = i - 3 * j;
+            float gj = L.gJ[j][a] + L.gtm[j][a];
+            for (int ci = L.M.child_start[j]; ci < L.M.child_start[j + 1]; ++ci) gj -= L.gtm[L.M.child_list[ci]][a];
+            s = fmaf(L.M.J_S[i][l], gj, s);
+        }
+        s = row16_sum(s);
+        if (g == 0) {
+            float gc = 0.f;
+            for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
+            s += gc;
+            if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.x[X_BETAS + l] * W.shape_w * W.shape_w;
+            L.gbeta[l] = s;
+        }
+    } else if (tid == 448) {
         float s = 0.f;
         for (int e = 0; e < 9; ++e) s += L.gRm[0][e] * L.R[0][e];
         L.gscale = s;
     }
+    if (!use_vp && (W.flags & MVFIT_F_PRIOR_GMM) && !(L.flags_dropped & 1)) {
+        // 0.5 (P d + P^T d) of the selected mixture: P d is gmm_t[m]; P^T d via the transposed copy
+        const int m = L.gmm_sel;
+        const int rowi = tid >> 4, l16 = tid & 15;
+        for (int i = rowi; i < 69; i += STEP_NT / 16) {
+            const float* mu = M.gmm_means + m * 69;
+            const float* PT = M.gmm_precT + ((size_t)m * 69 + i) * 72;
+            float s = 0.f;
+            for (int r = l16; r < 69; r += 16) s = fmaf(PT[r], L.theta[3 + r] - mu[r], s);
+            s = row16_sum(s);
+            if (l16 == 0) L.gmm_d[i] = 0.5f * (L.gmm_t[m][i] + s);
+        }
+    }
     __syncthreads();
-    // Rodrigues adjoint per joint
+    // ---- E9: Rodrigues adjoint per joint + priors on the pose ----
+    const float wp2 = W.pose_w * W.pose_w;
     if (tid < NJ) {
         const float rx = L.theta[3 * tid], ry = L.theta[3 * tid + 1], rz = L.theta[3 * tid + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
-        const float a = L.ang[tid];
+        const float a = L.rod[tid][0], sn = L.rod[tid][1], cs = L.rod[tid][2];
         const float kx = rx / a, ky = ry / a, kz = rz / a;
-        float sn, cs;
-        sincosf(a, &sn, &cs);
         const float oc = 1.f - cs;
         const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
         float KK[9];
         mat3_mul(K, K, KK);
-        const float* g = L.gR[tid];
+        float g[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) g[e] = L.gR[tid][e];
         float gK_dot = 0.f, gKK_dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 9; ++e) { gK_dot += g[e] * K[e]; gKK_dot += g[e] * KK[e]; }
@@ -688,52 +883,37 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, const DevWeig
             }
         const float gkx = gKt[7] - gKt[5], gky = gKt[2] - gKt[6], gkz = gKt[3] - gKt[1];
         ga -= (gkx * rx + gky * ry + gkz * rz) / (a * a);
-        L.gtheta[3 * tid] = gkx / a + ga * ex / a;
-        L.gtheta[3 * tid + 1] = gky / a + ga * ey / a;
-        L.gtheta[3 * tid + 2] = gkz / a + ga * ez / a;
-    }
-    // g_beta = shapedirs part of g_coef + J_S^T g_J  (+ shape prior)
-    if (tid >= 64 && tid < 74) {
-        const int l = tid - 64;
-        float s = L.gcoef[207 + l];
-        for (int i = 0; i < NJ * 3; ++i) s = fmaf(M.J_S[i * 10 + l], (&L.gJ[0][0])[i], s);
-        if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.beta[l] * W.shape_w * W.shape_w;
-        L.gbeta[l] = s;
-    }
-    __syncthreads();
-    // priors on the pose
-    const float wp2 = W.pose_w * W.pose_w;
-    if (!use_vp) {
-        if ((W.flags & MVFIT_F_PRIOR_GMM) && !(L.flags_dropped & 1)) {
-            const int m = L.gmm_sel;
-            for (int i = tid; i < 69; i += nt) {
-                // 0.5 (P d + P^T d): P d is gmm_t[m]; P^T d by columns
-                const float* mu = M.gmm_means + m * 69;
-                const float* P = M.gmm_prec + (size_t)m * 69 * 69;
-                float s = 0.f;
-                for (int r = 0; r < 69; ++r) s = fmaf(P[r * 69 + i], L.theta[3 + r] - mu[r], s);
-                L.gtheta[3 + i] += 0.5f * (L.gmm_t[m][i] + s) * wp2;
+        float gth[3] = {gkx / a + ga * ex / a, gky / a + ga * ey / a, gkz / a + ga * ez / a};
+        if (tid > 0 && !use_vp) {
+            // priors on body_pose (fitting.py:330-337)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = 3 * (tid - 1) + q;               // body_pose index
+                const float bp = L.theta[3 + i];
+                float gq = gth[q];
+                if (W.flags & MVFIT_F_PRIOR_GMM) { if (!(L.flags_dropped & 1)) gq += L.gmm_d[i] * wp2; }
+                else if (!(L.flags_dropped & 1)) gq += 2.f * bp * wp2;
+                gq += 2.f * bp * 16.f * wp2;
+                gth[q] = gq;
             }
         }
-        __syncthreads();
-        for (int i = tid; i < 69; i += nt) {
-            float g = L.gtheta[3 + i];
-            const float bp = L.theta[3 + i];
-            if (!(W.flags & MVFIT_F_PRIOR_GMM) && !(L.flags_dropped & 1)) g += 2.f * bp * wp2;
-            g += 2.f * bp * 16.f * wp2;
-            L.gtheta[3 + i] = g;
+        if (tid > 0 && !(L.flags_dropped & 2)) {
+            // angle prior gradient on full_pose[3:66] idx 52,55,9,12
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = 3 * (tid - 1) + q;
+                if (i == 52 || i == 55 || i == 9 || i == 12) {
+                    const float sg = (i == 52) ? 1.f : -1.f;
+                    gth[q] += 2.f * expf(2.f * L.theta[3 + i] * sg) * sg * W.bend_w;
+                }
+            }
         }
-        __syncthreads();
-    }
-    if (tid < 4 && !(L.flags_dropped & 2)) {
-        const int idx[4] = {3 + 52, 3 + 55, 3 + 9, 3 + 12};
-        const float sg[4] = {1.f, -1.f, -1.f, -1.f};
-        const float th = L.theta[idx[tid]];
-        L.gtheta[idx[tid]] += 2.f * expf(2.f * th * sg[tid]) * sg[tid] * W.bend_w;
+        L.gtheta[3 * tid] = gth[0]; L.gtheta[3 * tid + 1] = gth[1]; L.gtheta[3 * tid + 2] = gth[2];
     }
     __syncthreads();
     // assemble the flat gradient (frozen / unused slots are zero)
-    for (int i = tid; i < DPAD; i += nt) {
+    if (tid < DPAD) {
+        const int i = tid;
         float g = 0.f;
         if (i < X_GO) g = (W.flags & MVFIT_F_FIX_SHAPE) ? 0.f : L.gbeta[i];
         else if (i < X_BP) g = L.gtheta[i - X_GO];
@@ -744,7 +924,15 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, const DevWeig
         L.grad[i] = g;
     }
     __syncthreads();
-    if (use_vp) vposer_backward(M, L, tid, nt);
+    if (use_vp) vposer_backward(M, L, tid);
+}
+
+// write the operands of the vertex pass for problem b
+__device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid) {
+    float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
+    for (int p = tid; p < KROWS; p += STEP_NT) ct[p * 32] = L.coef[p];
+    for (int i = tid; i < NJ * 12; i += STEP_NT) P.Amat[(size_t)b * 288 + i] = (&L.A[0][0])[i];
+    if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.x[X_TR + tid];
 }
 
 }  // namespace mvfit

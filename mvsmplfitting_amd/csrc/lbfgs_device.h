@@ -9,26 +9,35 @@
 //
 // The reference calls closure() from inside nested Python loops; here every closure call is a
 // yield point: advance() consumes (loss, grad) of the last trial point, runs the optimiser
-// logic up to the next closure call, emits the next trial point and returns.  Vectors are
-// lane-distributed (element i lives in lane i%64, register i/64); all scalars are wave-uniform
-// (xor-butterfly reductions give bit-identical values in every lane), so there is no LDS and
-// no barrier in here.  VT = vector storage type (float in production, double in the KAT);
-// scalar logic and dot-product accumulation are always double.
+// logic up to the next closure call, emits the next trial point and returns.
+//
+// Lane layout: the flat parameter vector (reference order of final_params, D <= 96) is spread
+// over the wave, LB_EPL = 2 consecutive elements per lane (lanes 48.. hold zeros); every dot
+// product is a 6-step butterfly (4 DPP + v_permlane16/32_swap, wave_ops.h) whose result is
+// bit-identical in all 64 lanes, so all scalar logic is wave-uniform: no LDS, no barrier, no
+// ds_bpermute in here.  VT = vector storage type, AT = accumulation type of the
+// dot products (float/float in production - the reference's vectors and torch.dot are float32 -
+// double/double in the known-answer test); line-search scalars are always double (Python floats
+// in the reference).  The (s, y) history rows are streamed with a 4-deep register prefetch ring,
+// from LDS (single-launch fit) or HBM/L2 (one launch per closure round).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wave_ops.h"
 
 namespace mvfit {
 
-constexpr int LB_NPL = 2;          // elements per lane -> D <= 128
+constexpr int LB_EPL = 2;          // elements per lane
+constexpr int LB_D = 96;           // row stride of every optimiser vector (>= D); lanes >= LB_D / LB_EPL idle
 constexpr int LB_HIST = 100;
+constexpr int LB_PD = 4;           // history prefetch depth (rows in flight)
 
 enum LbPhase : int { PH_STEP_START = 0, PH_LS_FIRST = 1, PH_LS_BRACKET = 2, PH_LS_ZOOM = 3 };
 
 struct LbOpts {
     double lr, tol_grad, tol_change, ftol, gtol;
     int max_iter, max_eval, history, maxiters, num_stages;
-    int nseg;            // parameter tensors taking part in the gtol test
+    int nseg;            // parameter tensors taking part in the gtol test (compact index ranges)
     int seg_lo[8], seg_hi[8];
 };
 
@@ -44,48 +53,39 @@ struct LbState {
     double loss, prev_loss, orig_loss, outer_prev;
     double t, H, gtd, f0, d_norm;
     double t_prev, f_prev, gtd_prev;
-    double br[2], bf[2], bgtd[2];
-    double stage_final[8];
+    double br0, br1, bf0, bf1, bgtd0, bgtd1;     // line-search bracket (no dynamic indexing: stays in registers)
 };
+#define LB_SEL(S, f, i) ((i) ? (S).f##1 : (S).f##0)
+#define LB_SET(S, i, t_, f_, g_) do { if (i) { (S).br1 = (t_); (S).bf1 = (f_); (S).bgtd1 = (g_); } \
+                                      else { (S).br0 = (t_); (S).bf0 = (f_); (S).bgtd0 = (g_); } } while (0)
 
 template <typename VT>
 struct LbVecs {            // lane-distributed working vectors
-    VT x[LB_NPL], d[LB_NPL], g[LB_NPL], pg[LB_NPL], gprev[LB_NPL], bg0[LB_NPL], bg1[LB_NPL];
+    VT x[LB_EPL], d[LB_EPL], g[LB_EPL], pg[LB_EPL], gprev[LB_EPL], bg0[LB_EPL], bg1[LB_EPL];
 };
+constexpr int LB_NVEC = 7;
 
-// History ring in global memory: y = dirs, s = stps, row stride LB_D_STRIDE.
-constexpr int LB_D_STRIDE = 128;
-template <typename VT>
+// History ring: y = dirs, s = stps, row stride LB_D; ro = 1/(y.s).  Generic pointers (LDS or global).
+template <typename VT, typename AT>
 struct LbHist {
-    VT* dirs;      // [LB_HIST][128]
-    VT* stps;      // [LB_HIST][128]
-    double* ro;    // [LB_HIST]
+    VT* dirs;      // [LB_HIST][LB_D]
+    VT* stps;      // [LB_HIST][LB_D]
+    AT* ro;        // [LB_HIST]
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
+template <typename VT, typename AT>
+__device__ __forceinline__ AT vdot(const VT* a, const VT* b) {
+    AT s = (AT)0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-template <typename VT>
-__device__ __forceinline__ double vdot(const VT* a, const VT* b) {
-    double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) s += (double)a[r] * (double)b[r];
-    return wave_sum(s);
+    for (int e = 0; e < LB_EPL; ++e) s = fma((AT)a[e], (AT)b[e], s);
+    return wave64_sum(s);
 }
 template <typename VT>
 __device__ __forceinline__ double vmaxabs(const VT* a) {
-    double s = 0.0;
+    VT s = (VT)0;
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) s = fmax(s, fabs((double)a[r]));
-    return wave_max(s);
+    for (int e = 0; e < LB_EPL; ++e) s = fmax(s, fabs(a[e]));
+    return (double)wave64_max(s);
 }
 
 // lbfgs_ls.py:11-36
@@ -106,19 +106,85 @@ __device__ __forceinline__ double lb_cubic(double x1, double f1, double g1, doub
     return (lo + hi) / 2.0;
 }
 
+template <typename VT, typename AT>
+struct LbRow { VT s[LB_EPL], y[LB_EPL]; AT ro; };
+
+template <typename VT, typename AT>
+__device__ __forceinline__ void lb_load_row(LbRow<VT, AT>& R, const LbHist<VT, AT>& Hh, int slot, int lane) {
+    if (LB_EPL * lane < LB_D) {
+        const VT* ps = Hh.stps + slot * LB_D + LB_EPL * lane;
+        const VT* py = Hh.dirs + slot * LB_D + LB_EPL * lane;
+#pragma unroll
+        for (int e = 0; e < LB_EPL; ++e) { R.s[e] = ps[e]; R.y[e] = py[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < LB_EPL; ++e) { R.s[e] = (VT)0; R.y[e] = (VT)0; }
+    }
+    R.ro = Hh.ro[slot];
+}
+
+// direction d = -H g by the two-loop recursion (lbfgs_ls.py:336-358), same operation order as the
+// reference: al_i = (s_i . q) ro_i ; q -= al_i y_i ; r = q H ; be_i = (y_i . r) ro_i ; r += (al_i - be_i) s_i
+template <typename VT, typename AT>
+__device__ void lb_two_loop(const LbState& S, const LbVecs<VT>& V, const LbHist<VT, AT>& Hh, VT* dout, int lane) {
+    const int n = __builtin_amdgcn_readfirstlane(S.hist_len), head = __builtin_amdgcn_readfirstlane(S.hist_head);
+    VT q[LB_EPL];
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) q[e] = -V.g[e];
+    AT al0 = (AT)0, al1 = (AT)0;                 // al[i] lives in lane i & 63, register i >> 6
+    LbRow<VT, AT> ring[LB_PD];
+#pragma unroll
+    for (int u = 0; u < LB_PD; ++u) {
+        const int i = n - 1 - u;
+        if (i >= 0) lb_load_row(ring[u], Hh, (head + i) % LB_HIST, lane);
+    }
+    for (int base = n - 1; base >= 0; base -= LB_PD) {
+#pragma unroll
+        for (int u = 0; u < LB_PD; ++u) {
+            const int i = base - u;
+            if (i >= 0) {
+                const AT a = vdot<VT, AT>(ring[u].s, q) * ring[u].ro;
+                if (lane == (i & 63)) { if (i < 64) al0 = a; else al1 = a; }
+#pragma unroll
+                for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)fma(-a, (AT)ring[u].y[e], (AT)q[e]);
+                const int nx = i - LB_PD;
+                if (nx >= 0) lb_load_row(ring[u], Hh, (head + nx) % LB_HIST, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)((AT)q[e] * (AT)S.H);
+#pragma unroll
+    for (int u = 0; u < LB_PD; ++u)
+        if (u < n) lb_load_row(ring[u], Hh, (head + u) % LB_HIST, lane);
+    for (int base = 0; base < n; base += LB_PD) {
+#pragma unroll
+        for (int u = 0; u < LB_PD; ++u) {
+            const int i = base + u;
+            if (i < n) {
+                const AT be = vdot<VT, AT>(ring[u].y, q) * ring[u].ro;
+                const AT a = lane_read((i < 64) ? al0 : al1, i & 63);
+                const AT c = a - be;
+#pragma unroll
+                for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)fma(c, (AT)ring[u].s[e], (AT)q[e]);
+                const int nx = i + LB_PD;
+                if (nx < n) lb_load_row(ring[u], Hh, (head + nx) % LB_HIST, lane);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) dout[e] = q[e];
+}
+
 // Consume (f_new, gnew) of the last closure call, emit the next trial point into xt.
 // Returns with S.status == 1 when all stages are finished (xt = final x).
-// D <= 128; lane = threadIdx & 63.  mask[r] = 0 freezes an element (gradient forced to zero by
-// the caller already; kept here only for the gtol segments).
-template <typename VT>
-__device__ void lbfgs_advance(LbState& S, LbVecs<VT>& V, const LbHist<VT>& Hh, const LbOpts& O,
-                              double f_new, const VT* gnew, VT* xt, int lane, int D) {
+// lane = threadIdx & 63; element e of this lane is flat index LB_EPL * lane + e.
+template <typename VT, typename AT>
+__device__ void lbfgs_advance(LbState& S, LbVecs<VT>& V, const LbHist<VT, AT>& Hh, const LbOpts& O,
+                              double f_new, const VT* gnew, VT* xt, int lane, double* stage_final) {
     const double c1 = 1e-4, c2 = 0.9;
     const int max_ls = 25;
     double gtd_new = 0.0;
-    int idx[LB_NPL];
-#pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) idx[r] = lane + 64 * r;
 
     S.n_closure += 1;
     switch (S.phase) {
@@ -132,7 +198,7 @@ __device__ void lbfgs_advance(LbState& S, LbVecs<VT>& V, const LbHist<VT>& Hh, c
     S.orig_loss = f_new;
     S.loss = f_new;
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) V.g[r] = gnew[r];
+    for (int e = 0; e < LB_EPL; ++e) V.g[e] = gnew[e];
     S.cur_evals = 1;
     if (vmaxabs(V.g) <= O.tol_grad) goto L_step_return;
     S.n = 0;
@@ -143,80 +209,48 @@ L_iter:
     S.n_lbfgs += 1;
     if (S.n_iter == 1) {                                              // :312-317
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) V.d[r] = -V.g[r];
+        for (int e = 0; e < LB_EPL; ++e) V.d[e] = -V.g[e];
         S.hist_len = 0;
         S.hist_head = 0;
         S.H = 1.0;
     } else {                                                          // :318-358
-        VT y[LB_NPL], s[LB_NPL];
+        VT y[LB_EPL], s[LB_EPL];
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) {
-            y[r] = V.g[r] - V.pg[r];
-            s[r] = (VT)((double)V.d[r] * S.t);
+        for (int e = 0; e < LB_EPL; ++e) {
+            y[e] = V.g[e] - V.pg[e];
+            s[e] = (VT)((AT)V.d[e] * (AT)S.t);
         }
-        double ys = vdot(y, s);
-        if (ys > 1e-10) {
+        const AT ys = vdot<VT, AT>(y, s);
+        if (ys > (AT)1e-10) {
             if (S.hist_len == O.history) S.hist_head = (S.hist_head + 1) % LB_HIST;
             else S.hist_len += 1;
-            int slot = (S.hist_head + S.hist_len - 1) % LB_HIST;
+            const int slot = (S.hist_head + S.hist_len - 1) % LB_HIST;
+            if (LB_EPL * lane < LB_D) {
 #pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) {
-                Hh.dirs[slot * LB_D_STRIDE + idx[r]] = y[r];
-                Hh.stps[slot * LB_D_STRIDE + idx[r]] = s[r];
+                for (int e = 0; e < LB_EPL; ++e) {
+                    Hh.dirs[slot * LB_D + LB_EPL * lane + e] = y[e];
+                    Hh.stps[slot * LB_D + LB_EPL * lane + e] = s[e];
+                }
             }
-            if (lane == 0) Hh.ro[slot] = 1.0 / ys;
-            S.H = ys / vdot(y, y);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // ro[] is written by lane 0, read by all
+            if (lane == 0) Hh.ro[slot] = (AT)1 / ys;
+            S.H = (double)(ys / vdot<VT, AT>(y, y));
+            wave_lds_fence();                         // history is re-read by all lanes of this wave
         }
-        // two-loop recursion; al[i] kept lane-distributed (lane i%64, register i/64)
-        double al0 = 0.0, al1 = 0.0;
-        VT q[LB_NPL];
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) q[r] = -V.g[r];
-        for (int i = S.hist_len - 1; i >= 0; --i) {
-            int slot = (S.hist_head + i) % LB_HIST;
-            VT sv[LB_NPL], yv[LB_NPL];
-#pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) {
-                sv[r] = Hh.stps[slot * LB_D_STRIDE + idx[r]];
-                yv[r] = Hh.dirs[slot * LB_D_STRIDE + idx[r]];
-            }
-            double a = vdot(sv, q) * Hh.ro[slot];
-            if (lane == (i & 63)) { if (i < 64) al0 = a; else al1 = a; }
-#pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) q[r] = (VT)((double)q[r] - a * (double)yv[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) q[r] = (VT)((double)q[r] * S.H);
-        for (int i = 0; i < S.hist_len; ++i) {
-            int slot = (S.hist_head + i) % LB_HIST;
-            VT sv[LB_NPL], yv[LB_NPL];
-#pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) {
-                sv[r] = Hh.stps[slot * LB_D_STRIDE + idx[r]];
-                yv[r] = Hh.dirs[slot * LB_D_STRIDE + idx[r]];
-            }
-            double be = vdot(yv, q) * Hh.ro[slot];
-            double a = __shfl((i < 64) ? al0 : al1, i & 63, 64);
-#pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) q[r] = (VT)((double)q[r] + (a - be) * (double)sv[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) V.d[r] = q[r];
+        lb_two_loop<VT, AT>(S, V, Hh, V.d, lane);
     }
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) V.pg[r] = V.g[r];                // :360-364
+    for (int e = 0; e < LB_EPL; ++e) V.pg[e] = V.g[e];                // :360-364
     S.prev_loss = S.loss;
     if (S.n_iter == 1) {                                              // :370-373
-        double asum = 0.0;
+        AT asum = (AT)0;
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) asum += fabs((double)V.g[r]);
-        asum = wave_sum(asum);
-        S.t = fmin(1.0, 1.0 / asum) * O.lr;
+        for (int e = 0; e < LB_EPL; ++e) asum += fabs((AT)V.g[e]);
+        asum = wave64_sum(asum);
+        S.t = fmin(1.0, 1.0 / (double)asum) * O.lr;
     } else {
         S.t = O.lr;
     }
-    S.gtd = vdot(V.g, V.d);                                           // :376
+    S.gtd = (double)vdot<VT, AT>(V.g, V.d);                           // :376
     if (S.gtd > -O.tol_change) goto L_step_return;                    // :379-380
     // ---- _strong_Wolfe entry (:43-53) ----
     S.d_norm = vmaxabs(V.d);
@@ -227,17 +261,17 @@ L_iter:
 
 L_ls_first:
     S.ls_evals = 1;
-    gtd_new = vdot(gnew, V.d);
+    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
     S.t_prev = 0.0; S.f_prev = S.f0; S.gtd_prev = S.gtd;
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) V.gprev[r] = V.g[r];
+    for (int e = 0; e < LB_EPL; ++e) V.gprev[e] = V.g[e];
     S.ls_done = 0;
     S.ls_it = 0;
     goto L_bracket_check;
 
 L_ls_bracket:                                                         // :90-93
     S.ls_evals += 1;
-    gtd_new = vdot(gnew, V.d);
+    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
     S.ls_it += 1;
 
 L_bracket_check:                                                      // :54-93
@@ -246,9 +280,9 @@ L_bracket_check:                                                      // :54-93
         if (f_new > (S.f0 + c1 * S.t * S.gtd) || (S.ls_it > 1 && f_new >= S.f_prev)) {
             two_point = true;                                         // :56-61
         } else if (fabs(gtd_new) <= -c2 * S.gtd) {                    // :63-69
-            S.br[0] = S.t; S.bf[0] = f_new; S.bgtd[0] = gtd_new;
+            S.br0 = S.t; S.bf0 = f_new; S.bgtd0 = gtd_new;
 #pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) V.bg0[r] = gnew[r];
+            for (int e = 0; e < LB_EPL; ++e) V.bg0[e] = gnew[e];
             S.nbr = 1;
             S.ls_done = 1;
             goto L_bracket_end;
@@ -256,11 +290,11 @@ L_bracket_check:                                                      // :54-93
             two_point = true;
         }
         if (two_point) {
-            S.br[0] = S.t_prev; S.br[1] = S.t;
-            S.bf[0] = S.f_prev; S.bf[1] = f_new;
-            S.bgtd[0] = S.gtd_prev; S.bgtd[1] = gtd_new;
+            S.br0 = S.t_prev; S.br1 = S.t;
+            S.bf0 = S.f_prev; S.bf1 = f_new;
+            S.bgtd0 = S.gtd_prev; S.bgtd1 = gtd_new;
 #pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) { V.bg0[r] = V.gprev[r]; V.bg1[r] = gnew[r]; }
+            for (int e = 0; e < LB_EPL; ++e) { V.bg0[e] = V.gprev[e]; V.bg1[e] = gnew[e]; }
             S.nbr = 2;
             goto L_bracket_end;
         }
@@ -271,7 +305,7 @@ L_bracket_check:                                                      // :54-93
             S.t = lb_cubic(S.t_prev, S.f_prev, S.gtd_prev, S.t, f_new, gtd_new, true, min_step, max_step);
             S.t_prev = tmp; S.f_prev = f_new; S.gtd_prev = gtd_new;
 #pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) V.gprev[r] = gnew[r];
+            for (int e = 0; e < LB_EPL; ++e) V.gprev[e] = gnew[e];
         }
         S.phase = PH_LS_BRACKET;
         goto L_emit_trial;
@@ -279,20 +313,20 @@ L_bracket_check:                                                      // :54-93
 
 L_bracket_end:
     if (S.ls_it == max_ls) {                                          // :96-100
-        S.br[0] = 0.0; S.br[1] = S.t;
-        S.bf[0] = S.f0; S.bf[1] = f_new;
-        S.bgtd[0] = S.gtd; S.bgtd[1] = gtd_new;
+        S.br0 = 0.0; S.br1 = S.t;
+        S.bf0 = S.f0; S.bf1 = f_new;
+        S.bgtd0 = S.gtd; S.bgtd1 = gtd_new;
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) { V.bg0[r] = V.g[r]; V.bg1[r] = gnew[r]; }
+        for (int e = 0; e < LB_EPL; ++e) { V.bg0[e] = V.g[e]; V.bg1[e] = gnew[e]; }
         S.nbr = 2;
     }
     S.insuf = 0;
-    if (S.bf[0] <= S.bf[S.nbr - 1]) { S.low = 0; S.high = 1; } else { S.low = 1; S.high = 0; }
+    if (S.bf0 <= (S.nbr == 2 ? S.bf1 : S.bf0)) { S.low = 0; S.high = 1; } else { S.low = 1; S.high = 0; }
 
 L_zoom_check:                                                         // :108-130
     if (!S.ls_done && S.ls_it < O.max_iter) {
-        double tt = lb_cubic(S.br[0], S.bf[0], S.bgtd[0], S.br[1], S.bf[1], S.bgtd[1], false, 0, 0);
-        double bmax = fmax(S.br[0], S.br[1]), bmin = fmin(S.br[0], S.br[1]);
+        double tt = lb_cubic(S.br0, S.bf0, S.bgtd0, S.br1, S.bf1, S.bgtd1, false, 0, 0);
+        double bmax = fmax(S.br0, S.br1), bmin = fmin(S.br0, S.br1);
         double eps = 0.1 * (bmax - bmin);
         if (fmin(bmax - tt, tt - bmin) < eps) {
             if (S.insuf || tt >= bmax || tt <= bmin) {
@@ -312,52 +346,47 @@ L_zoom_check:                                                         // :108-13
 
 L_ls_zoom:                                                            // :130-161
     S.ls_evals += 1;
-    gtd_new = vdot(gnew, V.d);
+    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
     S.ls_it += 1;
-    if (f_new > (S.f0 + c1 * S.t * S.gtd) || f_new >= S.bf[S.low]) {
+    if (f_new > (S.f0 + c1 * S.t * S.gtd) || f_new >= LB_SEL(S, bf, S.low)) {
         int h = S.high;
-        S.br[h] = S.t; S.bf[h] = f_new; S.bgtd[h] = gtd_new;
+        LB_SET(S, h, S.t, f_new, gtd_new);
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) { if (h == 0) V.bg0[r] = gnew[r]; else V.bg1[r] = gnew[r]; }
-        if (S.bf[0] <= S.bf[1]) { S.low = 0; S.high = 1; } else { S.low = 1; S.high = 0; }
+        for (int e = 0; e < LB_EPL; ++e) { if (h == 0) V.bg0[e] = gnew[e]; else V.bg1[e] = gnew[e]; }
+        if (S.bf0 <= S.bf1) { S.low = 0; S.high = 1; } else { S.low = 1; S.high = 0; }
     } else {
         if (fabs(gtd_new) <= -c2 * S.gtd) {
             S.ls_done = 1;
-        } else if (gtd_new * (S.br[S.high] - S.br[S.low]) >= 0.0) {
+        } else if (gtd_new * (LB_SEL(S, br, S.high) - LB_SEL(S, br, S.low)) >= 0.0) {
             int h = S.high, l = S.low;
-            S.br[h] = S.br[l]; S.bf[h] = S.bf[l]; S.bgtd[h] = S.bgtd[l];
+            { const double t_ = LB_SEL(S, br, l), f_ = LB_SEL(S, bf, l), g_ = LB_SEL(S, bgtd, l); LB_SET(S, h, t_, f_, g_); }
 #pragma unroll
-            for (int r = 0; r < LB_NPL; ++r) { if (h == 0) V.bg0[r] = V.bg1[r]; else V.bg1[r] = V.bg0[r]; }
+            for (int e = 0; e < LB_EPL; ++e) { if (h == 0) V.bg0[e] = V.bg1[e]; else V.bg1[e] = V.bg0[e]; }
         }
         int l = S.low;
-        S.br[l] = S.t; S.bf[l] = f_new; S.bgtd[l] = gtd_new;
+        LB_SET(S, l, S.t, f_new, gtd_new);
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) { if (l == 0) V.bg0[r] = gnew[r]; else V.bg1[r] = gnew[r]; }
+        for (int e = 0; e < LB_EPL; ++e) { if (l == 0) V.bg0[e] = gnew[e]; else V.bg1[e] = gnew[e]; }
     }
-    if (fabs(S.br[1] - S.br[0]) * S.d_norm < O.tol_change) goto L_ls_return;
+    if (fabs(S.br1 - S.br0) * S.d_norm < O.tol_change) goto L_ls_return;
     goto L_zoom_check;
 
 L_ls_return:                                                          // :163-167, :393-399
     {
         int l = S.low;
-        S.loss = S.bf[l];
-        S.t = S.br[l];
+        S.loss = LB_SEL(S, bf, l);
+        S.t = LB_SEL(S, br, l);
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) {
-            V.g[r] = (l == 0) ? V.bg0[r] : V.bg1[r];
-            V.x[r] = (VT)((double)V.x[r] + S.t * (double)V.d[r]);
+        for (int e = 0; e < LB_EPL; ++e) {
+            V.g[e] = (l == 0) ? V.bg0[e] : V.bg1[e];
+            V.x[e] = (VT)fma((AT)S.t, (AT)V.d[e], (AT)V.x[e]);
         }
         S.cur_evals += S.ls_evals;
     }
     if (S.n == O.max_iter) goto L_step_return;                        // :419-434
     if (S.cur_evals >= O.max_eval) goto L_step_return;
     if (vmaxabs(V.g) <= O.tol_grad) goto L_step_return;
-    {
-        double m = 0.0;
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) m = fmax(m, fabs((double)V.d[r] * S.t));
-        if (wave_max(m) <= O.tol_change) goto L_step_return;
-    }
+    if (S.d_norm * fabs(S.t) <= O.tol_change) goto L_step_return;     // max|d t| == max|d| |t|
     if (fabs(S.loss - S.prev_loss) < O.tol_change) goto L_step_return;
     goto L_iter;
 
@@ -376,12 +405,14 @@ L_step_return:
                 // all(|max(grad_tensor)| < gtol): grad of the LAST closure call (= gnew)
                 bool all_small = true;
                 for (int sgi = 0; sgi < O.nseg; ++sgi) {
-                    double m = -INFINITY;
+                    VT m = (VT)-INFINITY;
 #pragma unroll
-                    for (int r = 0; r < LB_NPL; ++r)
-                        if (idx[r] >= O.seg_lo[sgi] && idx[r] < O.seg_hi[sgi]) m = fmax(m, (double)gnew[r]);
-                    m = wave_max(m);
-                    if (!(fabs(m) < O.gtol)) all_small = false;
+                    for (int e = 0; e < LB_EPL; ++e) {
+                        const int ix = LB_EPL * lane + e;
+                        if (ix >= O.seg_lo[sgi] && ix < O.seg_hi[sgi]) m = fmax(m, gnew[e]);
+                    }
+                    m = wave64_max(m);
+                    if (!(fabs((double)m) < O.gtol)) all_small = false;
                 }
                 if (all_small) stop = true;
             }
@@ -389,7 +420,7 @@ L_step_return:
         }
         S.outer_n += 1;
         if (stop || S.outer_n >= O.maxiters) {
-            S.stage_final[S.stage] = S.has_outer_prev ? S.outer_prev : (double)NAN;
+            if (lane == 0) stage_final[S.stage] = S.has_outer_prev ? S.outer_prev : (double)NAN;
             S.stage += 1;
             S.outer_n = 0;
             S.has_outer_prev = 0;
@@ -400,14 +431,13 @@ L_step_return:
         }
         S.phase = PH_STEP_START;
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) xt[r] = V.x[r];
+        for (int e = 0; e < LB_EPL; ++e) xt[e] = V.x[e];
         return;
     }
 
 L_emit_trial:                                                         // _directional_evaluate :249-254
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) xt[r] = (VT)((double)V.x[r] + S.t * (double)V.d[r]);
-    (void)D;
+    for (int e = 0; e < LB_EPL; ++e) xt[e] = (VT)fma((AT)S.t, (AT)V.d[e], (AT)V.x[e]);
     return;
 }
 

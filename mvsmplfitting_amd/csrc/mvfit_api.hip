@@ -26,8 +26,6 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
                               hipStream_t stream);
 hipError_t vertex_pass_configure();
 
-constexpr int STEP_NT = 256;
-
 #ifdef MVFIT_TIMING
 __device__ long long g_dbg[16];
 #define DBG_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[k] += clock64() - t_last; if (threadIdx.x == 0) t_last = clock64(); } while (0)
@@ -40,93 +38,144 @@ struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
 // per-problem optimiser storage in HBM
 struct FitBuffers {
     LbState* S;          // [B]
-    float* vecs;         // [B][8][128]: x d g pg gprev bg0 bg1 xt
-    float* dirs;         // [B][100][128]
-    float* stps;         // [B][100][128]
-    double* ro;          // [B][100]
+    float* vecs;         // [B][LB_NVEC][LB_D]: x d g pg gprev bg0 bg1 (compact order)
+    float* xt;           // [B][DPAD]: current trial point, flat parameter layout
+    float* dirs;         // [B][100][LB_D]
+    float* stps;         // [B][100][LB_D]
+    float* ro;           // [B][100]
+    double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
     int* n_done;         // [1]
 };
 
-__device__ __forceinline__ void load_x(ClosureLds& L, const float* src, int tid, int nt) {
-    for (int i = tid; i < DPAD; i += nt) L.x[i] = (i < DV) ? src[i] : 0.f;
+// compact optimiser index (reference final_params order, non_linear_solver.py:164-170) -> flat x slot
+__device__ __forceinline__ int cmap(int i, bool use_vp) {
+    if (!use_vp) return i;                         // betas go body_pose transl scale = x[0:86]
+    return i < 13 ? i : (i < 17 ? X_TR + (i - 13) : X_EMB + (i - 17));   // betas go transl scale embedding
+}
+__device__ __forceinline__ int dact(bool use_vp) { return use_vp ? 49 : 86; }
+
+__device__ __forceinline__ void load_x(ClosureLds& L, const float* src, int tid) {
+    if (tid < DPAD) L.x[tid] = (tid < DV) ? src[tid] : 0.f;
+}
+
+// pose operands of the vertex pass only: E1 + chain
+__device__ __forceinline__ void pose_and_chain(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+    pose_prep(M, L, flags, tid);
+    if (tid < 64) chain_forward_wave(L, tid);
     __syncthreads();
 }
 
-__global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, DevPose P, const float* __restrict__ params,
-                                                       int xstride, uint32_t flags) {
+__global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, DevProblems Q, DevPose P,
+                                                       const float* __restrict__ params, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    load_x(L, params + (size_t)b * xstride, tid, STEP_NT);
-    pose_prep(M, L, flags, tid, STEP_NT);
-    publish_pose(L, P, b, tid, STEP_NT);
+    lds_load_constants(L, M, Q, b, tid);
+    load_x(L, params + (size_t)b * DV, tid);
+    __syncthreads();
+    pose_and_chain(M, L, flags, tid);
+    publish_pose(L, P, b, tid);
 }
 
-__global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, DevProblems Q, DevWeights W,
-                                                          const float* __restrict__ params,
-                                                          const float* __restrict__ verts,
+__global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, DevProblems Q, DevWeights W, DevPose P,
+                                                          const float* __restrict__ params, int from_pass,
                                                           float* __restrict__ loss, float* __restrict__ grad,
                                                           float* __restrict__ joints) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    load_x(L, params + (size_t)b * DV, tid, STEP_NT);
-    pose_prep(M, L, W.flags, tid, STEP_NT);
-    const float* vb = (verts && !(W.flags & MVFIT_F_SPARSE_VERTS)) ? verts + (size_t)b * M.nv * 3 : nullptr;
-    sparse_forward(M, L, vb, tid, STEP_NT);
+    lds_load_constants(L, M, Q, b, tid);
+    load_x(L, params + (size_t)b * DV, tid);
+    __syncthreads();
+    pose_prep(M, L, W.flags, tid);
+    const float* vpp = from_pass ? P.vposed_sel + (size_t)b * NC_MAX : nullptr;
+    const float* xsp = from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr;
+    sparse_forward(M, L, vpp, xsp, tid);
     const bool want_grad = grad != nullptr;
-    const double total = loss_and_keypoint_grad(M, L, Q, b, W, want_grad, tid, STEP_NT);
+    const double total = loss_and_keypoint_grad(M, L, Q.V, W, want_grad, tid);
     if (tid == 0 && loss) loss[b] = (float)total;
-    if (joints) for (int i = tid; i < NKP * 3; i += STEP_NT) joints[(size_t)b * NKP * 3 + i] = (&L.kp[0][0])[i];
+    if (joints && tid < NKP * 3) joints[(size_t)b * NKP * 3 + tid] = (&L.kp[0][0])[tid];
     if (want_grad) {
-        closure_backward(M, L, W, tid, STEP_NT);
-        for (int i = tid; i < DV; i += STEP_NT) grad[(size_t)b * DV + i] = L.grad[i];
+        closure_backward(M, L, Q.V, W, tid);
+        if (tid < DV) grad[(size_t)b * DV + tid] = L.grad[tid];
     }
 }
 
 // keypoints only (mvfit_vertices): gather from the vertex buffer
-__global__ __launch_bounds__(STEP_NT) void joints_kernel(DevModel M, const float* __restrict__ verts,
-                                                         float* __restrict__ joints) {
+__global__ __launch_bounds__(64) void joints_kernel(DevModel M, const float* __restrict__ verts,
+                                                    float* __restrict__ joints) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < NKP * 3; i += STEP_NT) {
-        const int k = i / 3, a = i - 3 * k;
+    const ModelLds& C = *M.mlds;
+    if (tid < NKP * 3) {
+        const int k = tid / 3, a = tid - 3 * k;
         float s = 0.f;
-        for (int v = 0; v < M.ns; ++v)
-            s = fmaf(M.ksel_sub[k * NS_MAX + v], verts[((size_t)b * M.nv + M.sel_v[v]) * 3 + a], s);
-        joints[(size_t)b * NKP * 3 + i] = s;      // rows of the selection sum to 1 (+transl already in verts)
+        for (int t = C.kp_start[k]; t < C.kp_start[k + 1]; ++t)
+            s = fmaf(C.kp_w[t], verts[((size_t)b * M.nv + C.sel_v[C.kp_s[t]]) * 3 + a], s);
+        joints[(size_t)b * NKP * 3 + tid] = s;      // rows of the selection sum to 1 (+transl already in verts)
     }
 }
 
 __device__ __forceinline__ void lb_load(LbVecs<float>& V, const float* base, int lane) {
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) {
-        const int i = lane + 64 * r;
-        V.x[r] = base[0 * 128 + i]; V.d[r] = base[1 * 128 + i]; V.g[r] = base[2 * 128 + i];
-        V.pg[r] = base[3 * 128 + i]; V.gprev[r] = base[4 * 128 + i]; V.bg0[r] = base[5 * 128 + i];
-        V.bg1[r] = base[6 * 128 + i];
+    for (int e = 0; e < LB_EPL; ++e) {
+        const int i = LB_EPL * lane + e;
+        const bool in = i < LB_D;
+        V.x[e] = in ? base[0 * LB_D + i] : 0.f; V.d[e] = in ? base[1 * LB_D + i] : 0.f;
+        V.g[e] = in ? base[2 * LB_D + i] : 0.f; V.pg[e] = in ? base[3 * LB_D + i] : 0.f;
+        V.gprev[e] = in ? base[4 * LB_D + i] : 0.f; V.bg0[e] = in ? base[5 * LB_D + i] : 0.f;
+        V.bg1[e] = in ? base[6 * LB_D + i] : 0.f;
     }
 }
 __device__ __forceinline__ void lb_store(const LbVecs<float>& V, float* base, int lane) {
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) {
-        const int i = lane + 64 * r;
-        base[0 * 128 + i] = V.x[r]; base[1 * 128 + i] = V.d[r]; base[2 * 128 + i] = V.g[r];
-        base[3 * 128 + i] = V.pg[r]; base[4 * 128 + i] = V.gprev[r]; base[5 * 128 + i] = V.bg0[r];
-        base[6 * 128 + i] = V.bg1[r];
+    for (int e = 0; e < LB_EPL; ++e) {
+        const int i = LB_EPL * lane + e;
+        if (i < LB_D) {
+            base[0 * LB_D + i] = V.x[e]; base[1 * LB_D + i] = V.d[e]; base[2 * LB_D + i] = V.g[e];
+            base[3 * LB_D + i] = V.pg[e]; base[4 * LB_D + i] = V.gprev[e]; base[5 * LB_D + i] = V.bg0[e];
+            base[6 * LB_D + i] = V.bg1[e];
+        }
     }
+}
+// optimiser state global <-> LDS (all threads; followed by a barrier at the call site)
+__device__ __forceinline__ void lb_state_in(ClosureLds& L, const FitBuffers& F, int b, int tid) {
+    const float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
+    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) (&L.lbV[0][0])[i] = vb[i];
+    constexpr int nw = sizeof(LbState) / 4;
+    const int* src = reinterpret_cast<const int*>(F.S + b);
+    if (tid < nw) reinterpret_cast<int*>(&L.lbS)[tid] = src[tid];
+    if (tid >= 64 && tid < 64 + LB_HIST) L.lb_ro[tid - 64] = F.ro[(size_t)b * LB_HIST + tid - 64];
+    if (tid == 0) { L.sh_stage = F.S[b].stage; L.sh_status = 0; }
+}
+__device__ __forceinline__ void opts_in(ClosureLds& L, const StageWeights& SW, const LbOpts& O, int tid) {
+    constexpr int nsw = sizeof(StageWeights) / 4, nop = sizeof(LbOpts) / 4;
+    if (tid < nsw) reinterpret_cast<int*>(&L.sw[0])[tid] = reinterpret_cast<const int*>(&SW)[tid];
+    if (tid >= 128 && tid < 128 + nop) reinterpret_cast<int*>(&L.opts)[tid - 128] = reinterpret_cast<const int*>(&O)[tid - 128];
+}
+__device__ __forceinline__ void lb_state_out(const ClosureLds& L, const FitBuffers& F, int b, int tid) {
+    float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
+    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) vb[i] = (&L.lbV[0][0])[i];
+    constexpr int nw = sizeof(LbState) / 4;
+    int* dst = reinterpret_cast<int*>(F.S + b);
+    if (tid < nw) dst[tid] = reinterpret_cast<const int*>(&L.lbS)[tid];
+    if (tid >= 64 && tid < 64 + LB_HIST) F.ro[(size_t)b * LB_HIST + tid - 64] = L.lb_ro[tid - 64];
+    if (tid < DPAD) F.xt[(size_t)b * DPAD + tid] = L.x[tid];
 }
 
 // initialise the optimiser state of every problem: x = params, first trial point = x
-__global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevPose P, FitBuffers F,
-                                                           const float* __restrict__ params, uint32_t flags) {
+__global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevProblems Q, DevPose P, FitBuffers F,
+                                                           const float* __restrict__ params, uint32_t flags,
+                                                           int publish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    float* vb = F.vecs + (size_t)b * 8 * 128;
-    for (int i = tid; i < 8 * 128; i += STEP_NT) {
-        const int r = i >> 7, e = i & 127;
-        vb[i] = ((r == 0 || r == 7) && e < DV) ? params[(size_t)b * DV + e] : 0.f;
+    const bool use_vp = (flags & MVFIT_F_VPOSER) != 0;
+    float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
+    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) {
+        const int r = i / LB_D, e = i - r * LB_D;
+        vb[i] = (r == 0 && e < dact(use_vp)) ? params[(size_t)b * DV + cmap(e, use_vp)] : 0.f;
     }
+    if (tid < DPAD) F.xt[(size_t)b * DPAD + tid] = tid < DV ? params[(size_t)b * DV + tid] : 0.f;
     if (tid == 0) {
         LbState s;
         memset(&s, 0, sizeof(s));
@@ -134,112 +183,132 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevPose P
         s.H = 1.0;
         F.S[b] = s;
     }
-    load_x(L, params + (size_t)b * DV, tid, STEP_NT);
-    pose_prep(M, L, flags, tid, STEP_NT);
-    publish_pose(L, P, b, tid, STEP_NT);
+    if (tid < MVFIT_MAX_STAGES) F.stage_final[(size_t)b * MVFIT_MAX_STAGES + tid] = (double)NAN;
+    if (publish) {
+        lds_load_constants(L, M, Q, b, tid);
+        load_x(L, params + (size_t)b * DV, tid);
+        __syncthreads();
+        pose_and_chain(M, L, flags, tid);
+        publish_pose(L, P, b, tid);
+    }
 }
 
 // shared by the two fit kernels: evaluate the closure at L.x, advance the optimiser, leave the
 // next trial point in L.x.  Returns true when the problem is finished.
-__device__ bool fit_round(const DevModel& M, ClosureLds& L, const DevProblems& Q, const StageWeights& SW,
-                          const LbOpts& O, LbState& S, LbVecs<float>& V, const LbHist<float>& H,
-                          const float* verts_b, int b, int tid) {
-    const DevWeights& W = SW.w[S.stage];
+__device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float, float>& H,
+                          const float* vposed_pass, const float* xs_pass, double* stage_final, int tid) {
+    DevWeights W = L.sw[L.sh_stage];
+    W.flags = __builtin_amdgcn_readfirstlane(W.flags);
+    const LbOpts& O = L.opts;
+    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
 #ifdef MVFIT_TIMING
     long long t_last = clock64();
 #endif
-    pose_prep(M, L, W.flags, tid, STEP_NT);
+    pose_prep(M, L, W.flags, tid);
     DBG_T(0);
-    sparse_forward(M, L, verts_b, tid, STEP_NT);
+    sparse_forward(M, L, vposed_pass, xs_pass, tid);
     DBG_T(1);
-    const double total = loss_and_keypoint_grad(M, L, Q, b, W, true, tid, STEP_NT);
+    const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     DBG_T(2);
-    closure_backward(M, L, W, tid, STEP_NT);
+    closure_backward(M, L, nviews, W, tid);
     DBG_T(3);
     if (tid < 64) {
-        float gnew[LB_NPL], xt[LB_NPL];
+        const int D = dact(use_vp);
+        LbState S = L.lbS;
+        LbVecs<float> V;
+        lb_load(V, &L.lbV[0][0], tid);
+        float gnew[LB_EPL], xt[LB_EPL];
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) gnew[r] = L.grad[tid + 64 * r];
+        for (int e = 0; e < LB_EPL; ++e) {
+            const int i = LB_EPL * tid + e;
+            gnew[e] = i < D ? L.grad[cmap(i, use_vp)] : 0.f;
+        }
         // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
-        lbfgs_advance<float>(S, V, H, O, (double)(float)total, gnew, xt, tid, DV);
+        lbfgs_advance<float, float>(S, V, H, O, (double)(float)total, gnew, xt, tid, stage_final);
+        lb_store(V, &L.lbV[0][0], tid);
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) L.x[tid + 64 * r] = xt[r];
-        if (tid == 0) { L.sh_stage = S.stage; L.sh_status = S.status; }
+        for (int e = 0; e < LB_EPL; ++e) {
+            const int i = LB_EPL * tid + e;
+            if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+        }
+        if (tid == 0) { L.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
+#ifdef MVFIT_TIMING
+        if (blockIdx.x == 0 && tid == 0) { g_dbg[5] += 1; g_dbg[6] += S.hist_len; }
+#endif
     }
     DBG_T(4);
-#ifdef MVFIT_TIMING
-    if (blockIdx.x == 0 && tid == 0) { g_dbg[5] += 1; g_dbg[6] += S.hist_len; }
-#endif
     __syncthreads();
-    S.stage = L.sh_stage;            // waves 1.. only track the scalars they need
-    S.status = L.sh_status;
-    return S.status != 0;
+    return L.sh_status != 0;
 }
 
+// one closure round per launch (full mode): the objective reads the vertex pass's output for its
+// vertices; afterwards the pose operands of the NEXT trial point are published for the next pass.
 __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
-                                                           DevPose P, FitBuffers F,
-                                                           const float* __restrict__ verts) {
+                                                           DevPose P, FitBuffers F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     if (F.S[b].status != 0) return;                       // uniform per block
-    float* vb = F.vecs + (size_t)b * 8 * 128;
-    load_x(L, vb + 7 * 128, tid, STEP_NT);
-    LbState S = F.S[b];
-    LbVecs<float> V;
-    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * 128, F.stps + (size_t)b * LB_HIST * 128,
-                    F.ro + (size_t)b * LB_HIST};
-    if (tid < 64) lb_load(V, vb, tid);
-    const bool done = fit_round(M, L, Q, SW, O, S, V, H, verts + (size_t)b * M.nv * 3, b, tid);
-    if (tid < 64) {
-        lb_store(V, vb, tid);
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) vb[7 * 128 + tid + 64 * r] = L.x[tid + 64 * r];
-        if (tid == 0) { F.S[b] = S; if (done) atomicAdd(F.n_done, 1); }
-    }
+    lds_load_constants(L, M, Q, b, tid);
+    load_x(L, F.xt + (size_t)b * DPAD, tid);
+    lb_state_in(L, F, b, tid);
+    opts_in(L, SW, O, tid);
+    LbHist<float, float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.lb_ro};
     __syncthreads();
+    const bool done = fit_round(M, L, Q.V, H, P.vposed_sel + (size_t)b * NC_MAX,
+                                P.xs_sel + (size_t)b * NC_MAX, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
+    lb_state_out(L, F, b, tid);
+    if (tid == 0 && done) atomicAdd(F.n_done, 1);
     // pose operands of the next trial point (also after the last round: final vertices)
-    const uint32_t flags = SW.w[min(S.stage, O.num_stages - 1)].flags;
-    pose_prep(M, L, flags, tid, STEP_NT);
-    publish_pose(L, P, b, tid, STEP_NT);
+    pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
+    publish_pose(L, P, b, tid);
 }
 
-__global__ __launch_bounds__(STEP_NT) void fit_sparse_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
-                                                             DevPose P, FitBuffers F, int max_rounds) {
+// the whole fit of one problem in a single launch (objective-vertices-only closure): the L-BFGS
+// history ring lives in LDS behind the closure workspace.
+__global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
+                                                                 DevPose P, FitBuffers F, int max_rounds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
+    float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
     const int b = blockIdx.x, tid = threadIdx.x;
     if (F.S[b].status != 0) return;
-    float* vb = F.vecs + (size_t)b * 8 * 128;
-    load_x(L, vb + 7 * 128, tid, STEP_NT);
-    LbState S = F.S[b];
-    LbVecs<float> V;
-    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * 128, F.stps + (size_t)b * LB_HIST * 128,
-                    F.ro + (size_t)b * LB_HIST};
-    if (tid < 64) lb_load(V, vb, tid);
-    for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
-        if (fit_round(M, L, Q, SW, O, S, V, H, nullptr, b, tid)) break;     // block-uniform
-    }
-    if (tid < 64) {
-        lb_store(V, vb, tid);
-#pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) vb[7 * 128 + tid + 64 * r] = L.x[tid + 64 * r];
-        if (tid == 0) { F.S[b] = S; if (S.status) atomicAdd(F.n_done, 1); }
-    }
+    lds_load_constants(L, M, Q, b, tid);
+    load_x(L, F.xt + (size_t)b * DPAD, tid);
+    lb_state_in(L, F, b, tid);
+    opts_in(L, SW, O, tid);
+    float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
+    float* gs = F.stps + (size_t)b * LB_HIST * LB_D;
+    const bool resume = F.S[b].n_closure > 0;             // relaunch after a round cap: restore the ring
+    if (resume)
+        for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { hist[i] = gd[i]; hist[LB_HIST * LB_D + i] = gs[i]; }
+    LbHist<float, float> H{hist, hist + LB_HIST * LB_D, L.lb_ro};
     __syncthreads();
-    pose_prep(M, L, SW.w[min(S.stage, O.num_stages - 1)].flags, tid, STEP_NT);
-    publish_pose(L, P, b, tid, STEP_NT);
+    bool done = false;
+    for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
+        // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address
+        // of the closure out of the round loop (which costs >256 live VGPRs and spills)
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        done = fit_round(M, L, Q.V, H, nullptr, nullptr, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t);
+        if (done) break;                                  // block-uniform
+    }
+    lb_state_out(L, F, b, tid);
+    if (tid == 0 && done) atomicAdd(F.n_done, 1);
+    if (!done)
+        for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
+    pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
+    publish_pose(L, P, b, tid);
 }
 
 __global__ void fit_finish_kernel(FitBuffers F, float* __restrict__ params, float* __restrict__ final_loss,
                                   int32_t* __restrict__ n_closure, int32_t* __restrict__ n_iter, int B,
                                   int num_stages) {
     const int b = blockIdx.x;
-    const float* vb = F.vecs + (size_t)b * 8 * 128;
-    for (int i = threadIdx.x; i < DV; i += blockDim.x) params[(size_t)b * DV + i] = vb[i];
+    for (int i = threadIdx.x; i < DV; i += blockDim.x) params[(size_t)b * DV + i] = F.xt[(size_t)b * DPAD + i];
     if (threadIdx.x == 0) {
         const LbState& s = F.S[b];
-        if (final_loss) final_loss[b] = (float)s.stage_final[num_stages - 1];
+        if (final_loss) final_loss[b] = (float)F.stage_final[(size_t)b * MVFIT_MAX_STAGES + num_stages - 1];
         if (n_closure) n_closure[b] = s.n_closure;
         if (n_iter) n_iter[b] = s.n_lbfgs;
     }
@@ -285,27 +354,27 @@ __device__ double kat_eval(int kind, int D, const double* x, double* g) {
 __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O, double* x_io, double* trace,
                                                        int max_trace, int* n_closure, double* final_loss,
                                                        double* dirs, double* stps, double* ro) {
-    __shared__ double xs[128], gs[128];
+    __shared__ double xs[LB_D], gs[LB_D];
     __shared__ double fsh;
     const int lane = threadIdx.x;
     LbState S;
     memset(&S, 0, sizeof(S));
     S.phase = PH_STEP_START; S.H = 1.0;
     LbVecs<double> V;
-    LbHist<double> H{dirs, stps, ro};
+    LbHist<double, double> H{dirs, stps, ro};
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) {
-        const int i = lane + 64 * r;
-        V.x[r] = i < D ? x_io[i] : 0.0;
-        V.d[r] = V.g[r] = V.pg[r] = V.gprev[r] = V.bg0[r] = V.bg1[r] = 0.0;
+    for (int e = 0; e < LB_EPL; ++e) {
+        const int i = LB_EPL * lane + e;
+        V.x[e] = i < D ? x_io[i] : 0.0;
+        V.d[e] = V.g[e] = V.pg[e] = V.gprev[e] = V.bg0[e] = V.bg1[e] = 0.0;
     }
-    double xt[LB_NPL];
+    double xt[LB_EPL];
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) xt[r] = V.x[r];
+    for (int e = 0; e < LB_EPL; ++e) xt[e] = V.x[e];
     int ncl = 0;
     for (int round = 0; round < 100000; ++round) {
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) xs[lane + 64 * r] = xt[r];
+        for (int e = 0; e < LB_EPL; ++e) if (LB_EPL * lane + e < LB_D) xs[LB_EPL * lane + e] = xt[e];
         __syncthreads();
         if (lane == 0) fsh = kat_eval(kind, D, xs, gs);
         __syncthreads();
@@ -315,16 +384,16 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
             trace[(size_t)ncl * (D + 1) + D] = f;
         }
         ncl += 1;
-        double gnew[LB_NPL];
+        double gnew[LB_EPL];
 #pragma unroll
-        for (int r = 0; r < LB_NPL; ++r) gnew[r] = (lane + 64 * r < D) ? gs[lane + 64 * r] : 0.0;
+        for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
-        lbfgs_advance<double>(S, V, H, O, f, gnew, xt, lane, D);
+        lbfgs_advance<double, double>(S, V, H, O, f, gnew, xt, lane, final_loss);
         if (S.status) break;
     }
 #pragma unroll
-    for (int r = 0; r < LB_NPL; ++r) if (lane + 64 * r < D) x_io[lane + 64 * r] = V.x[r];
-    if (lane == 0) { *n_closure = ncl; *final_loss = S.stage_final[0]; }
+    for (int e = 0; e < LB_EPL; ++e) if (LB_EPL * lane + e < D) x_io[LB_EPL * lane + e] = V.x[e];
+    if (lane == 0) *n_closure = ncl;
 }
 
 }  // namespace mvfit
@@ -347,9 +416,14 @@ struct mvfit_ctx {
     DevPose P{};
     float* d_verts = nullptr;          // [B][nv][3] internal vertex buffer
     FitBuffers F{};
+    int* h_done = nullptr;             // pinned
     int ksplit = 4;
     bool has_vposer = false;
     int gmm_M = 0;
+    // full-mode round loop captured as a graph: key = everything baked into the kernel nodes
+    hipGraphExec_t round_graph = nullptr;
+    std::vector<unsigned char> graph_key;
+    int graph_rounds = 0;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
@@ -379,7 +453,13 @@ static T* dev_upload(mvfit_ctx* c, const std::vector<T>& h) {
     return d;
 }
 
-static size_t step_lds() { return sizeof(ClosureLds); }
+static size_t step_lds() { return (sizeof(ClosureLds) + 15) & ~(size_t)15; }
+static size_t persistent_lds() { return step_lds() + (size_t)2 * LB_HIST * LB_D * sizeof(float); }
+
+static void drop_graph(mvfit_ctx* c) {
+    if (c->round_graph) { hipGraphExecDestroy(c->round_graph); c->round_graph = nullptr; }
+    c->graph_key.clear();
+}
 
 extern "C" const char* mvfit_last_error(const mvfit_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
@@ -399,6 +479,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     M.ntiles = (nv + TILE_V - 1) / TILE_V;
     M.nv_pad = M.ntiles * TILE_V;
     if (m->parents[0] >= 0) return fail(c, MVFIT_E_ARG, "parents[0] must be -1");
+    if (persistent_lds() > 160 * 1024) return fail(c, MVFIT_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", persistent_lds());
 
     // ---- blendshape basis, re-tiled in MFMA B-operand order: [tile][coord][group][lane][4] ----
     // element (tile T, coord k, group g, lane l, q): row p = 2*(4g+q) + (l>>5), vertex v = 32T + (l&31)
@@ -430,25 +511,24 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 wt[((size_t)(v / 32) * NJ + j) * 32 + (v % 32)] = m->lbs_weights[(size_t)v * NJ + j];
         M.wt_tiles = dev_upload(c, wt);
     }
-    // ---- joints as an affine function of beta (float64 accumulation on the host) ----
-    {
-        std::vector<float> Jt(NJ * 3), JS(NJ * 3 * 10);
-        for (int j = 0; j < NJ; ++j)
-            for (int a = 0; a < 3; ++a) {
-                double s = 0.0, sl[10] = {0};
-                for (int v = 0; v < nv; ++v) {
-                    const double w = m->J_regressor[(size_t)j * nv + v];
-                    if (w == 0.0) continue;
-                    s += w * m->v_template[3 * v + a];
-                    for (int l = 0; l < 10; ++l) sl[l] += w * m->shapedirs[((size_t)v * 3 + a) * 10 + l];
-                }
-                Jt[j * 3 + a] = (float)s;
-                for (int l = 0; l < 10; ++l) JS[(j * 3 + a) * 10 + l] = (float)sl[l];
+    // ---- the LDS image of the per-problem kernels ----
+    std::vector<ModelLds> imgv(1);
+    ModelLds& G = imgv[0];
+    memset(&G, 0, sizeof(G));
+    // joints as an affine function of beta (float64 accumulation on the host)
+    for (int j = 0; j < NJ; ++j)
+        for (int a = 0; a < 3; ++a) {
+            double s = 0.0, sl[10] = {0};
+            for (int v = 0; v < nv; ++v) {
+                const double w = m->J_regressor[(size_t)j * nv + v];
+                if (w == 0.0) continue;
+                s += w * m->v_template[3 * v + a];
+                for (int l = 0; l < 10; ++l) sl[l] += w * m->shapedirs[((size_t)v * 3 + a) * 10 + l];
             }
-        M.J_t = dev_upload(c, Jt);
-        M.J_S = dev_upload(c, JS);
-    }
-    // ---- the vertices the objective reads: non-zero columns of the mapped 17 x Nv selection ----
+            G.J_t[j * 3 + a] = (float)s;
+            for (int l = 0; l < 10; ++l) G.J_S[j * 3 + a][l] = (float)sl[l];
+        }
+    // the vertices the objective reads: non-zero columns of the mapped 17 x Nv selection
     {
         std::vector<double> ksel((size_t)NKP * nv, 0.0);
         for (int k = 0; k < NKP; ++k) {
@@ -471,14 +551,15 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         M.ns = (int)sel.size();
         M.nc = 3 * M.ns;
         M.nc_pad = (M.nc + 3) & ~3;
+        G.ns = M.ns; G.nc = M.nc; G.nc_pad = M.nc_pad;
         M.sel_v = dev_upload(c, sel);
-        std::vector<float> vts(M.nc_pad, 0.f), pds((size_t)KROWS * M.nc_pad, 0.f), pdsT((size_t)M.nc_pad * KROWS, 0.f),
-            ws((size_t)M.ns * NJ), ks((size_t)NKP * NS_MAX, 0.f);
+        std::vector<float> pds((size_t)KROWS * M.nc_pad, 0.f), pdsT((size_t)M.nc_pad * KROWS, 0.f);
         for (int s = 0; s < M.ns; ++s) {
             const int v = sel[s];
+            G.sel_v[s] = v;
             for (int a = 0; a < 3; ++a) {
                 const int cidx = 3 * s + a;
-                vts[cidx] = m->v_template[3 * v + a];
+                G.vt_sub[cidx] = m->v_template[3 * v + a];
                 for (int p = 0; p < 217; ++p) {
                     const float val = p < 207 ? m->posedirs[(size_t)p * nv * 3 + 3 * v + a]
                                               : m->shapedirs[((size_t)v * 3 + a) * 10 + (p - 207)];
@@ -486,39 +567,70 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                     pdsT[(size_t)cidx * KROWS + p] = val;
                 }
             }
-            for (int j = 0; j < NJ; ++j) ws[(size_t)s * NJ + j] = m->lbs_weights[(size_t)v * NJ + j];
-            for (int k = 0; k < NKP; ++k) ks[(size_t)k * NS_MAX + s] = (float)ksel[(size_t)k * nv + v];
+            for (int j = 0; j < NJ; ++j) G.wT[j][s] = m->lbs_weights[(size_t)v * NJ + j];
         }
-        M.vt_sub = dev_upload(c, vts);
         M.pd_sub = dev_upload(c, pds);
         M.pd_subT = dev_upload(c, pdsT);
-        M.w_sub = dev_upload(c, ws);
-        M.ksel_sub = dev_upload(c, ks);
+        // selection in CSR form, both ways
+        int nnz = 0;
+        for (int k = 0; k < NKP; ++k) {
+            G.kp_start[k] = nnz;
+            for (int s = 0; s < M.ns; ++s) {
+                const double w = ksel[(size_t)k * nv + sel[s]];
+                if (w == 0.0) continue;
+                if (nnz >= KNNZ_MAX) return fail(c, MVFIT_E_UNSUPPORTED, "keypoint selection has more than %d non-zeros", KNNZ_MAX);
+                G.kp_s[nnz] = s; G.kp_w[nnz] = (float)w; ++nnz;
+            }
+        }
+        G.kp_start[NKP] = nnz;
+        nnz = 0;
+        for (int s = 0; s < M.ns; ++s) {
+            G.vs_start[s] = nnz;
+            for (int k = 0; k < NKP; ++k) {
+                const double w = ksel[(size_t)k * nv + sel[s]];
+                if (w == 0.0) continue;
+                G.vs_k[nnz] = k; G.vs_w[nnz] = (float)w; ++nnz;
+            }
+        }
+        for (int s = M.ns; s <= NS_MAX; ++s) G.vs_start[s] = nnz;
+        // per-tile lists for the vertex pass side outputs
+        std::vector<int> tstart(M.ntiles + 1, 0), tlocal(std::max(M.ns, 1)), tslot(std::max(M.ns, 1));
+        int pos = 0;
+        for (int T = 0; T < M.ntiles; ++T) {
+            tstart[T] = pos;
+            for (int s = 0; s < M.ns; ++s)
+                if (sel[s] / TILE_V == T) { tlocal[pos] = sel[s] % TILE_V; tslot[pos] = s; ++pos; }
+        }
+        tstart[M.ntiles] = pos;
+        M.tile_sel_start = dev_upload(c, tstart);
+        M.tile_sel_local = dev_upload(c, tlocal);
+        M.tile_sel_slot = dev_upload(c, tslot);
     }
-    // ---- kinematic tree: levels and child lists ----
+    // kinematic tree: levels and child lists
     {
         int depth[NJ];
         for (int j = 0; j < NJ; ++j) {
-            M.parents[j] = m->parents[j];
+            G.parents[j] = m->parents[j];
             if (j > 0 && (m->parents[j] < 0 || m->parents[j] >= j)) return fail(c, MVFIT_E_ARG, "parents must be topologically ordered");
             depth[j] = j == 0 ? 0 : depth[m->parents[j]] + 1;
         }
         int maxd = 0;
         for (int j = 0; j < NJ; ++j) maxd = std::max(maxd, depth[j]);
-        M.nlevels = maxd + 1;
+        G.nlevels = maxd + 1;
         int pos = 0;
         for (int lv = 0; lv <= maxd; ++lv) {
-            M.level_start[lv] = pos;
-            for (int j = 0; j < NJ; ++j) if (depth[j] == lv) M.level_joints[pos++] = j;
+            G.level_start[lv] = pos;
+            for (int j = 0; j < NJ; ++j) if (depth[j] == lv) G.level_joints[pos++] = j;
         }
-        M.level_start[maxd + 1] = pos;
+        for (int lv = maxd + 1; lv <= NJ; ++lv) G.level_start[lv] = pos;
         pos = 0;
         for (int p = 0; p < NJ; ++p) {
-            M.child_start[p] = pos;
-            for (int j = 1; j < NJ; ++j) if (m->parents[j] == p) M.child_list[pos++] = j;
+            G.child_start[p] = pos;
+            for (int j = 1; j < NJ; ++j) if (m->parents[j] == p) G.child_list[pos++] = j;
         }
-        M.child_start[NJ] = pos;
+        G.child_start[NJ] = pos;
     }
+    M.mlds = dev_upload(c, imgv);
     // ---- VPoser decoder ----
     if (m->vp_fc1_w) {
         if (!m->vp_fc1_b || !m->vp_fc2_w || !m->vp_fc2_b || !m->vp_out_w || !m->vp_out_b) return fail(c, MVFIT_E_ARG, "incomplete vposer weights");
@@ -539,10 +651,18 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     if (m->gmm_M > 0) {
         if (m->gmm_M > 8 || !m->gmm_means || !m->gmm_precisions || !m->gmm_nll_weights) return fail(c, MVFIT_E_ARG, "gmm: M <= 8 and all arrays required");
         M.gmm_M = m->gmm_M;
-        std::vector<float> mu(m->gmm_means, m->gmm_means + m->gmm_M * 69),
-            pr(m->gmm_precisions, m->gmm_precisions + (size_t)m->gmm_M * 69 * 69), lw(m->gmm_M);
+        std::vector<float> mu(m->gmm_means, m->gmm_means + m->gmm_M * 69), lw(m->gmm_M),
+            pr((size_t)m->gmm_M * 69 * 72, 0.f), prT((size_t)m->gmm_M * 69 * 72, 0.f);
+        for (int g = 0; g < m->gmm_M; ++g)
+            for (int r = 0; r < 69; ++r)
+                for (int q = 0; q < 69; ++q) {
+                    const float v = m->gmm_precisions[((size_t)g * 69 + r) * 69 + q];
+                    pr[((size_t)g * 69 + r) * 72 + q] = v;
+                    prT[((size_t)g * 69 + q) * 72 + r] = v;
+                }
         for (int i = 0; i < m->gmm_M; ++i) lw[i] = logf(m->gmm_nll_weights[i]);
-        M.gmm_means = dev_upload(c, mu); M.gmm_prec = dev_upload(c, pr); M.gmm_lognw = dev_upload(c, lw);
+        M.gmm_means = dev_upload(c, mu); M.gmm_prec = dev_upload(c, pr); M.gmm_precT = dev_upload(c, prT);
+        M.gmm_lognw = dev_upload(c, lw);
         c->gmm_M = m->gmm_M;
     }
     for (void* p : c->allocs) if (!p) return fail(c, MVFIT_E_HIP, "device allocation failed");
@@ -551,14 +671,17 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_sparse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+    HIP_OK(c, hipHostMalloc(&c->h_done, 4));
     HIP_OK(c, hipDeviceSynchronize());
     return MVFIT_OK;
 }
 
 static void free_problem_buffers(mvfit_ctx* c) {
+    drop_graph(c);
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
-                  c->d_verts, c->F.S, c->F.vecs, c->F.dirs, c->F.stps, c->F.ro, c->F.n_done};
+                  c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->F.S, c->F.vecs, c->F.xt, c->F.dirs, c->F.stps, c->F.ro,
+                  c->F.stage_final, c->F.n_done};
     for (void* p : ps) if (p) hipFree(p);
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
     c->P = DevPose{};
@@ -572,6 +695,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
     for (void* p : c->allocs) if (p) hipFree(p);
+    if (c->h_done) hipHostFree(c->h_done);
     for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_step) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -599,13 +723,18 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->d_gt, (size_t)B * V * NKP * 2 * 4)); HIP_OK(c, hipMalloc(&c->d_wc, (size_t)B * V * NKP * 4));
         HIP_OK(c, hipMalloc(&c->P.coefT, (size_t)Bpad * KROWS * 4)); HIP_OK(c, hipMalloc(&c->P.Amat, (size_t)Bpad * 288 * 4));
         HIP_OK(c, hipMalloc(&c->P.tau, (size_t)Bpad * 4 * 4));
+        HIP_OK(c, hipMalloc(&c->P.vposed_sel, (size_t)Bpad * NC_MAX * 4));
+        HIP_OK(c, hipMalloc(&c->P.xs_sel, (size_t)Bpad * NC_MAX * 4));
         HIP_OK(c, hipMemset(c->P.coefT, 0, (size_t)Bpad * KROWS * 4));
         HIP_OK(c, hipMalloc(&c->d_verts, (size_t)B * c->nv * 3 * 4));
         HIP_OK(c, hipMalloc(&c->F.S, (size_t)B * sizeof(LbState)));
-        HIP_OK(c, hipMalloc(&c->F.vecs, (size_t)B * 8 * 128 * 4));
-        HIP_OK(c, hipMalloc(&c->F.dirs, (size_t)B * LB_HIST * 128 * 4));
-        HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * 128 * 4));
-        HIP_OK(c, hipMalloc(&c->F.ro, (size_t)B * LB_HIST * 8));
+        HIP_OK(c, hipMalloc(&c->F.vecs, (size_t)B * LB_NVEC * LB_D * 4));
+        HIP_OK(c, hipMalloc(&c->F.xt, (size_t)B * DPAD * 4));
+        HIP_OK(c, hipMalloc(&c->F.dirs, (size_t)B * LB_HIST * LB_D * 4));
+        HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * LB_D * 4));
+        HIP_OK(c, hipMalloc(&c->F.ro, (size_t)B * LB_HIST * 4));
+        HIP_OK(c, hipMemset(c->F.ro, 0, (size_t)B * LB_HIST * 4));
+        HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
         HIP_OK(c, hipMalloc(&c->F.n_done, 4));
         c->B = B; c->V = V; c->Bpad = Bpad;
     }
@@ -661,12 +790,12 @@ extern "C" int mvfit_vertices(mvfit_ctx* c, const float* params, uint32_t flags,
     int rc = check_flags(c, flags);
     if (rc) return rc;
     HIP_OK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, params, DV, flags);
+    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, params, flags);
     HIP_OK(c, hipGetLastError());
     rc = run_vertex_pass(c, verts);
     if (rc) return rc;
     if (joints) {
-        hipLaunchKernelGGL(joints_kernel, dim3(c->B), dim3(STEP_NT), 0, c->stream, c->M, verts, joints);
+        hipLaunchKernelGGL(joints_kernel, dim3(c->B), dim3(64), 0, c->stream, c->M, (const float*)verts, joints);
         HIP_OK(c, hipGetLastError());
     }
     return MVFIT_OK;
@@ -683,14 +812,14 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     float* vbuf = verts ? verts : c->d_verts;
     const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0;
     if (!sparse || verts) {
-        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, params, DV, w->flags);
+        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, params, w->flags);
         HIP_OK(c, hipGetLastError());
         rc = run_vertex_pass(c, vbuf);
         if (rc) return rc;
     }
     prof_begin(c, c->ev_step);
-    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, to_dev(*w), params,
-                       sparse ? (const float*)nullptr : (const float*)vbuf, loss, grad, joints);
+    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, to_dev(*w), c->P, params,
+                       sparse ? 0 : 1, loss, grad, joints);
     prof_end(c, c->ev_step);
     HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
@@ -700,19 +829,60 @@ static int make_opts(mvfit_ctx* c, const mvfit_lbfgs_opts* o, uint32_t flags, Lb
     if (o->max_iter <= 0 || o->history <= 0 || o->history > MVFIT_HISTORY || o->maxiters <= 0 || o->num_stages <= 0 ||
         o->num_stages > MVFIT_MAX_STAGES)
         return fail(c, MVFIT_E_ARG, "bad lbfgs options");
+    memset(&O, 0, sizeof(O));
     O.lr = o->lr; O.tol_grad = o->tolerance_grad; O.tol_change = o->tolerance_change; O.ftol = o->ftol; O.gtol = o->gtol;
     O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
     O.num_stages = o->num_stages;
-    // parameter tensors that take part in the gtol test (fitting.py:115-116): requires_grad ones
+    // parameter tensors that take part in the gtol test (fitting.py:115-116): requires_grad ones,
+    // as index ranges of the compact optimiser vector (reference final_params order)
     int n = 0;
     auto add = [&](int lo, int hi) { O.seg_lo[n] = lo; O.seg_hi[n] = hi; ++n; };
-    if (!(flags & MVFIT_F_FIX_SHAPE)) add(X_BETAS, X_GO);
-    add(X_GO, X_BP);
-    if (!(flags & MVFIT_F_VPOSER)) add(X_BP, X_TR);
-    add(X_TR, X_SC);
-    if (!(flags & MVFIT_F_FIX_SCALE)) add(X_SC, X_EMB);
-    if (flags & MVFIT_F_VPOSER) add(X_EMB, DV);
+    if (flags & MVFIT_F_VPOSER) {
+        if (!(flags & MVFIT_F_FIX_SHAPE)) add(0, 10);
+        add(10, 13); add(13, 16);
+        if (!(flags & MVFIT_F_FIX_SCALE)) add(16, 17);
+        add(17, 49);
+    } else {
+        if (!(flags & MVFIT_F_FIX_SHAPE)) add(0, 10);
+        add(10, 13); add(13, 82); add(82, 85);
+        if (!(flags & MVFIT_F_FIX_SCALE)) add(85, 86);
+    }
     O.nseg = n;
+    return MVFIT_OK;
+}
+
+// rounds of (vertex pass, step kernel) between two looks at the done counter, replayed as one graph
+static const int kGraphRounds = 24;
+
+static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O) {
+    std::vector<unsigned char> key(sizeof(SW) + sizeof(O) + sizeof(DevPose) + sizeof(FitBuffers) + sizeof(DevProblems) + sizeof(int));
+    unsigned char* k = key.data();
+    memcpy(k, &SW, sizeof(SW)); k += sizeof(SW);
+    memcpy(k, &O, sizeof(O)); k += sizeof(O);
+    memcpy(k, &c->P, sizeof(DevPose)); k += sizeof(DevPose);
+    memcpy(k, &c->F, sizeof(FitBuffers)); k += sizeof(FitBuffers);
+    memcpy(k, &c->Q, sizeof(DevProblems)); k += sizeof(DevProblems);
+    memcpy(k, &c->ksplit, sizeof(int));
+    if (c->round_graph && key == c->graph_key) return MVFIT_OK;
+    drop_graph(c);
+    hipStream_t cs;
+    HIP_OK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        for (int r = 0; r < kGraphRounds && e == hipSuccess; ++r) {
+            e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, cs);
+            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), cs, c->M, c->Q, SW, O, c->P, c->F);
+        }
+        hipError_t e2 = hipStreamEndCapture(cs, &g);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&c->round_graph, g, nullptr, nullptr, 0);
+    if (g) hipGraphDestroy(g);
+    hipStreamDestroy(cs);
+    if (e != hipSuccess) { c->round_graph = nullptr; return fail(c, MVFIT_E_HIP, "round graph: %s", hipGetErrorString(e)); }
+    c->graph_key = key;
+    c->graph_rounds = kGraphRounds;
     return MVFIT_OK;
 }
 
@@ -737,43 +907,52 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0;
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
-    hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->P, c->F, params, sw[0].flags);
+    hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, c->F, (const float*)params,
+                       sw[0].flags, sparse ? 0 : 1);
     HIP_OK(c, hipGetLastError());
-    int* h_done = nullptr;
-    HIP_OK(c, hipHostMalloc(&h_done, 4));
+    int* h_done = c->h_done;
     *h_done = 0;
     int rounds = 0;
     const int cap = o->max_rounds > 0 ? o->max_rounds : (o->num_stages * o->maxiters * (O.max_eval + 30) + 8);
     if (sparse) {
         while (rounds < cap) {
-            const int chunk = 4096;
-            hipLaunchKernelGGL(fit_sparse_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F, chunk);
+            const int chunk = std::min(cap - rounds, 1 << 20);
+            hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M, c->Q, SW, O, c->P,
+                               c->F, chunk);
             HIP_OK(c, hipGetLastError());
             rounds += chunk;
             HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_OK(c, hipStreamSynchronize(c->stream));
             if (*h_done >= B) break;
         }
-    } else {
-        const int batch = 32;      // rounds enqueued between two looks at the done counter
+    } else if (c->profile) {
+        // eager launches bracketed by events (bench.py's per-launch timing of the vertex pass)
         while (rounds < cap) {
-            for (int r = 0; r < batch; ++r) {
+            for (int r = 0; r < kGraphRounds; ++r) {
                 rc = run_vertex_pass(c, c->d_verts);
-                if (rc) { hipHostFree(h_done); return rc; }
+                if (rc) return rc;
                 prof_begin(c, c->ev_step);
-                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F,
-                                   (const float*)c->d_verts);
+                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F);
                 prof_end(c, c->ev_step);
             }
             HIP_OK(c, hipGetLastError());
-            rounds += batch;
+            rounds += kGraphRounds;
+            HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(c, hipStreamSynchronize(c->stream));
+            if (*h_done >= B) break;
+        }
+    } else {
+        rc = ensure_round_graph(c, SW, O);
+        if (rc) return rc;
+        while (rounds < cap) {
+            HIP_OK(c, hipGraphLaunch(c->round_graph, c->stream));
+            rounds += c->graph_rounds;
             HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_OK(c, hipStreamSynchronize(c->stream));
             if (*h_done >= B) break;
         }
     }
     const bool finished = *h_done >= B;
-    hipHostFree(h_done);
     hipLaunchKernelGGL(fit_finish_kernel, dim3(B), dim3(128), 0, c->stream, c->F, params, final_loss, n_closure, n_iter, B,
                        o->num_stages);
     HIP_OK(c, hipGetLastError());
@@ -823,9 +1002,10 @@ extern "C" int mvfit_profile_read(mvfit_ctx* c, double* vp_ms, int* launches, do
 
 extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs, int nseg, const mvfit_lbfgs_opts* o,
                                double* x_inout, double* trace, int max_trace, int* n_closure, double* final_loss) {
-    if (!o || !x_inout || D <= 1 || D > 128 || nseg < 1 || nseg > 8 || !segs) return MVFIT_E_ARG;
+    if (!o || !x_inout || D <= 1 || D > LB_D || nseg < 1 || nseg > 8 || !segs) return MVFIT_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return MVFIT_E_HIP;
     LbOpts O;
+    memset(&O, 0, sizeof(O));
     O.lr = o->lr; O.tol_grad = o->tolerance_grad; O.tol_change = o->tolerance_change; O.ftol = o->ftol; O.gtol = o->gtol;
     O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
     O.num_stages = 1; O.nseg = nseg;
@@ -833,11 +1013,13 @@ extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs,
     double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro;
     int* dn;
     const size_t tb = (size_t)std::max(max_trace, 1) * (D + 1) * 8;
-    if (hipMalloc(&dx, 128 * 8) || hipMalloc(&dtrace, tb) || hipMalloc(&dfl, 8) || hipMalloc(&dn, 4) ||
-        hipMalloc(&ddirs, LB_HIST * 128 * 8) || hipMalloc(&dstps, LB_HIST * 128 * 8) || hipMalloc(&dro, LB_HIST * 8))
+    if (hipMalloc(&dx, LB_D * 8) || hipMalloc(&dtrace, tb) || hipMalloc(&dfl, 8) || hipMalloc(&dn, 4) ||
+        hipMalloc(&ddirs, LB_HIST * LB_D * 8) || hipMalloc(&dstps, LB_HIST * LB_D * 8) || hipMalloc(&dro, LB_HIST * 8))
         return MVFIT_E_HIP;
     hipMemcpy(dx, x_inout, D * 8, hipMemcpyHostToDevice);
     hipMemset(dtrace, 0, tb);
+    hipMemset(ddirs, 0, LB_HIST * LB_D * 8);
+    hipMemset(dstps, 0, LB_HIST * LB_D * 8);
     hipLaunchKernelGGL(lbfgs_kat_kernel, dim3(1), dim3(64), 0, 0, kind, D, O, dx, dtrace, max_trace, dn, dfl, ddirs, dstps, dro);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(x_inout, dx, D * 8, hipMemcpyDeviceToHost);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mvfit.h"
+#include "wave_ops.h"
 #include "lbfgs_device.h"
 
 namespace mvfit {
@@ -14,35 +15,56 @@ constexpr int KGROUPS = 28;       // groups of 4 MFMA k-steps (8 rows) each
 constexpr int TILE_V = 32;        // vertices per MFMA tile
 constexpr int DV = MVFIT_D;       // 118
 constexpr int DPAD = 128;
-constexpr int NS_MAX = 128;       // selected (objective-relevant) vertices
+constexpr int NS_MAX = 96;        // selected (objective-relevant) vertices
+constexpr int NS_STRIDE = 112;    // row stride of the transposed skinning weights (== 16 mod 32: the four
+                                  // 16-lane rows of a wave hit disjoint LDS banks)
 constexpr int NC_MAX = NS_MAX * 3;
-constexpr int A_STRIDE = 292;     // per-problem stride of the 24x12 skinning transforms in LDS
+constexpr int KNNZ_MAX = 160;     // non-zeros of the 17 x ns keypoint selection
+constexpr int A_STRIDE = 292;     // per-problem stride of the 24x12 skinning transforms in LDS (vertex pass)
+constexpr int STEP_NT = 512;      // threads of the per-problem kernels (8 waves)
+constexpr int STEP_NW = STEP_NT / 64;
 
 // flat parameter layout (include/mvfit.h)
 constexpr int X_BETAS = 0, X_GO = 10, X_BP = 13, X_TR = 82, X_SC = 85, X_EMB = 86;
 
-struct DevModel {
-    int nv, nv_pad, ntiles;
-    const float* bs4;        // [ntiles][3][KGROUPS][64][4]   MFMA-B-operand order (see vertex pass)
-    const float* vt_planes;  // [3][nv_pad]
-    const float* wt_tiles;   // [ntiles][24][32]
-    const float* J_t;        // [24][3]
-    const float* J_S;        // [24][3][10]
-    // objective-relevant vertex subset
-    int ns, nc, nc_pad;      // nc = 3*ns, nc_pad multiple of 4
-    const int* sel_v;        // [ns]
-    const float* vt_sub;     // [nc_pad]
-    const float* pd_sub;     // [KROWS][nc_pad]
-    const float* pd_subT;    // [nc_pad][KROWS]
-    const float* w_sub;      // [ns][24]
-    const float* ksel_sub;   // [17][NS_MAX]
-    // kinematic tree
+// Model constants every per-problem workgroup keeps in LDS (bulk-copied once per launch).
+struct ModelLds {
+    float wT[NJ][NS_STRIDE];          // lbs_weights of the selected vertices, transposed: wT[j][s]
+    float J_t[NJ * 3];                // J_regressor . v_template
+    float J_S[NJ * 3][11];            // J_regressor . shapedirs  (row padded to 11: conflict-free by lane)
+    float vt_sub[NC_MAX];             // v_template of the selected vertices, c = 3 s + a
+    int sel_v[NS_MAX];                // vertex id of selected vertex s
+    int kp_start[NKP + 1];            // keypoint k = sum_t kp_w[t] * xs[kp_s[t]]  (ascending s)
+    int kp_s[KNNZ_MAX];
+    float kp_w[KNNZ_MAX];
+    int vs_start[NS_MAX + 1];         // transpose: selected vertex s feeds keypoints vs_k[t] (ascending k)
+    int vs_k[KNNZ_MAX];
+    float vs_w[KNNZ_MAX];
     int parents[NJ];
     int nlevels;
     int level_start[NJ + 1];
     int level_joints[NJ];
     int child_start[NJ + 1];
     int child_list[NJ];
+    int ns, nc, nc_pad, pad0, pad1, pad2;
+};
+static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds is bulk-copied as 16-byte words");
+
+struct DevModel {
+    int nv, nv_pad, ntiles;
+    const float* bs4;        // [ntiles][3][KGROUPS][64][4]   MFMA-B-operand order (see vertex pass)
+    const float* vt_planes;  // [3][nv_pad]
+    const float* wt_tiles;   // [ntiles][24][32]
+    // objective-relevant vertex subset
+    int ns, nc, nc_pad;      // nc = 3*ns, nc_pad multiple of 4
+    const ModelLds* mlds;    // LDS image (global copy)
+    const int* sel_v;        // [ns]
+    const float* pd_sub;     // [KROWS][nc_pad]
+    const float* pd_subT;    // [nc_pad][KROWS]
+    // vertex-pass side outputs for the selected vertices: per tile, which local vertices are selected
+    const int* tile_sel_start;   // [ntiles + 1]
+    const int* tile_sel_local;   // [ns] local vertex index inside its tile
+    const int* tile_sel_slot;    // [ns] selected-vertex slot s
     // VPoser decoder (null if absent)
     const float* vp_w1; const float* vp_b1;     // [512][32]
     const float* vp_w2; const float* vp_b2;     // [512][512]
@@ -53,7 +75,8 @@ struct DevModel {
     // GMM
     int gmm_M;
     const float* gmm_means;      // [M][69]
-    const float* gmm_prec;       // [M][69][69]
+    const float* gmm_prec;       // [M][69][72]   rows padded to 72 floats (16-byte aligned)
+    const float* gmm_precT;      // [M][69][72]   transposed precisions
     const float* gmm_lognw;      // [M]  log(nll_weights)
 };
 
@@ -82,10 +105,15 @@ struct DevWeights {          // one stage
 //   coefT [B/32][KROWS][32]   (pose_feature | betas | 0), transposed per 32-problem chunk
 //   Amat  [B][24][12]
 //   tau   [B][4]
+// and back (vertex pass -> step kernel), for the selected vertices only:
+//   vposed_sel [B][NC_MAX]   blendshaped rest positions  (lbs.py:203), c = 3 s + a
+//   xs_sel     [B][NC_MAX]   skinned positions before "+ transl"
 struct DevPose {
     float* coefT;
     float* Amat;
     float* tau;
+    float* vposed_sel;
+    float* xs_sel;
 };
 
 }  // namespace mvfit

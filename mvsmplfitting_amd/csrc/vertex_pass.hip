@@ -136,22 +136,21 @@ __global__ __launch_bounds__(192 * KSPLIT) void lbs_vertex_pass_kernel(DevModel 
                 tr[i][3] = fmaf(wv[i], a.w, tr[i][3]);
             }
         }
-        const float tk = tau_l[b * 4 + k];
         float xo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 vp = *reinterpret_cast<const float4*>(vp_l + (b * 32 + 4 * vg + i) * 4);
-            float x = fmaf(tr[i][0], vp.x, fmaf(tr[i][1], vp.y, fmaf(tr[i][2], vp.z, tr[i][3])));
-            xo[i] = x + tk;
+            xo[i] = fmaf(tr[i][0], vp.x, fmaf(tr[i][1], vp.y, fmaf(tr[i][2], vp.z, tr[i][3])));
         }
         // out_l aliases the (now dead) partial slabs only after every thread passed the combine
-        // barrier above; the slabs are not read again in this loop.
+        // barrier above; the slabs are not read again in this loop.  It holds the skinned position
+        // BEFORE "+ transl" (the step kernel wants that value; the store below adds transl).
 #pragma unroll
         for (int i = 0; i < 4; ++i) out_l[b * 96 + (4 * vg + i) * 3 + k] = xo[i];
     }
     __syncthreads();
 
-    // ---- coalesced store: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
+    // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
     {
         const int vbase = tile * TILE_V;
         const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
@@ -159,11 +158,26 @@ __global__ __launch_bounds__(192 * KSPLIT) void lbs_vertex_pass_kernel(DevModel 
             const int b = i / 48, q = i - b * 48;
             if (b0 + b >= B) continue;
             float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
+            const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
+            float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+            o.x += tau_l[b * 4 + k0];
+            o.y += tau_l[b * 4 + k1];
             if (2 * q + 1 < nvalid) {
-                *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+                *reinterpret_cast<float2*>(dst) = o;
             } else if (2 * q < nvalid) {
-                dst[0] = out_l[b * 96 + 2 * q];
+                dst[0] = o.x;
             }
+        }
+    }
+    // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
+    {
+        const int s0 = M.tile_sel_start[tile], nsel = M.tile_sel_start[tile + 1] - s0;
+        for (int i = tid; i < nsel * 96; i += NT) {
+            const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
+            if (b0 + b >= B) continue;
+            const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
+            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vp_l[(b * 32 + lv) * 4 + k];
+            P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
         }
     }
 }
