@@ -94,6 +94,7 @@ struct ClosureLds {
     DevWeights sw[MVFIT_MAX_STAGES];          // per-stage weights and optimiser options: read from LDS inside the
     __attribute__((aligned(16))) LbOpts opts; // round loop so that they do not pin ~100 SGPRs across it
     __attribute__((aligned(16))) LbState lbS;
+    __attribute__((aligned(16))) LbWork<float> lbW;
     __attribute__((aligned(16))) float lbV[LB_NVEC][LB_D];
 };
 
@@ -490,6 +491,7 @@ __device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* vp
     float vp_in = 0.f, xs_in = 0.f;
     if (vposed_pass != nullptr && tid < nc) { vp_in = vposed_pass[tid]; xs_in = xs_pass[tid]; }
     __syncthreads();
+    PH_T(1);
     // thread per coordinate c = 3 s + a: T row a of vertex s, v_posed[c], xs[c]
     if (tid < nc) {
         const int c = tid, s = c / 3, a = c - 3 * s;
@@ -768,6 +770,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         L.gvp[tid] = v;
     }
     __syncthreads();
+    PH_T(4);
     // ---- E6: g_A = sum_s W[s][j] [g_x v_posed^T | g_x]: 16-lane row per joint, lanes stride s ----
     if (tid < NJ * 16) {
         const int j = tid >> 4, g = tid & 15;
@@ -799,11 +802,13 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         }
     }
     __syncthreads();
+    PH_T(5);
     // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
     if (tid < 64) chain_backward_wave(L, tid);
     else contraction_backward(M, L, tid - 64, STEP_NT - 64);
     const int ncs = bwd_slices(STEP_NT - 64);
     __syncthreads();
+    PH_T(6);
     // ---- E8: g_R, g_scale, g_J -> g_beta ----
     if (tid < NJ * 9) {
         const int j = tid / 9, e = tid - 9 * j;
@@ -852,6 +857,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         }
     }
     __syncthreads();
+    PH_T(7);
     // ---- E9: Rodrigues adjoint per joint + priors on the pose ----
     const float wp2 = W.pose_w * W.pose_w;
     if (tid < NJ) {

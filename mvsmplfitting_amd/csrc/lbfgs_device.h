@@ -14,12 +14,22 @@
 // Lane layout: the flat parameter vector (reference order of final_params, D <= 96) is spread
 // over the wave, LB_EPL = 2 consecutive elements per lane (lanes 48.. hold zeros); every dot
 // product is a 6-step butterfly (4 DPP + v_permlane16/32_swap, wave_ops.h) whose result is
-// bit-identical in all 64 lanes, so all scalar logic is wave-uniform: no LDS, no barrier, no
-// ds_bpermute in here.  VT = vector storage type, AT = accumulation type of the
-// dot products (float/float in production - the reference's vectors and torch.dot are float32 -
-// double/double in the known-answer test); line-search scalars are always double (Python floats
-// in the reference).  The (s, y) history rows are streamed with a 4-deep register prefetch ring,
-// from LDS (single-launch fit) or HBM/L2 (one launch per closure round).
+// bit-identical in all 64 lanes, so all scalar logic is wave-uniform.  T = storage and
+// accumulation type (float in production - the reference's vectors and torch.dot are float32 -
+// double in the known-answer test); line-search scalars are always double (Python floats in the
+// reference).
+//
+// The two-loop recursion (lbfgs_ls.py:336-358) is the one part that is NOT wave-local.  Written
+// literally it is 2 m dependent (dot -> axpy) steps and every dot is a ~110-cycle cross-lane
+// reduction (measured, tests/microbench/lat.hip).  It is evaluated here in Gram form - same
+// products, the sums regrouped - with G[a][b] = s_a . y_b kept per problem:
+//     first loop   al_i = ro_i (s_i.q_i),  q_i = -g - sum_{j>i} al_j y_j
+//              =>  al_i = ro_i (b_i - sum_{j>i} al_j G[i][j]),  b_i = s_i.(-g)
+//     second loop  be_i = ro_i (y_i.r_i),  r_i = H q_0 + sum_{j<i} (al_j - be_j) s_j
+//              =>  be_i = ro_i (e_i + sum_{j<i} c_j G[j][i]),  e_i = y_i.(H q_0),  c_j = al_j - be_j
+// The m dots b_i / e_i and the two mat-vecs (q_0, d) are independent and run on all waves of the
+// workgroup; the two triangular recurrences run column-oriented on wave 0 (lane k owns the
+// running value of index k; per step one v_readlane + one FMA, G rows prefetched 8 deep).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,9 +40,13 @@ namespace mvfit {
 constexpr int LB_EPL = 2;          // elements per lane
 constexpr int LB_D = 96;           // row stride of every optimiser vector (>= D); lanes >= LB_D / LB_EPL idle
 constexpr int LB_HIST = 100;
-constexpr int LB_PD = 4;           // history prefetch depth (rows in flight)
+constexpr int LB_PD = 8;           // Gram rows in flight in the recurrences
+constexpr int LB_GS = 104;         // row stride of the Gram matrices (columns indexed by history slot)
+constexpr int LB_GPAD = 2 * LB_PD;                  // pad rows on both sides (prefetch runs up to 2 LB_PD - 1 rows past the end)
+constexpr int LB_GROWS = 2 * LB_HIST + 2 * LB_GPAD; // rows: pad | slots 0..99 | slots 0..99 again | pad
+constexpr int LB_GSIZE = LB_GROWS * LB_GS;          // elements of one Gram matrix
 
-enum LbPhase : int { PH_STEP_START = 0, PH_LS_FIRST = 1, PH_LS_BRACKET = 2, PH_LS_ZOOM = 3 };
+enum LbPhase : int { PH_STEP_START = 0, PH_LS_FIRST = 1, PH_LS_BRACKET = 2, PH_LS_ZOOM = 3, PH_DIRECTION = 4 };
 
 struct LbOpts {
     double lr, tol_grad, tol_change, ftol, gtol;
@@ -49,7 +63,7 @@ struct LbState {
     int ls_it, ls_evals, ls_done, low, high, insuf, nbr;
     int has_outer_prev;
     int n_closure, n_lbfgs;
-    int pad0;
+    int ins_slot;        // history slot written by the current iteration (-1: pair rejected)
     double loss, prev_loss, orig_loss, outer_prev;
     double t, H, gtd, f0, d_norm;
     double t_prev, f_prev, gtd_prev;
@@ -65,19 +79,41 @@ struct LbVecs {            // lane-distributed working vectors
 };
 constexpr int LB_NVEC = 7;
 
-// History ring: y = dirs, s = stps, row stride LB_D; ro = 1/(y.s).  Generic pointers (LDS or global).
-template <typename VT, typename AT>
+// History ring: y = dirs, s = stps, row stride LB_D; ro = 1/(y.s).  dirs/stps/ro may be LDS or
+// global (generic pointers).  Gram matrices (global), rows and columns indexed by history slot,
+// pre-scaled and exactly zero outside their triangle so that a recurrence step is one FMA:
+//     gcol[i][k] = ro_k (s_k . y_i)  for k older than i, else 0      (first loop, row = newer pair)
+//     grow[i][k] = ro_k (s_i . y_k)  for k newer than i, else 0      (second loop, row = older pair)
+// Every row is stored twice (slot and slot + 100) so that "age order" is a linear walk without a
+// ring wrap; LB_PD pad rows on both sides keep the prefetch in bounds.
+template <typename T>
 struct LbHist {
-    VT* dirs;      // [LB_HIST][LB_D]
-    VT* stps;      // [LB_HIST][LB_D]
-    AT* ro;        // [LB_HIST]
+    T* dirs;       // [LB_HIST][LB_D]
+    T* stps;       // [LB_HIST][LB_D]
+    T* ro;         // [LB_HIST]
+    T* grow;       // [LB_GROWS][LB_GS]
+    T* gcol;       // [LB_GROWS][LB_GS]
 };
 
-template <typename VT, typename AT>
-__device__ __forceinline__ AT vdot(const VT* a, const VT* b) {
-    AT s = (AT)0;
+// LDS scratch of the block-wide direction computation
+template <typename T>
+struct LbWork {
+    T qv[LB_D];            // -g, then r_0 = H q_0
+    T dv[LB_D];            // direction
+    T bvec[128];           // b_i, then e_i (by age index: 0 = oldest)
+    T alpha[128];
+    T cvec[128];
+    T part[8][LB_D];
+    T gnew[LB_HIST + 4];   // s_a . y_new by slot (insert pass)
+    int n, head, ins_slot, need_dir;
+    T Hdiag;
+};
+
+template <typename T>
+__device__ __forceinline__ T vdot(const T* a, const T* b) {
+    T s = (T)0;
 #pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) s = fma((AT)a[e], (AT)b[e], s);
+    for (int e = 0; e < LB_EPL; ++e) s = fma(a[e], b[e], s);
     return wave64_sum(s);
 }
 template <typename VT>
@@ -106,86 +142,179 @@ __device__ __forceinline__ double lb_cubic(double x1, double f1, double g1, doub
     return (lo + hi) / 2.0;
 }
 
-template <typename VT, typename AT>
-struct LbRow { VT s[LB_EPL], y[LB_EPL]; AT ro; };
-
-template <typename VT, typename AT>
-__device__ __forceinline__ void lb_load_row(LbRow<VT, AT>& R, const LbHist<VT, AT>& Hh, int slot, int lane) {
-    if (LB_EPL * lane < LB_D) {
-        const VT* ps = Hh.stps + slot * LB_D + LB_EPL * lane;
-        const VT* py = Hh.dirs + slot * LB_D + LB_EPL * lane;
+// dots of history rows against LDS vectors: 16 lanes per row (6 elements each), NT/16 rows per pass.
+//   which = 0: b_a = s_a . qv  and, if a pair was inserted, W.gnew[slot_a] = s_a . y_new
+//   which = 1: e_a = y_a . qv
+template <typename T, int NT>
+__device__ void lb_row_dots(const LbHist<T>& Hh, LbWork<T>& W, int which, int tid) {
+    const int n = W.n, head = W.head, ins = W.ins_slot;
+    const int l16 = tid & 15;
+    const bool two = which == 0 && ins >= 0;
+    T qv[6], yn[6];
 #pragma unroll
-        for (int e = 0; e < LB_EPL; ++e) { R.s[e] = ps[e]; R.y[e] = py[e]; }
-    } else {
+    for (int e = 0; e < 6; ++e) { qv[e] = W.qv[6 * l16 + e]; yn[e] = (T)0; }
+    if (two) {
 #pragma unroll
-        for (int e = 0; e < LB_EPL; ++e) { R.s[e] = (VT)0; R.y[e] = (VT)0; }
+        for (int e = 0; e < 6; ++e) yn[e] = Hh.dirs[ins * LB_D + 6 * l16 + e];
     }
-    R.ro = Hh.ro[slot];
+    for (int a = tid >> 4; a < n; a += NT / 16) {
+        int slot = head + a;
+        slot = slot >= LB_HIST ? slot - LB_HIST : slot;
+        const T* row = (which == 0 ? Hh.stps : Hh.dirs) + slot * LB_D + 6 * l16;
+        T d0 = (T)0, d1 = (T)0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { const T v = row[e]; d0 = fma(v, qv[e], d0); d1 = fma(v, yn[e], d1); }
+        d0 = row16_sum(d0);
+        if (two) d1 = row16_sum(d1);
+        if (l16 == 0) { W.bvec[a] = d0; if (two) W.gnew[slot] = d1; }
+    }
 }
 
-// direction d = -H g by the two-loop recursion (lbfgs_ls.py:336-358), same operation order as the
-// reference: al_i = (s_i . q) ro_i ; q -= al_i y_i ; r = q H ; be_i = (y_i . r) ro_i ; r += (al_i - be_i) s_i
-template <typename VT, typename AT>
-__device__ void lb_two_loop(const LbState& S, const LbVecs<VT>& V, const LbHist<VT, AT>& Hh, VT* dout, int lane) {
-    const int n = __builtin_amdgcn_readfirstlane(S.hist_len), head = __builtin_amdgcn_readfirstlane(S.hist_head);
-    VT q[LB_EPL];
-#pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) q[e] = -V.g[e];
-    AT al0 = (AT)0, al1 = (AT)0;                 // al[i] lives in lane i & 63, register i >> 6
-    LbRow<VT, AT> ring[LB_PD];
-#pragma unroll
-    for (int u = 0; u < LB_PD; ++u) {
-        const int i = n - 1 - u;
-        if (i >= 0) lb_load_row(ring[u], Hh, (head + i) % LB_HIST, lane);
+// Gram maintenance after the row dots of an inserted pair t: rows t and column t of both matrices
+// (see LbHist).  Thread a < 100 owns history slot a.
+template <typename T, int NT>
+__device__ void lb_gram_insert(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+    const int n = W.n, head = W.head, t = W.ins_slot;
+    for (int a = tid; a < LB_HIST; a += NT) {
+        int age = a - head;
+        age = age < 0 ? age + LB_HIST : age;                     // age of slot a (valid if < n)
+        const bool older = age < n && a != t;                    // live and older than the new pair
+        const T g = older ? W.gnew[a] : (T)0;                    // s_a . y_t
+        const T c = older ? Hh.ro[a] * g : (T)0;                 // gcol[t][a] = ro_a (s_a . y_t)
+        const T r = older ? Hh.ro[t] * g : (T)0;                 // grow[a][t] = ro_t (s_a . y_t)
+        T* gc = Hh.gcol + LB_GPAD * LB_GS;
+        T* gr = Hh.grow + LB_GPAD * LB_GS;
+        gc[t * LB_GS + a] = c;              gc[(t + LB_HIST) * LB_GS + a] = c;
+        gr[t * LB_GS + a] = (T)0;           gr[(t + LB_HIST) * LB_GS + a] = (T)0;
+        gc[a * LB_GS + t] = (T)0;           gc[(a + LB_HIST) * LB_GS + t] = (T)0;
+        gr[a * LB_GS + t] = r;              gr[(a + LB_HIST) * LB_GS + t] = r;
     }
-    for (int base = n - 1; base >= 0; base -= LB_PD) {
-#pragma unroll
-        for (int u = 0; u < LB_PD; ++u) {
-            const int i = base - u;
-            if (i >= 0) {
-                const AT a = vdot<VT, AT>(ring[u].s, q) * ring[u].ro;
-                if (lane == (i & 63)) { if (i < 64) al0 = a; else al1 = a; }
-#pragma unroll
-                for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)fma(-a, (AT)ring[u].y[e], (AT)q[e]);
-                const int nx = i - LB_PD;
-                if (nx >= 0) lb_load_row(ring[u], Hh, (head + nx) % LB_HIST, lane);
-            }
+}
+
+// out[e] = (in[e] + sign * sum_j coef[j] * rows_j[e]) * scale, j split over the waves
+template <typename T, int NT>
+__device__ void lb_matvec(const T* rows, const T* coef, T sign, T scale, const T* in, T* outvec, LbWork<T>& W, int tid) {
+    constexpr int NW = NT / 64;
+    const int n = W.n, head = W.head;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (LB_EPL * lane < LB_D) {
+        T a0 = (T)0, a1 = (T)0;
+        for (int j = wave; j < n; j += NW) {
+            int slot = head + j;
+            slot = slot >= LB_HIST ? slot - LB_HIST : slot;
+            const T c = coef[j];
+            a0 = fma(c, rows[slot * LB_D + 2 * lane], a0);
+            a1 = fma(c, rows[slot * LB_D + 2 * lane + 1], a1);
         }
+        W.part[wave][2 * lane] = a0;
+        W.part[wave][2 * lane + 1] = a1;
     }
+    __syncthreads();
+    for (int e = tid; e < LB_D; e += NT) {
+        T s = (T)0;
 #pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)((AT)q[e] * (AT)S.H);
+        for (int w = 0; w < NW; ++w) s += W.part[w][e];
+        outvec[e] = (in[e] + sign * s) * scale;
+    }
+    __syncthreads();
+}
+
+// One triangular recurrence on wave 0: x_k -= x_i * M[i][k] for i in age order (DESC: newest ->
+// oldest over gcol; else oldest -> newest over grow).  Lane k owns ages k and k + 64; when the
+// loop is done lane k holds the solution component of age k (al_k, resp. c_k = al_k - be_k).
+// Per step: one prefetched row element per owned age, one v_readlane, one FMA.
+template <typename T, bool DESC, bool TWO>
+__device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int lane, T& x0, T& x1) {
+    int s0 = head + lane, s1 = head + lane + 64;
+    s0 = s0 >= LB_HIST ? s0 - LB_HIST : s0;
+    s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
+    s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
+    // row of age i is physical row LB_GPAD + head + i (doubled layout: no wrap for i < 100)
+    const T* p0 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s0;
+    const T* p1 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s1;
+    constexpr int RS = DESC ? -LB_GS : LB_GS;
+    T g0[LB_PD], g1[LB_PD];
 #pragma unroll
-    for (int u = 0; u < LB_PD; ++u)
-        if (u < n) lb_load_row(ring[u], Hh, (head + u) % LB_HIST, lane);
+    for (int u = 0; u < LB_PD; ++u) { g0[u] = p0[u * RS]; g1[u] = TWO ? p1[u * RS] : (T)0; }
     for (int base = 0; base < n; base += LB_PD) {
+        p0 += LB_PD * RS;
+        p1 += LB_PD * RS;
 #pragma unroll
         for (int u = 0; u < LB_PD; ++u) {
-            const int i = base + u;
-            if (i < n) {
-                const AT be = vdot<VT, AT>(ring[u].y, q) * ring[u].ro;
-                const AT a = lane_read((i < 64) ? al0 : al1, i & 63);
-                const AT c = a - be;
-#pragma unroll
-                for (int e = 0; e < LB_EPL; ++e) q[e] = (VT)fma(c, (AT)ring[u].s[e], (AT)q[e]);
-                const int nx = i + LB_PD;
-                if (nx < n) lb_load_row(ring[u], Hh, (head + nx) % LB_HIST, lane);
+            const int st = base + u;
+            if (st < n) {
+                const int i = DESC ? n - 1 - st : st;
+                const T v = TWO ? lane_read(i < 64 ? x0 : x1, i & 63) : lane_read(x0, i);
+                x0 = fma(-v, g0[u], x0);
+                if (TWO) x1 = fma(-v, g1[u], x1);
             }
+            g0[u] = p0[u * RS];                 // row st + LB_PD (pad rows keep this in bounds)
+            if (TWO) g1[u] = p1[u * RS];
         }
     }
-#pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) dout[e] = q[e];
+}
+
+template <typename T, bool FIRST>
+__device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane) {
+    const int n = __builtin_amdgcn_readfirstlane(W.n), head = __builtin_amdgcn_readfirstlane(W.head);
+    const int k0 = lane, k1 = lane + 64;
+    int s0 = head + k0, s1 = head + k1;
+    s0 = s0 >= LB_HIST ? s0 - LB_HIST : s0;
+    s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
+    s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
+    T x0 = (T)0, x1 = (T)0;
+    if (FIRST) {       // r'_k = ro_k b_k
+        if (k0 < n) x0 = Hh.ro[s0] * W.bvec[k0];
+        if (k1 < n) x1 = Hh.ro[s1] * W.bvec[k1];
+    } else {           // w_k = al_k - ro_k e_k
+        if (k0 < n) x0 = W.alpha[k0] - Hh.ro[s0] * W.bvec[k0];
+        if (k1 < n) x1 = W.alpha[k1] - Hh.ro[s1] * W.bvec[k1];
+    }
+    if (n > 64) lb_recur_loop<T, FIRST, true>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
+    else lb_recur_loop<T, FIRST, false>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
+    T* out = FIRST ? W.alpha : W.cvec;
+    if (k0 < n) out[k0] = x0;
+    if (k1 < n) out[k1] = x1;
+}
+
+// d = -H g (lbfgs_ls.py:336-358) by the whole workgroup (NT threads, wave 0 = the optimiser wave).
+// In: W.qv = -g, W.n/head/ins_slot/Hdiag, history rows incl. the freshly inserted pair.  Out: W.dv.
+template <typename T, int NT>
+__device__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+    lb_row_dots<T, NT>(Hh, W, 0, tid);
+    __syncthreads();
+    if (W.ins_slot >= 0) { lb_gram_insert<T, NT>(Hh, W, tid); __syncthreads(); }
+    PH_T(16);
+    if (tid < 64) lb_recurrence<T, true>(Hh, W, tid);
+    __syncthreads();
+    PH_T(17);
+    // r_0 = H (-g - sum_j al_j y_j)
+    lb_matvec<T, NT>(Hh.dirs, W.alpha, (T)-1, W.Hdiag, W.qv, W.qv, W, tid);
+    PH_T(18);
+    lb_row_dots<T, NT>(Hh, W, 1, tid);
+    __syncthreads();
+    PH_T(19);
+    if (tid < 64) lb_recurrence<T, false>(Hh, W, tid);
+    __syncthreads();
+    PH_T(20);
+    // d = r_0 + sum_j c_j s_j
+    lb_matvec<T, NT>(Hh.stps, W.cvec, (T)1, (T)1, W.qv, W.dv, W, tid);
+    PH_T(21);
 }
 
 // Consume (f_new, gnew) of the last closure call, emit the next trial point into xt.
-// Returns with S.status == 1 when all stages are finished (xt = final x).
+// Returns 0 when a trial point was emitted (S.status == 1: all stages finished, xt = final x), or
+// 1 when a new search direction is needed: the caller then runs lb_direction_block() with the whole
+// workgroup and calls again (S.phase == PH_DIRECTION; f_new / gnew are ignored on that call).
 // lane = threadIdx & 63; element e of this lane is flat index LB_EPL * lane + e.
-template <typename VT, typename AT>
-__device__ void lbfgs_advance(LbState& S, LbVecs<VT>& V, const LbHist<VT, AT>& Hh, const LbOpts& O,
-                              double f_new, const VT* gnew, VT* xt, int lane, double* stage_final) {
+template <typename T>
+__device__ int lbfgs_advance(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
+                             double f_new, const T* gnew, T* xt, int lane, double* stage_final) {
     const double c1 = 1e-4, c2 = 0.9;
     const int max_ls = 25;
     double gtd_new = 0.0;
 
+    if (S.phase == PH_DIRECTION) goto L_have_direction;
     S.n_closure += 1;
     switch (S.phase) {
         case PH_LS_FIRST: goto L_ls_first;
@@ -214,14 +343,15 @@ L_iter:
         S.hist_head = 0;
         S.H = 1.0;
     } else {                                                          // :318-358
-        VT y[LB_EPL], s[LB_EPL];
+        T y[LB_EPL], s[LB_EPL];
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) {
             y[e] = V.g[e] - V.pg[e];
-            s[e] = (VT)((AT)V.d[e] * (AT)S.t);
+            s[e] = V.d[e] * (T)S.t;
         }
-        const AT ys = vdot<VT, AT>(y, s);
-        if (ys > (AT)1e-10) {
+        const T ys = vdot<T>(y, s);
+        S.ins_slot = -1;
+        if (ys > (T)1e-10) {
             if (S.hist_len == O.history) S.hist_head = (S.hist_head + 1) % LB_HIST;
             else S.hist_len += 1;
             const int slot = (S.hist_head + S.hist_len - 1) % LB_HIST;
@@ -232,25 +362,41 @@ L_iter:
                     Hh.stps[slot * LB_D + LB_EPL * lane + e] = s[e];
                 }
             }
-            if (lane == 0) Hh.ro[slot] = (AT)1 / ys;
-            S.H = (double)(ys / vdot<VT, AT>(y, y));
-            wave_lds_fence();                         // history is re-read by all lanes of this wave
+            if (lane == 0) Hh.ro[slot] = (T)1 / ys;
+            S.H = (double)(ys / vdot<T>(y, y));
+            S.ins_slot = slot;
         }
-        lb_two_loop<VT, AT>(S, V, Hh, V.d, lane);
+        if (S.hist_len > 0) {
+            // hand the two-loop recursion to the workgroup: W.qv = -g
+            if (LB_EPL * lane < LB_D) {
+#pragma unroll
+                for (int e = 0; e < LB_EPL; ++e) W.qv[LB_EPL * lane + e] = -V.g[e];
+            }
+            if (lane == 0) { W.n = S.hist_len; W.head = S.hist_head; W.ins_slot = S.ins_slot; W.Hdiag = (T)S.H; }
+            S.phase = PH_DIRECTION;
+            return 1;
+        }
+#pragma unroll
+        for (int e = 0; e < LB_EPL; ++e) V.d[e] = (T)S.H * (-V.g[e]);     // empty history: d = -g H
     }
+    goto L_after_direction;
+L_have_direction:
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) V.d[e] = (LB_EPL * lane < LB_D) ? W.dv[LB_EPL * lane + e] : (T)0;
+L_after_direction:
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) V.pg[e] = V.g[e];                // :360-364
     S.prev_loss = S.loss;
     if (S.n_iter == 1) {                                              // :370-373
-        AT asum = (AT)0;
+        T asum = (T)0;
 #pragma unroll
-        for (int e = 0; e < LB_EPL; ++e) asum += fabs((AT)V.g[e]);
+        for (int e = 0; e < LB_EPL; ++e) asum += fabs(V.g[e]);
         asum = wave64_sum(asum);
         S.t = fmin(1.0, 1.0 / (double)asum) * O.lr;
     } else {
         S.t = O.lr;
     }
-    S.gtd = (double)vdot<VT, AT>(V.g, V.d);                           // :376
+    S.gtd = (double)vdot<T>(V.g, V.d);                                // :376
     if (S.gtd > -O.tol_change) goto L_step_return;                    // :379-380
     // ---- _strong_Wolfe entry (:43-53) ----
     S.d_norm = vmaxabs(V.d);
@@ -261,7 +407,7 @@ L_iter:
 
 L_ls_first:
     S.ls_evals = 1;
-    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
+    gtd_new = (double)vdot<T>(gnew, V.d);
     S.t_prev = 0.0; S.f_prev = S.f0; S.gtd_prev = S.gtd;
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) V.gprev[e] = V.g[e];
@@ -271,7 +417,7 @@ L_ls_first:
 
 L_ls_bracket:                                                         // :90-93
     S.ls_evals += 1;
-    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
+    gtd_new = (double)vdot<T>(gnew, V.d);
     S.ls_it += 1;
 
 L_bracket_check:                                                      // :54-93
@@ -346,7 +492,7 @@ L_zoom_check:                                                         // :108-13
 
 L_ls_zoom:                                                            // :130-161
     S.ls_evals += 1;
-    gtd_new = (double)vdot<VT, AT>(gnew, V.d);
+    gtd_new = (double)vdot<T>(gnew, V.d);
     S.ls_it += 1;
     if (f_new > (S.f0 + c1 * S.t * S.gtd) || f_new >= LB_SEL(S, bf, S.low)) {
         int h = S.high;
@@ -379,7 +525,7 @@ L_ls_return:                                                          // :163-16
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) {
             V.g[e] = (l == 0) ? V.bg0[e] : V.bg1[e];
-            V.x[e] = (VT)fma((AT)S.t, (AT)V.d[e], (AT)V.x[e]);
+            V.x[e] = fma((T)S.t, V.d[e], V.x[e]);
         }
         S.cur_evals += S.ls_evals;
     }
@@ -405,7 +551,7 @@ L_step_return:
                 // all(|max(grad_tensor)| < gtol): grad of the LAST closure call (= gnew)
                 bool all_small = true;
                 for (int sgi = 0; sgi < O.nseg; ++sgi) {
-                    VT m = (VT)-INFINITY;
+                    T m = (T)-INFINITY;
 #pragma unroll
                     for (int e = 0; e < LB_EPL; ++e) {
                         const int ix = LB_EPL * lane + e;
@@ -432,13 +578,13 @@ L_step_return:
         S.phase = PH_STEP_START;
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) xt[e] = V.x[e];
-        return;
+        return 0;
     }
 
 L_emit_trial:                                                         // _directional_evaluate :249-254
 #pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) xt[e] = (VT)fma((AT)S.t, (AT)V.d[e], (AT)V.x[e]);
-    return;
+    for (int e = 0; e < LB_EPL; ++e) xt[e] = fma((T)S.t, V.d[e], V.x[e]);
+    return 0;
 }
 
 }  // namespace mvfit

@@ -26,13 +26,6 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
                               hipStream_t stream);
 hipError_t vertex_pass_configure();
 
-#ifdef MVFIT_TIMING
-__device__ long long g_dbg[16];
-#define DBG_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[k] += clock64() - t_last; if (threadIdx.x == 0) t_last = clock64(); } while (0)
-#else
-#define DBG_T(k) do { } while (0)
-#endif
-
 struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
 
 // per-problem optimiser storage in HBM
@@ -43,6 +36,8 @@ struct FitBuffers {
     float* dirs;         // [B][100][LB_D]
     float* stps;         // [B][100][LB_D]
     float* ro;           // [B][100]
+    float* grow;         // [B][LB_GSIZE] pre-scaled Gram matrices (lbfgs_device.h:LbHist)
+    float* gcol;         // [B][LB_GSIZE]
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
     int* n_done;         // [1]
 };
@@ -195,28 +190,28 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevProble
 
 // shared by the two fit kernels: evaluate the closure at L.x, advance the optimiser, leave the
 // next trial point in L.x.  Returns true when the problem is finished.
-__device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float, float>& H,
+__device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           const float* vposed_pass, const float* xs_pass, double* stage_final, int tid) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
-#ifdef MVFIT_TIMING
-    long long t_last = clock64();
-#endif
+    PH_T0();
     pose_prep(M, L, W.flags, tid);
-    DBG_T(0);
+    PH_T(0);
     sparse_forward(M, L, vposed_pass, xs_pass, tid);
-    DBG_T(1);
+    PH_T(2);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
-    DBG_T(2);
+    PH_T(3);
     closure_backward(M, L, nviews, W, tid);
-    DBG_T(3);
+    PH_T(8);
+    LbState S;
+    LbVecs<float> V;
+    const int D = dact(use_vp);
     if (tid < 64) {
-        const int D = dact(use_vp);
-        LbState S = L.lbS;
-        LbVecs<float> V;
+        S = L.lbS;
         lb_load(V, &L.lbV[0][0], tid);
+        PH_T(9);
         float gnew[LB_EPL], xt[LB_EPL];
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) {
@@ -224,20 +219,40 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
             gnew[e] = i < D ? L.grad[cmap(i, use_vp)] : 0.f;
         }
         // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
-        lbfgs_advance<float, float>(S, V, H, O, (double)(float)total, gnew, xt, tid, stage_final);
-        lb_store(V, &L.lbV[0][0], tid);
+        const int need = lbfgs_advance<float>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final);
+        if (tid == 0) L.lbW.need_dir = need;
+        if (!need) {
 #pragma unroll
-        for (int e = 0; e < LB_EPL; ++e) {
-            const int i = LB_EPL * tid + e;
-            if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+            for (int e = 0; e < LB_EPL; ++e) {
+                const int i = LB_EPL * tid + e;
+                if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+            }
         }
-        if (tid == 0) { L.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
-#ifdef MVFIT_TIMING
-        if (blockIdx.x == 0 && tid == 0) { g_dbg[5] += 1; g_dbg[6] += S.hist_len; }
-#endif
     }
-    DBG_T(4);
     __syncthreads();
+    PH_T(10);
+    if (L.lbW.need_dir) {                                  // block-uniform
+        lb_direction_block<float, STEP_NT>(H, L.lbW, tid);
+        PH_T(11); PH_ADD(15, 1);
+        if (tid < 64) {
+            float gnew[LB_EPL], xt[LB_EPL];
+#pragma unroll
+            for (int e = 0; e < LB_EPL; ++e) gnew[e] = 0.f;
+            lbfgs_advance<float>(S, V, H, L.lbW, O, 0.0, gnew, xt, tid, stage_final);
+#pragma unroll
+            for (int e = 0; e < LB_EPL; ++e) {
+                const int i = LB_EPL * tid + e;
+                if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+            }
+        }
+    }
+    if (tid < 64) {
+        lb_store(V, &L.lbV[0][0], tid);
+        if (tid == 0) { L.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
+        PH_ADD(13, 1); PH_ADD(14, S.hist_len);
+    }
+    __syncthreads();
+    PH_T(12);
     return L.sh_status != 0;
 }
 
@@ -253,7 +268,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, DevProble
     load_x(L, F.xt + (size_t)b * DPAD, tid);
     lb_state_in(L, F, b, tid);
     opts_in(L, SW, O, tid);
-    LbHist<float, float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.lb_ro};
+    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.lb_ro,
+                    F.grow + (size_t)b * LB_GSIZE, F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
     const bool done = fit_round(M, L, Q.V, H, P.vposed_sel + (size_t)b * NC_MAX,
                                 P.xs_sel + (size_t)b * NC_MAX, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
@@ -282,7 +298,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, Dev
     const bool resume = F.S[b].n_closure > 0;             // relaunch after a round cap: restore the ring
     if (resume)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { hist[i] = gd[i]; hist[LB_HIST * LB_D + i] = gs[i]; }
-    LbHist<float, float> H{hist, hist + LB_HIST * LB_D, L.lb_ro};
+    LbHist<float> H{hist, hist + LB_HIST * LB_D, L.lb_ro, F.grow + (size_t)b * LB_GSIZE,
+                    F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
     bool done = false;
     for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
@@ -353,15 +370,17 @@ __device__ double kat_eval(int kind, int D, const double* x, double* g) {
 
 __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O, double* x_io, double* trace,
                                                        int max_trace, int* n_closure, double* final_loss,
-                                                       double* dirs, double* stps, double* ro) {
+                                                       double* dirs, double* stps, double* ro, double* grow,
+                                                       double* gcol) {
     __shared__ double xs[LB_D], gs[LB_D];
     __shared__ double fsh;
+    __shared__ LbWork<double> W;
     const int lane = threadIdx.x;
     LbState S;
     memset(&S, 0, sizeof(S));
     S.phase = PH_STEP_START; S.H = 1.0;
     LbVecs<double> V;
-    LbHist<double, double> H{dirs, stps, ro};
+    LbHist<double> H{dirs, stps, ro, grow, gcol};
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) {
         const int i = LB_EPL * lane + e;
@@ -388,7 +407,11 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
-        lbfgs_advance<double, double>(S, V, H, O, f, gnew, xt, lane, final_loss);
+        if (lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss)) {     // wave-uniform
+            __syncthreads();
+            lb_direction_block<double, 64>(H, W, lane);
+            lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss);
+        }
         if (S.status) break;
     }
 #pragma unroll
@@ -681,7 +704,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     drop_graph(c);
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->F.S, c->F.vecs, c->F.xt, c->F.dirs, c->F.stps, c->F.ro,
-                  c->F.stage_final, c->F.n_done};
+                  c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done};
     for (void* p : ps) if (p) hipFree(p);
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
     c->P = DevPose{};
@@ -734,6 +757,10 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * LB_D * 4));
         HIP_OK(c, hipMalloc(&c->F.ro, (size_t)B * LB_HIST * 4));
         HIP_OK(c, hipMemset(c->F.ro, 0, (size_t)B * LB_HIST * 4));
+        HIP_OK(c, hipMalloc(&c->F.grow, (size_t)B * LB_GSIZE * 4));
+        HIP_OK(c, hipMalloc(&c->F.gcol, (size_t)B * LB_GSIZE * 4));
+        HIP_OK(c, hipMemset(c->F.grow, 0, (size_t)B * LB_GSIZE * 4));
+        HIP_OK(c, hipMemset(c->F.gcol, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
         HIP_OK(c, hipMalloc(&c->F.n_done, 4));
         c->B = B; c->V = V; c->Bpad = Bpad;
@@ -961,10 +988,10 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
 }
 
 #ifdef MVFIT_TIMING
-extern "C" int mvfit_debug_timing(long long* out16, int reset) {
+extern "C" int mvfit_debug_timing(long long* out32, int reset) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16);
-    if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z)); }
+    hipMemcpyFromSymbol(out32, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 32);
+    if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z)); }
     return 0;
 }
 #endif
@@ -1010,22 +1037,26 @@ extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs,
     O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
     O.num_stages = 1; O.nseg = nseg;
     for (int i = 0; i < nseg; ++i) { O.seg_lo[i] = segs[i]; O.seg_hi[i] = segs[i + 1]; }
-    double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro;
+    double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro, *dgrow, *dgcol;
     int* dn;
     const size_t tb = (size_t)std::max(max_trace, 1) * (D + 1) * 8;
     if (hipMalloc(&dx, LB_D * 8) || hipMalloc(&dtrace, tb) || hipMalloc(&dfl, 8) || hipMalloc(&dn, 4) ||
-        hipMalloc(&ddirs, LB_HIST * LB_D * 8) || hipMalloc(&dstps, LB_HIST * LB_D * 8) || hipMalloc(&dro, LB_HIST * 8))
+        hipMalloc(&ddirs, LB_HIST * LB_D * 8) || hipMalloc(&dstps, LB_HIST * LB_D * 8) || hipMalloc(&dro, LB_HIST * 8) ||
+        hipMalloc(&dgrow, LB_GSIZE * 8) || hipMalloc(&dgcol, LB_GSIZE * 8))
         return MVFIT_E_HIP;
     hipMemcpy(dx, x_inout, D * 8, hipMemcpyHostToDevice);
     hipMemset(dtrace, 0, tb);
+    hipMemset(dgrow, 0, LB_GSIZE * 8);
+    hipMemset(dgcol, 0, LB_GSIZE * 8);
     hipMemset(ddirs, 0, LB_HIST * LB_D * 8);
     hipMemset(dstps, 0, LB_HIST * LB_D * 8);
-    hipLaunchKernelGGL(lbfgs_kat_kernel, dim3(1), dim3(64), 0, 0, kind, D, O, dx, dtrace, max_trace, dn, dfl, ddirs, dstps, dro);
+    hipLaunchKernelGGL(lbfgs_kat_kernel, dim3(1), dim3(64), 0, 0, kind, D, O, dx, dtrace, max_trace, dn, dfl, ddirs, dstps, dro,
+                       dgrow, dgcol);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(x_inout, dx, D * 8, hipMemcpyDeviceToHost);
     if (trace && max_trace > 0) hipMemcpy(trace, dtrace, tb, hipMemcpyDeviceToHost);
     if (n_closure) hipMemcpy(n_closure, dn, 4, hipMemcpyDeviceToHost);
     if (final_loss) hipMemcpy(final_loss, dfl, 8, hipMemcpyDeviceToHost);
-    hipFree(dx); hipFree(dtrace); hipFree(dfl); hipFree(dn); hipFree(ddirs); hipFree(dstps); hipFree(dro);
+    hipFree(dx); hipFree(dtrace); hipFree(dfl); hipFree(dn); hipFree(ddirs); hipFree(dstps); hipFree(dro); hipFree(dgrow); hipFree(dgcol);
     return e == hipSuccess ? MVFIT_OK : MVFIT_E_HIP;
 }

@@ -9,6 +9,20 @@
 
 namespace mvfit {
 
+// developer build (-DMVFIT_TIMING): per-phase shader-clock accumulation of workgroup 0
+#ifdef MVFIT_TIMING
+static __device__ long long g_dbg[32];
+static __device__ long long g_dbg_last;
+#define PH_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_dbg[k] += now_ - g_dbg_last; g_dbg_last = now_; } } while (0)
+#define PH_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_last = clock64(); } while (0)
+#define PH_ADD(k, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[k] += (v); } while (0)
+#else
+#define PH_T(k) do { } while (0)
+#define PH_T0() do { } while (0)
+#define PH_ADD(k, v) do { } while (0)
+#endif
+
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));

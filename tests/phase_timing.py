@@ -16,11 +16,14 @@ eng.set_problems(cams, np.zeros((B,V,17,2),np.float32), np.ones((B,V,17),np.floa
 _, joints = eng.vertices(xgt)
 gt, conf = syn.make_observations(joints.cpu().numpy(), cams); eng.set_problems(cams, gt, conf)
 x0 = np.zeros((B,118), np.float32); x0[:,85]=1
-buf = (C.c_longlong*16)()
+buf = (C.c_longlong*32)()
 for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
     lib.mvfit_debug_timing(buf, 1)
     xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
     lib.mvfit_debug_timing(buf, 1)
-    n = max(buf[5],1)
-    names = ['pose_prep','sparse_fwd','loss','backward','lbfgs']
-    print(name, 'rounds(block0)=%d avg hist=%.1f' % (n, buf[6]/n), ' '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(5)), 'cycles/round; total=%.0f' % (sum(buf[i] for i in range(5))/n))
+    n = max(buf[13],1)
+    names = ['pose_prep','chain||stream','T/xs','loss','E5 gx','E6 gA','E7 chainT||streamT','E8 gR/gbeta','E9 rodT+asm(+vpbwd)','lb load','lb advance A','lb direction','lb advance B+store']
+    print(name, 'rounds(block0)=%d avg hist=%.1f two-loops=%d' % (n, buf[14]/n, buf[15]))
+    print('   ', ' | '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(13)), '| total=%.0f cycles/round' % (sum(buf[i] for i in range(13))/n))
+    if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
+    print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
