@@ -42,10 +42,9 @@ struct ClosureLds {
     float R[NJ][9];
     float rod[NJ][3];               // angle, sin, cos
     float J[NJ][3];
-    float Rm[NJ][9];
-    float tm[NJ][3];
-    float Gr[NJ][9];
-    float Gt[NJ][3];
+    // 3x4 transforms, row-major [a][4] = [rotation | translation]; row NJ.. of gG / Mj are zero (absent child)
+    __attribute__((aligned(16))) float Mj[32][12];     // relative transforms [Rm | tm]          (lbs.py:341-348)
+    __attribute__((aligned(16))) float G[NJ][12];      // chained transforms  [Gr | Gt]          (lbs.py:349-355)
     __attribute__((aligned(16))) float A[NJ][12];
     float coef[KROWS];
     float vposed[NC_MAX];
@@ -55,11 +54,9 @@ struct ClosureLds {
     float gkp_part[MVFIT_MAX_VIEWS][NKP][3];
     float gx[NC_MAX];
     __attribute__((aligned(16))) float gvp[NC_MAX];
-    float gGr[NJ][9];
-    float gGt[NJ][3];
+    __attribute__((aligned(16))) float gG[32][12];     // adjoint of G
+    __attribute__((aligned(16))) float gM[NJ][12];     // adjoint of Mj = [g_Rm | g_tm]
     float gJ[NJ][3];
-    float gRm[NJ][9];
-    float gtm[NJ][3];
     float gR[NJ][9];
     float gtheta[72];
     float gbeta[12];
@@ -108,6 +105,7 @@ __device__ __forceinline__ void lds_load_constants(ClosureLds& L, const DevModel
         static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds must be a multiple of 16 bytes");
         for (int i = tid; i < n16; i += STEP_NT) dst[i] = src[i];
     }
+    if (tid < 8 * 12) { (&L.gG[NJ][0])[tid] = 0.f; (&L.Mj[NJ][0])[tid] = 0.f; }     // "no child" rows
     const int V = Q.V;
     const size_t cb = Q.cam_batched ? (size_t)b * V : 0;
     for (int i = tid; i < V * 9; i += STEP_NT) (&L.camR[0][0])[i] = Q.cam_R[cb * 9 + i];
@@ -389,7 +387,7 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
 #pragma unroll
             for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
             L.R[j][e] = sel;
-            L.Rm[j][e] = (j == 0 ? L.x[X_SC] : 1.0f) * sel;
+            L.Mj[j][4 * (e / 3) + (e % 3)] = (j == 0 ? L.x[X_SC] : 1.0f) * sel;
             if (e < 3) L.rod[j][e] = rod[e];
         } else {
             // J = J_t + J_S beta   (== J_regressor (v_template + shapedirs beta), lbs.py:179-183)
@@ -405,43 +403,40 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
                 for (int l = 0; l < 10; ++l) sp = fmaf(L.M.J_S[3 * pa + a][l], L.x[X_BETAS + l], sp);
             }
             L.J[j][a] = s;
-            L.tm[j][a] = s - sp;
+            L.Mj[j][4 * a + 3] = s - sp;
         }
     }
     __syncthreads();
 }
 
-// kinematic chain, level by level (lbs.py:349-355), then A_j = [Gr_j | Gt_j - Gr_j J_j] (lbs.py:365-368).
-// Executed by ONE wave: 12 lanes per joint, up to 5 joints of a level at a time, LDS hand-off
-// between levels without s_barrier.
+// kinematic chain (lbs.py:349-355) G_j = G_parent M_j in 3x4 form, then A_j = [Gr_j | Gt_j - Gr_j J_j]
+// (lbs.py:365-368).  Executed by ONE wave following the host-built schedule: lane = (slot q, row a,
+// column c); per pass one table word, one ds_read_b128 of the parent row and three FMAs, handed to
+// the next pass through LDS without s_barrier.
 __device__ void chain_forward_wave(ClosureLds& L, int lane) {
-    if (lane < 12) { if (lane < 9) L.Gr[0][lane] = L.Rm[0][lane]; else L.Gt[0][lane - 9] = L.tm[0][lane - 9]; }
+    if (lane < 12) L.G[0][lane] = L.Mj[0][lane];
+    const int q = lane / 12, e = lane - 12 * q, a = e >> 2, c = e & 3;
+    const int npass = L.M.n_fwd;
+    int w = (q < 5 && npass > 0) ? L.M.fwd_tab[0][q] : -1;
     wave_lds_fence();
-    const int q = lane / 12, e = lane - 12 * q;
-    const int nlevels = L.M.nlevels;
-    for (int lv = 1; lv < nlevels; ++lv) {
-        const int ls = L.M.level_start[lv], le = L.M.level_start[lv + 1];
-        for (int base = ls; base < le; base += 5) {
-            if (q < 5 && base + q < le) {
-                const int j = L.M.level_joints[base + q];
-                const int pa = L.M.parents[j];
-                if (e < 9) {
-                    const int a = e / 3, b = e - 3 * a;
-                    L.Gr[j][e] = L.Gr[pa][a * 3] * L.Rm[j][b] + L.Gr[pa][a * 3 + 1] * L.Rm[j][3 + b] + L.Gr[pa][a * 3 + 2] * L.Rm[j][6 + b];
-                } else {
-                    const int a = e - 9;
-                    L.Gt[j][a] = L.Gr[pa][a * 3] * L.tm[j][0] + L.Gr[pa][a * 3 + 1] * L.tm[j][1] + L.Gr[pa][a * 3 + 2] * L.tm[j][2] + L.Gt[pa][a];
-                }
-            }
+    for (int p = 0; p < npass; ++p) {
+        const int wn = (q < 5 && p + 1 < npass) ? L.M.fwd_tab[p + 1][q] : -1;    // next pass's word: off the critical path
+        if (w >= 0) {
+            const int j = w & 0xff, pa = w >> 8;
+            const float m0 = L.Mj[j][c], m1 = L.Mj[j][4 + c], m2 = L.Mj[j][8 + c];
+            const float4 g = *reinterpret_cast<const float4*>(&L.G[pa][4 * a]);
+            float v = g.x * m0 + g.y * m1 + g.z * m2;
+            if (c == 3) v += g.w;
+            L.G[j][e] = v;
         }
+        w = wn;
         wave_lds_fence();
     }
-    for (int i = lane; i < NJ * 12; i += 64) {
-        const int j = i / 12, ee = i - j * 12, a = ee >> 2, c = ee & 3;
-        float v;
-        if (c < 3) v = L.Gr[j][a * 3 + c];
-        else v = L.Gt[j][a] - (L.Gr[j][a * 3] * L.J[j][0] + L.Gr[j][a * 3 + 1] * L.J[j][1] + L.Gr[j][a * 3 + 2] * L.J[j][2]);
-        L.A[j][ee] = v;
+    for (int i = lane; i < NJ * 3; i += 64) {          // (joint, row a)
+        const int j = i / 3, aa = i - 3 * j;
+        const float4 g = *reinterpret_cast<const float4*>(&L.G[j][4 * aa]);
+        const float t = g.w - (g.x * L.J[j][0] + g.y * L.J[j][1] + g.z * L.J[j][2]);
+        *reinterpret_cast<float4*>(&L.A[j][4 * aa]) = make_float4(g.x, g.y, g.z, t);
     }
 }
 
@@ -486,7 +481,7 @@ __device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* vp
                                int tid) {
     const int nc = L.M.nc, nc_pad = L.M.nc_pad;
     const int nks = fwd_slices(nc_pad, STEP_NT - 64);
-    if (tid < 64) chain_forward_wave(L, tid);
+    if (tid < 64) { chain_forward_wave(L, tid); PH_T(22); }
     else if (vposed_pass == nullptr) contraction_forward(M, L, tid - 64, STEP_NT - 64);
     float vp_in = 0.f, xs_in = 0.f;
     if (vposed_pass != nullptr && tid < nc) { vp_in = vposed_pass[tid]; xs_in = xs_pass[tid]; }
@@ -670,43 +665,36 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
     return total;
 }
 
-// chain adjoint by ONE wave, deepest parents first: 12 lanes per parent joint.
+// chain adjoint by ONE wave, deepest parents first, following the host-built schedule:
+// g_G_p[a][m] += sum_children sum_col g_G_c[a][col] M_c[m][col]  (m < 3),  g_G_p[a][3] += g_G_c[a][3].
 __device__ void chain_backward_wave(ClosureLds& L, int lane) {
-    const int q = lane / 12, e = lane - 12 * q;
-    const int nlevels = L.M.nlevels;
-    for (int lv = nlevels - 2; lv >= 0; --lv) {
-        const int ls = L.M.level_start[lv], le = L.M.level_start[lv + 1];
-        for (int base = ls; base < le; base += 5) {
-            if (q < 5 && base + q < le) {
-                const int p = L.M.level_joints[base + q];
-                float acc = 0.f;
-                for (int ci = L.M.child_start[p]; ci < L.M.child_start[p + 1]; ++ci) {
-                    const int c = L.M.child_list[ci];
-                    if (e < 9) {
-                        const int a = e / 3, bq = e - 3 * a;
-                        acc += L.gGr[c][a * 3] * L.Rm[c][bq * 3] + L.gGr[c][a * 3 + 1] * L.Rm[c][bq * 3 + 1] +
-                               L.gGr[c][a * 3 + 2] * L.Rm[c][bq * 3 + 2] + L.gGt[c][a] * L.tm[c][bq];
-                    } else {
-                        acc += L.gGt[c][e - 9];
-                    }
-                }
-                if (e < 9) L.gGr[p][e] += acc; else L.gGt[p][e - 9] += acc;
+    const int q = lane / 12, e = lane - 12 * q, a = e >> 2, m = e & 3;
+    const int npass = L.M.n_bwd;
+    int w = (q < 5 && npass > 0) ? L.M.bwd_tab[0][q] : -1;
+    wave_lds_fence();
+    for (int ps = 0; ps < npass; ++ps) {
+        const int wn = (q < 5 && ps + 1 < npass) ? L.M.bwd_tab[ps + 1][q] : -1;
+        if (w != -1) {
+            const int p = w & 0xff, c0 = (w >> 8) & 0xff, c1 = (w >> 16) & 0xff, c2 = (w >> 24) & 0xff;
+            // child rows 24..31 are zero: absent children contribute nothing
+            const float4 k0 = *reinterpret_cast<const float4*>(&L.Mj[c0][4 * (m < 3 ? m : 0)]);
+            const float4 k1 = *reinterpret_cast<const float4*>(&L.Mj[c1][4 * (m < 3 ? m : 0)]);
+            const float4 k2 = *reinterpret_cast<const float4*>(&L.Mj[c2][4 * (m < 3 ? m : 0)]);
+            const float4 g0 = *reinterpret_cast<const float4*>(&L.gG[c0][4 * a]);
+            const float4 g1 = *reinterpret_cast<const float4*>(&L.gG[c1][4 * a]);
+            const float4 g2 = *reinterpret_cast<const float4*>(&L.gG[c2][4 * a]);
+            float acc;
+            if (m < 3) {
+                acc = (g0.x * k0.x + g0.y * k0.y + g0.z * k0.z + g0.w * k0.w) +
+                      (g1.x * k1.x + g1.y * k1.y + g1.z * k1.z + g1.w * k1.w) +
+                      (g2.x * k2.x + g2.y * k2.y + g2.z * k2.z + g2.w * k2.w);
+            } else {
+                acc = g0.w + g1.w + g2.w;
             }
+            L.gG[p][e] += acc;
         }
+        w = wn;
         wave_lds_fence();
-    }
-    // g_Rm = Gr_parent^T g_Gr ; g_tm = Gr_parent^T g_Gt   (root: identity)
-    for (int i = lane; i < NJ * 12; i += 64) {
-        const int j = i / 12, ee = i - j * 12;
-        if (j == 0) {
-            if (ee < 9) L.gRm[0][ee] = L.gGr[0][ee]; else L.gtm[0][ee - 9] = L.gGt[0][ee - 9];
-        } else {
-            const int pa = L.M.parents[j];
-            if (ee < 9) { const int a = ee / 3, bq = ee - 3 * a;
-                L.gRm[j][ee] = L.Gr[pa][a] * L.gGr[j][bq] + L.Gr[pa][3 + a] * L.gGr[j][3 + bq] + L.Gr[pa][6 + a] * L.gGr[j][6 + bq]; }
-            else { const int a = ee - 9;
-                L.gtm[j][a] = L.Gr[pa][a] * L.gGt[j][0] + L.Gr[pa][3 + a] * L.gGt[j][1] + L.Gr[pa][6 + a] * L.gGt[j][2]; }
-        }
     }
 }
 
@@ -793,55 +781,41 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
             const float J0 = L.J[j][0], J1 = L.J[j][1], J2 = L.J[j][2];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                L.gGr[j][3 * a + 0] = acc[3 * a + 0] - acc[9 + a] * J0;
-                L.gGr[j][3 * a + 1] = acc[3 * a + 1] - acc[9 + a] * J1;
-                L.gGr[j][3 * a + 2] = acc[3 * a + 2] - acc[9 + a] * J2;
-                L.gGt[j][a] = acc[9 + a];
-                L.gJ[j][a] = -(L.Gr[j][0 + a] * acc[9] + L.Gr[j][3 + a] * acc[10] + L.Gr[j][6 + a] * acc[11]);
+                *reinterpret_cast<float4*>(&L.gG[j][4 * a]) =
+                    make_float4(acc[3 * a + 0] - acc[9 + a] * J0, acc[3 * a + 1] - acc[9 + a] * J1,
+                                acc[3 * a + 2] - acc[9 + a] * J2, acc[9 + a]);
+                L.gJ[j][a] = -(L.G[j][0 + a] * acc[9] + L.G[j][4 + a] * acc[10] + L.G[j][8 + a] * acc[11]);
             }
         }
     }
     __syncthreads();
     PH_T(5);
     // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
-    if (tid < 64) chain_backward_wave(L, tid);
+    if (tid < 64) { chain_backward_wave(L, tid); PH_T(23); }
     else contraction_backward(M, L, tid - 64, STEP_NT - 64);
     const int ncs = bwd_slices(STEP_NT - 64);
     __syncthreads();
     PH_T(6);
-    // ---- E8: g_R, g_scale, g_J -> g_beta ----
-    if (tid < NJ * 9) {
-        const int j = tid / 9, e = tid - 9 * j;
+    // ---- E8a: g_M = G_parent^T g_G (root: identity) ; g_R = g_Rm (+ g_coef) ----
+    if (tid < NJ * 12) {
+        const int j = tid / 12, e = tid - 12 * j, mm = e >> 2, c = e & 3;
         float v;
-        if (j == 0) v = L.x[X_SC] * L.gRm[0][e];
+        if (j == 0) v = L.gG[0][e];
         else {
-            float gc = 0.f;
-            for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + e];
-            v = L.gRm[j][e] + gc;
+            const int pa = L.M.parents[j];
+            v = L.G[pa][mm] * L.gG[j][c] + L.G[pa][4 + mm] * L.gG[j][4 + c] + L.G[pa][8 + mm] * L.gG[j][8 + c];
         }
-        L.gR[j][e] = v;
-    } else if (tid >= 256 && tid < 256 + 160) {
-        // g_beta[l] = g_coef[207 + l] + sum_i J_S[i][l] g_J[i]  (+ shape prior): 16 lanes per l
-        const int l = (tid - 256) >> 4, g = tid & 15;
-        float s = 0.f;
-        for (int i = g; i < NJ * 3; i += 16) {
-            const int j = i / 3, a = i - 3 * j;
-            float gj = L.gJ[j][a] + L.gtm[j][a];
-            for (int ci = L.M.child_start[j]; ci < L.M.child_start[j + 1]; ++ci) gj -= L.gtm[L.M.child_list[ci]][a];
-            s = fmaf(L.M.J_S[i][l], gj, s);
+        L.gM[j][e] = v;
+        if (c < 3) {
+            float gr;
+            if (j == 0) gr = L.x[X_SC] * v;
+            else {
+                float gc = 0.f;
+                for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + 3 * mm + c];
+                gr = v + gc;
+            }
+            L.gR[j][3 * mm + c] = gr;
         }
-        s = row16_sum(s);
-        if (g == 0) {
-            float gc = 0.f;
-            for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
-            s += gc;
-            if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.x[X_BETAS + l] * W.shape_w * W.shape_w;
-            L.gbeta[l] = s;
-        }
-    } else if (tid == 448) {
-        float s = 0.f;
-        for (int e = 0; e < 9; ++e) s += L.gRm[0][e] * L.R[0][e];
-        L.gscale = s;
     }
     if (!use_vp && (W.flags & MVFIT_F_PRIOR_GMM) && !(L.flags_dropped & 1)) {
         // 0.5 (P d + P^T d) of the selected mixture: P d is gmm_t[m]; P^T d via the transposed copy
@@ -858,9 +832,32 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
     }
     __syncthreads();
     PH_T(7);
-    // ---- E9: Rodrigues adjoint per joint + priors on the pose ----
+    // ---- E8b || E9: g_scale ; g_J -> g_beta ; Rodrigues adjoint + pose priors ----
     const float wp2 = W.pose_w * W.pose_w;
-    if (tid < NJ) {
+    if (tid >= 256 && tid < 256 + 160) {
+        // g_beta[l] = g_coef[207 + l] + sum_i J_S[i][l] g_J[i]  (+ shape prior): 16 lanes per l
+        const int l = (tid - 256) >> 4, g = tid & 15;
+        float s = 0.f;
+        for (int i = g; i < NJ * 3; i += 16) {
+            const int j = i / 3, a = i - 3 * j;
+            float gj = L.gJ[j][a] + L.gM[j][4 * a + 3];
+            for (int ci = L.M.child_start[j]; ci < L.M.child_start[j + 1]; ++ci) gj -= L.gM[L.M.child_list[ci]][4 * a + 3];
+            s = fmaf(L.M.J_S[i][l], gj, s);
+        }
+        s = row16_sum(s);
+        if (g == 0) {
+            float gc = 0.f;
+            for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
+            s += gc;
+            if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.x[X_BETAS + l] * W.shape_w * W.shape_w;
+            L.gbeta[l] = s;
+        }
+    } else if (tid == 448) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s += L.gM[0][4 * (e / 3) + (e % 3)] * L.R[0][e];
+        L.gscale = s;
+    } else if (tid < NJ) {
         const float rx = L.theta[3 * tid], ry = L.theta[3 * tid + 1], rz = L.theta[3 * tid + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
         const float a = L.rod[tid][0], sn = L.rod[tid][1], cs = L.rod[tid][2];

@@ -652,6 +652,56 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
             for (int j = 1; j < NJ; ++j) if (m->parents[j] == p) G.child_list[pos++] = j;
         }
         G.child_start[NJ] = pos;
+        // forward schedule: each level in groups of 5 joints (one wave = 5 x 12 lanes)
+        memset(G.fwd_tab, 0xff, sizeof(G.fwd_tab));
+        memset(G.bwd_tab, 0xff, sizeof(G.bwd_tab));
+        int np = 0;
+        for (int lv = 1; lv <= maxd; ++lv)
+            for (int base = G.level_start[lv]; base < G.level_start[lv + 1]; base += 5, ++np) {
+                if (np >= NJ) return fail(c, MVFIT_E_UNSUPPORTED, "kinematic tree needs more than %d chain passes", NJ);
+                for (int q = 0; q < 5 && base + q < G.level_start[lv + 1]; ++q) {
+                    const int j = G.level_joints[base + q];
+                    G.fwd_tab[np][q] = j | (m->parents[j] << 8);
+                }
+            }
+        G.n_fwd = np;
+        // backward schedule: parents with children, deepest level first; <= 3 children per entry
+        // (a parent with more children appears in consecutive passes), <= 5 entries per pass.
+        // Two entries of the same parent never share a pass (they would race on its row).
+        np = 0;
+        for (int lv = maxd - 1; lv >= 0; --lv) {
+            std::vector<int> entries;     // packed words of this level
+            for (int i = G.level_start[lv]; i < G.level_start[lv + 1]; ++i) {
+                const int p = G.level_joints[i];
+                const int nc = G.child_start[p + 1] - G.child_start[p];
+                for (int k = 0; k < nc; k += 3) {
+                    int ch[3] = {31, 31, 31};
+                    for (int t = 0; t < 3 && k + t < nc; ++t) ch[t] = G.child_list[G.child_start[p] + k + t];
+                    entries.push_back(p | (ch[0] << 8) | (ch[1] << 16) | (ch[2] << 24));
+                }
+            }
+            // greedy packing into passes: at most 5 entries, no repeated parent inside a pass
+            std::vector<bool> used(entries.size(), false);
+            size_t left = entries.size();
+            while (left > 0) {
+                if (np >= NJ) return fail(c, MVFIT_E_UNSUPPORTED, "kinematic tree needs more than %d adjoint passes", NJ);
+                int q = 0;
+                std::vector<int> parents_in_pass;
+                for (size_t i = 0; i < entries.size() && q < 5; ++i) {
+                    if (used[i]) continue;
+                    const int p = entries[i] & 0xff;
+                    bool clash = false;
+                    for (int pp : parents_in_pass) clash |= pp == p;
+                    if (clash) continue;
+                    G.bwd_tab[np][q++] = entries[i];
+                    parents_in_pass.push_back(p);
+                    used[i] = true;
+                    --left;
+                }
+                ++np;
+            }
+        }
+        G.n_bwd = np;
     }
     M.mlds = dev_upload(c, imgv);
     // ---- VPoser decoder ----

@@ -46,7 +46,13 @@ struct ModelLds {
     int level_joints[NJ];
     int child_start[NJ + 1];
     int child_list[NJ];
-    int ns, nc, nc_pad, pad0, pad1, pad2;
+    // kinematic chain schedules for ONE wave (12 lanes per joint, 5 joints per pass):
+    //   fwd_tab[pass][q] = j | parent << 8 (or -1): joints whose parent transform is complete
+    //   bwd_tab[pass][q] = parent | c0 << 8 | c1 << 16 | c2 << 24 (or -1), children 31 = none
+    int n_fwd, n_bwd;
+    int fwd_tab[NJ][5];
+    int bwd_tab[NJ][5];
+    int ns, nc, nc_pad, pad0;
 };
 static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds is bulk-copied as 16-byte words");
 
