@@ -6,15 +6,18 @@
 // J(beta) and the kinematic chain (lbs.py:183,205) are done per problem by the step kernel.
 //
 // MI355X mapping
-//   * one workgroup = one tile of 32 vertices x one chunk of 32 problems; 3*KSPLIT waves.
-//   * the blendshape contraction [32 problems x 224] . [224 x (32 verts x 3 coords)] runs on the
-//     matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32): wave (coord, kslice) owns one 32x32
-//     accumulator.  The basis is pre-tiled in HBM in B-operand order so every wave load is one
-//     contiguous 1 KiB global_load_dwordx4 covering 4 k-steps; each basis element is read once
-//     per chunk.  The A operand (coefficients, transposed per chunk by the step kernel) is
-//     staged once in LDS and read conflict-free (64 consecutive floats per k-step).
-//   * k-slice partials meet in LDS in a fixed order (deterministic), then the skinning blend
-//     T = W.A and the affine apply run on the VALU while other workgroups' MFMAs proceed.
+//   * one workgroup = one tile of 32 vertices x one chunk of 32 problems; 8 waves with two roles,
+//     one wave of each role per SIMD (matrix pipe and VALU are separate pipes and run concurrently):
+//       waves 0-3 "contraction": the blendshape contraction [32 problems x 224] . [224 x 32 verts x 3]
+//         on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  Wave w owns
+//         k-slice w (56 of the 224 rows) of all three coordinate planes: 3 accumulators, 84 MFMAs.  The
+//         basis is pre-tiled in HBM in B-operand order so every wave load is one contiguous 1 KiB
+//         global_load_dwordx4 covering 4 k-steps; all 21 loads of a wave are issued before anything
+//         else, so the HBM stream overlaps the operand staging; each basis element is read once per chunk.
+//       waves 4-7 "blend": the skinning transforms T = W . A (32 problems x 32 vertices x 12 entries x 24
+//         joints, 295 kFMA) on the VALU while the MFMAs run, kept in registers (48 per thread).
+//   * k-slice partials meet in LDS in a fixed order (deterministic); the blend waves add them up and
+//     apply their T; all waves store.
 //   * tile index = blockIdx.x, so the tile -> XCD assignment (block b -> XCD b%8) is the same in
 //     every launch: each XCD keeps its 1/8 of the 18 MB basis in its own 4 MiB L2 across the
 //     closure rounds of a fit.
@@ -22,22 +25,29 @@
 
 namespace mvfit {
 
+#ifdef MVFIT_TIMING
+__device__ long long g_vp[16];
+#define VP_T(k, t0) do { if (blockIdx.x == 5 && (threadIdx.x & 255) == 0) g_vp[(k) + (threadIdx.x >> 8) * 8] += clock64() - (t0); } while (0)
+#else
+#define VP_T(k, t0) do { } while (0)
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int KSPLIT>
-__global__ __launch_bounds__(192 * KSPLIT) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
-                                                                       float* __restrict__ verts) {
-    constexpr int NT = 192 * KSPLIT;
-    constexpr int GPS = KGROUPS / KSPLIT;           // k-groups per slice
-    static_assert(KGROUPS % KSPLIT == 0, "KSPLIT must divide 28");
+constexpr int VP_NT = 512;
+constexpr int VP_KSPLIT = 4;
+constexpr int VP_GPS = KGROUPS / VP_KSPLIT;      // 7 groups of 4 k-steps per slice
+
+__global__ __launch_bounds__(VP_NT) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
+                                                                float* __restrict__ verts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* coefT_l = smem;                          // [KROWS][32]
     float* A_l = coefT_l + KROWS * 32;              // [32][A_STRIDE]
     float* Wt_l = A_l + 32 * A_STRIDE;              // [24][32]
     float* tau_l = Wt_l + NJ * 32;                  // [32][4]
     float* part = tau_l + 32 * 4;                   // [KSPLIT][3][32][33]
-    float* vp_l = part + KSPLIT * 3 * 32 * 33;      // [32 b][32 v][4]  (x,y,z,pad)
-    float* out_l = part;                            // alias: [32 b][96] after the partials are consumed
+    float* out_l = part + VP_KSPLIT * 3 * 32 * 33;  // [32 b][96]  skinned positions before "+ transl"
+    float* vps_l = out_l + 32 * 96;                 // [32 b][96]  v_posed (only read for the side outputs)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -45,176 +55,202 @@ __global__ __launch_bounds__(192 * KSPLIT) void lbs_vertex_pass_kernel(DevModel 
     const int tile = blockIdx.x;
     const int chunk = blockIdx.y;
     const int b0 = chunk * 32;
+    const bool mfma_role = wave < 4;
+#ifdef MVFIT_TIMING
+    const long long t_start = clock64();
+#else
+    const long long t_start = 0;
+#endif
 
-    // ---- stage the per-chunk operands in LDS ----
-    {
-        const float4* src = reinterpret_cast<const float4*>(P.coefT + (size_t)chunk * KROWS * 32);
-        float4* dst = reinterpret_cast<float4*>(coefT_l);
-        for (int i = tid; i < KROWS * 32 / 4; i += NT) dst[i] = src[i];
-        for (int i = tid; i < 32 * 288; i += NT) {
-            int b = i / 288, e = i - b * 288;
-            A_l[b * A_STRIDE + e] = (b0 + b < B) ? P.Amat[(size_t)(b0 + b) * 288 + e] : 0.f;
-        }
-        const float* wsrc = M.wt_tiles + (size_t)tile * NJ * 32;
-        for (int i = tid; i < NJ * 32; i += NT) Wt_l[i] = wsrc[i];
-        if (tid < 128) {
-            int b = tid >> 2;
-            tau_l[tid] = (b0 + b < B) ? P.tau[(size_t)(b0 + b) * 4 + (tid & 3)] : 0.f;
+    // ---- contraction waves: the whole HBM stream of the wave goes out first ----
+    float4 bv[3][VP_GPS];
+    float vt_init[3] = {0.f, 0.f, 0.f};
+    if (mfma_role) {
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc) {
+            const float4* bsrc = reinterpret_cast<const float4*>(M.bs4) +
+                                 ((size_t)(tile * 3 + kc) * KGROUPS + wave * VP_GPS) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < VP_GPS; ++g) bv[kc][g] = bsrc[g * 64];
+            if (wave == 0) vt_init[kc] = M.vt_planes[kc * M.nv_pad + tile * TILE_V + (lane & 31)];
         }
     }
-    __syncthreads();
 
-    // ---- blendshape contraction on the matrix cores ----
+    // ---- stage the per-chunk operands in LDS: loads first, then the LDS writes ----
     {
-        const int k = wave % 3;           // coordinate plane
-        const int ks = wave / 3;          // k-slice
-        floatx16 acc;
-        float init = (ks == 0) ? M.vt_planes[k * M.nv_pad + tile * TILE_V + (lane & 31)] : 0.f;
+        const float4* csrc = reinterpret_cast<const float4*>(P.coefT + (size_t)chunk * KROWS * 32);
+        const float4* asrc4 = reinterpret_cast<const float4*>(P.Amat + (size_t)b0 * 288);   // Bpad rows exist
+        float4 c4[4], a4[5];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = init;
-        const float4* bsrc = reinterpret_cast<const float4*>(M.bs4) +
-                             ((size_t)(tile * 3 + k) * KGROUPS + ks * GPS) * 64 + lane;
+        for (int r = 0; r < 4; ++r) { const int i = tid + r * VP_NT; c4[r] = i < KROWS * 8 ? csrc[i] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { const int i = tid + r * VP_NT; a4[r] = i < 32 * 72 ? asrc4[i] : make_float4(0, 0, 0, 0); }
+        float4 w4 = make_float4(0, 0, 0, 0), t4 = w4;
+        if (tid < NJ * 8) w4 = reinterpret_cast<const float4*>(M.wt_tiles + (size_t)tile * NJ * 32)[tid];
+        if (tid < 32) t4 = reinterpret_cast<const float4*>(P.tau + (size_t)b0 * 4)[tid];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int i = tid + r * VP_NT; if (i < KROWS * 8) reinterpret_cast<float4*>(coefT_l)[i] = c4[r]; }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int i = tid + r * VP_NT;
+            if (i < 32 * 72) { const int b = i / 72, q = i - b * 72; *reinterpret_cast<float4*>(A_l + b * A_STRIDE + 4 * q) = a4[r]; }
+        }
+        if (tid < NJ * 8) reinterpret_cast<float4*>(Wt_l)[tid] = w4;
+        if (tid < 32) reinterpret_cast<float4*>(tau_l)[tid] = t4;
+    }
+    VP_T(0, t_start);
+    __syncthreads();
+    VP_T(1, t_start);
+
+    // skinning item of a blend thread: 4 vertices x 1 problem, all three rows of T
+    const int bt = tid - 256, vg = bt & 7, bb = bt >> 3;
+    float tr[3][4][4];
+    if (mfma_role) {
+        // ---- blendshape contraction: k-slice `wave` of the three coordinate planes ----
+        floatx16 acc[3];
+#pragma unroll
+        for (int kc = 0; kc < 3; ++kc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kc][r] = vt_init[kc];
         const float* asrc = coefT_l + (lane >> 5) * 32 + (lane & 31);
-        float4 bv[GPS];
 #pragma unroll
-        for (int g = 0; g < GPS; ++g) bv[g] = bsrc[g * 64];
+        for (int g = 0; g < VP_GPS; ++g) {
+            const int kk0 = (wave * VP_GPS + g) * 4;
+            const float a0 = asrc[(2 * (kk0 + 0)) * 32];
+            const float a1 = asrc[(2 * (kk0 + 1)) * 32];
+            const float a2 = asrc[(2 * (kk0 + 2)) * 32];
+            const float a3 = asrc[(2 * (kk0 + 3)) * 32];
 #pragma unroll
-        for (int g = 0; g < GPS; ++g) {
-            const int kk0 = (ks * GPS + g) * 4;
-            float a0 = asrc[(2 * (kk0 + 0)) * 32];
-            float a1 = asrc[(2 * (kk0 + 1)) * 32];
-            float a2 = asrc[(2 * (kk0 + 2)) * 32];
-            float a3 = asrc[(2 * (kk0 + 3)) * 32];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bv[g].w, acc, 0, 0, 0);
+            for (int kc = 0; kc < 3; ++kc) {
+                acc[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[kc][g].x, acc[kc], 0, 0, 0);
+                acc[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[kc][g].y, acc[kc], 0, 0, 0);
+                acc[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv[kc][g].z, acc[kc], 0, 0, 0);
+                acc[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bv[kc][g].w, acc[kc], 0, 0, 0);
+            }
         }
         // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        float* pdst = part + ((ks * 3 + k) * 32) * 33 + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            pdst[b * 33] = acc[r];
+        for (int kc = 0; kc < 3; ++kc) {
+            float* pdst = part + ((wave * 3 + kc) * 32) * 33 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                pdst[b * 33] = acc[kc][r];
+            }
+        }
+    } else {
+        // ---- skinning blend T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213) ----
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+        const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll 2
+        for (int j = 0; j < NJ; ++j) {
+            const float4 w = *reinterpret_cast<const float4*>(Wt_l + j * 32 + 4 * vg);
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
+                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
+                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
+                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
+                }
+            }
         }
     }
+    VP_T(2, t_start);
     __syncthreads();
+    VP_T(3, t_start);
 
-    // ---- combine k-slices (fixed order) -> v_posed[b][v][coord] ----
-    for (int t = tid; t < 32 * 3 * 8; t += NT) {
-        const int vg = t & 7, bk = t >> 3, k = bk % 3, b = bk / 3;
+    // ---- blend waves: combine the k-slices (fixed order) and apply T ----
+    if (!mfma_role) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int v = 4 * vg + i;
-            float s = part[((0 * 3 + k) * 32 + b) * 33 + v];
+            float vp[3];
 #pragma unroll
-            for (int q = 1; q < KSPLIT; ++q) s += part[((q * 3 + k) * 32 + b) * 33 + v];
-            vp_l[(b * 32 + v) * 4 + k] = s;
-        }
-    }
-    __syncthreads();
-
-    // ---- skinning: row k of T = sum_j W[v][j] A_b[j], applied to v_posed; + transl ----
-    for (int t = tid; t < 32 * 3 * 8; t += NT) {
-        const int vg = t & 7, bk = t >> 3, k = bk % 3, b = bk / 3;
-        float tr[4][4];
+            for (int k = 0; k < 3; ++k) {
+                float sm = part[((0 * 3 + k) * 32 + bb) * 33 + v];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int q = 1; q < VP_KSPLIT; ++q) sm += part[((q * 3 + k) * 32 + bb) * 33 + v];
+                vp[k] = sm;
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tr[i][e] = 0.f;
-        const float* arow = A_l + b * A_STRIDE + 4 * k;
-#pragma unroll 4
-        for (int j = 0; j < NJ; ++j) {
-            const float4 w = *reinterpret_cast<const float4*>(Wt_l + j * 32 + 4 * vg);
-            const float4 a = *reinterpret_cast<const float4*>(arow + j * 12);
-            const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tr[i][0] = fmaf(wv[i], a.x, tr[i][0]);
-                tr[i][1] = fmaf(wv[i], a.y, tr[i][1]);
-                tr[i][2] = fmaf(wv[i], a.z, tr[i][2]);
-                tr[i][3] = fmaf(wv[i], a.w, tr[i][3]);
+            for (int k = 0; k < 3; ++k) {
+                out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+                vps_l[bb * 96 + v * 3 + k] = vp[k];
             }
         }
-        float xo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 vp = *reinterpret_cast<const float4*>(vp_l + (b * 32 + 4 * vg + i) * 4);
-            xo[i] = fmaf(tr[i][0], vp.x, fmaf(tr[i][1], vp.y, fmaf(tr[i][2], vp.z, tr[i][3])));
-        }
-        // out_l aliases the (now dead) partial slabs only after every thread passed the combine
-        // barrier above; the slabs are not read again in this loop.  It holds the skinned position
-        // BEFORE "+ transl" (the step kernel wants that value; the store below adds transl).
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out_l[b * 96 + (4 * vg + i) * 3 + k] = xo[i];
     }
+    VP_T(4, t_start);
     __syncthreads();
+    VP_T(5, t_start);
 
     // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
     {
         const int vbase = tile * TILE_V;
         const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
-        for (int i = tid; i < 32 * 48; i += NT) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
             const int b = i / 48, q = i - b * 48;
-            if (b0 + b >= B) continue;
-            float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
-            const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
-            float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
-            o.x += tau_l[b * 4 + k0];
-            o.y += tau_l[b * 4 + k1];
-            if (2 * q + 1 < nvalid) {
-                *reinterpret_cast<float2*>(dst) = o;
-            } else if (2 * q < nvalid) {
-                dst[0] = o.x;
+            if (b0 + b < B) {
+                float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
+                const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
+                float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+                o.x += tau_l[b * 4 + k0];
+                o.y += tau_l[b * 4 + k1];
+                if (2 * q + 1 < nvalid) *reinterpret_cast<float2*>(dst) = o;
+                else if (2 * q < nvalid) dst[0] = o.x;
             }
         }
     }
     // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
     {
         const int s0 = M.tile_sel_start[tile], nsel = M.tile_sel_start[tile + 1] - s0;
-        for (int i = tid; i < nsel * 96; i += NT) {
+        for (int i = tid; i < nsel * 96; i += VP_NT) {
             const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
             if (b0 + b >= B) continue;
             const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
-            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vp_l[(b * 32 + lv) * 4 + k];
+            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
             P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
         }
     }
+    VP_T(6, t_start);
+#ifdef MVFIT_TIMING
+    if (blockIdx.x == 5 && threadIdx.x == 0) g_vp[7] += 1;
+#endif
 }
 
-size_t vertex_pass_lds_bytes(int ksplit) {
+size_t vertex_pass_lds_bytes() {
     return sizeof(float) * (size_t)(KROWS * 32 + 32 * A_STRIDE + NJ * 32 + 32 * 4 +
-                                    ksplit * 3 * 32 * 33 + 32 * 32 * 4);
+                                    VP_KSPLIT * 3 * 32 * 33 + 2 * 32 * 96);
 }
 
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream) {
+    (void)ksplit;
     dim3 grid(M.ntiles, (B + 31) / 32);
-    size_t lds = vertex_pass_lds_bytes(ksplit);
-    switch (ksplit) {
-        case 1:
-            hipLaunchKernelGGL(lbs_vertex_pass_kernel<1>, grid, dim3(192), lds, stream, M, P, B, verts);
-            break;
-        case 2:
-            hipLaunchKernelGGL(lbs_vertex_pass_kernel<2>, grid, dim3(384), lds, stream, M, P, B, verts);
-            break;
-        default:
-            hipLaunchKernelGGL(lbs_vertex_pass_kernel<4>, grid, dim3(768), lds, stream, M, P, B, verts);
-            break;
-    }
+    hipLaunchKernelGGL(lbs_vertex_pass_kernel, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
     return hipGetLastError();
 }
 
 hipError_t vertex_pass_configure() {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes(1));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes(2));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<4>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes(4));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
 }
 
 }  // namespace mvfit
+
+#ifdef MVFIT_TIMING
+extern "C" int mvfit_debug_vp(long long* out16) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_vp), sizeof(long long) * 16);
+}
+#endif

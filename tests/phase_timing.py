@@ -28,3 +28,10 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
     if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
     print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
+
+vb = (C.c_longlong*16)()
+lib.mvfit_debug_vp(vb)
+nl = max(vb[7], 1)
+print('vertex pass (workgroup 5, %d launches), cumulative cycles at each mark: [issue+stage | sync1 | mfma-or-blend | sync2 | apply | sync3 | end]' % nl)
+print('   contraction wave 0:', ' '.join('%.0f' % (vb[i]/nl) for i in range(7)))
+print('   blend wave 4      :', ' '.join('%.0f' % (vb[8+i]/nl) for i in range(7)))
