@@ -27,34 +27,49 @@
 
 namespace mvfit {
 
-struct ClosureLds {
-    ModelLds M;                     // model constants (copied once per launch)
-    // per-problem observations (copied once per launch)
+// Blocks of the LDS image that are moved to / from HBM as 16-byte words (one load per thread, all
+// issued before a single wait: a kernel prologue costs one memory round trip, not one per array).
+struct ObsBlock {                   // per-problem observations, packed by mvfit_set_problems
     float camR[MVFIT_MAX_VIEWS][9];
     float camt[MVFIT_MAX_VIEWS][3];
     float camf[MVFIT_MAX_VIEWS];
     float camc[MVFIT_MAX_VIEWS][2];
     float gt[MVFIT_MAX_VIEWS * NKP * 2];
     float wc[MVFIT_MAX_VIEWS * NKP];
-    // state of one evaluation
-    __attribute__((aligned(16))) float x[DPAD];
+};
+struct PoseBlock {                  // everything pose_prep + the chain derive from x (handed from launch to launch)
     float theta[72];
     float R[NJ][9];
     float rod[NJ][3];               // angle, sin, cos
     float J[NJ][3];
-    // 3x4 transforms, row-major [a][4] = [rotation | translation]; row NJ.. of gG / Mj are zero (absent child)
-    __attribute__((aligned(16))) float Mj[32][12];     // relative transforms [Rm | tm]          (lbs.py:341-348)
-    __attribute__((aligned(16))) float G[NJ][12];      // chained transforms  [Gr | Gt]          (lbs.py:349-355)
-    __attribute__((aligned(16))) float A[NJ][12];
+    // 3x4 transforms, row-major [a][4] = [rotation | translation]; rows NJ.. of Mj are zero (absent child)
+    float Mj[32][12];               // relative transforms [Rm | tm]          (lbs.py:341-348)
+    float G[NJ][12];                // chained transforms  [Gr | Gt]          (lbs.py:349-355)
+    float A[NJ][12];                // skinning transforms                    (lbs.py:365-368)
+};
+struct OptBlock {                   // optimiser state that survives between closure rounds
+    float x[DPAD];                  // current trial point, flat parameter layout
+    float lb_ro[104];               // ro = 1/(y.s) per history slot
+    LbState lbS;
+    float lbV[LB_NVEC][LB_D];
+};
+static_assert(sizeof(ObsBlock) % 16 == 0 && sizeof(PoseBlock) % 16 == 0 && sizeof(OptBlock) % 16 == 0, "16-byte blocks");
+
+struct ClosureLds {
+    ModelLds M;                     // model constants
+    __attribute__((aligned(16))) ObsBlock obs;
+    __attribute__((aligned(16))) OptBlock opt;
+    __attribute__((aligned(16))) PoseBlock pose;
+    // state of one evaluation
     float coef[KROWS];
-    float vposed[NC_MAX];
-    float xs[NC_MAX];
+    __attribute__((aligned(16))) float vposed[NC_MAX];
+    __attribute__((aligned(16))) float xs[NC_MAX];
     __attribute__((aligned(16))) float T[NS_MAX][12];
     float kp[NKP][3];
     float gkp_part[MVFIT_MAX_VIEWS][NKP][3];
     float gx[NC_MAX];
     __attribute__((aligned(16))) float gvp[NC_MAX];
-    __attribute__((aligned(16))) float gG[32][12];     // adjoint of G
+    __attribute__((aligned(16))) float gG[32][12];     // adjoint of G (rows NJ.. zero)
     __attribute__((aligned(16))) float gM[NJ][12];     // adjoint of Mj = [g_Rm | g_tm]
     float gJ[NJ][3];
     float gR[NJ][9];
@@ -84,36 +99,46 @@ struct ClosureLds {
     float gmm_d[72];
     float gmm_t[8][72];
     float gmm_ll[8];
-    // L-BFGS: ro = 1/(y.s) per history slot, scalar state and working vectors (only wave 0 touches
-    // them, and only between two closure evaluations: kept here so that they cost no registers
-    // while the closure runs); in the single-launch fit the (s, y) ring follows this struct.
-    float lb_ro[LB_HIST];
-    DevWeights sw[MVFIT_MAX_STAGES];          // per-stage weights and optimiser options: read from LDS inside the
-    __attribute__((aligned(16))) LbOpts opts; // round loop so that they do not pin ~100 SGPRs across it
-    __attribute__((aligned(16))) LbState lbS;
+    // per-stage weights and optimiser options: read from LDS inside the round loop so that they do not
+    // pin ~100 SGPRs across it; in the single-launch fit the (s, y) ring follows this struct.
+    DevWeights sw[MVFIT_MAX_STAGES];
+    __attribute__((aligned(16))) LbOpts opts;
     __attribute__((aligned(16))) LbWork<float> lbW;
-    __attribute__((aligned(16))) float lbV[LB_NVEC][LB_D];
 };
 
-// copy the launch-constant part of the LDS image: model block + this problem's observations
-__device__ __forceinline__ void lds_load_constants(ClosureLds& L, const DevModel& M, const DevProblems& Q, int b,
-                                                   int tid) {
-    {
-        const int4* src = reinterpret_cast<const int4*>(M.mlds);
-        int4* dst = reinterpret_cast<int4*>(&L.M);
-        constexpr int n16 = sizeof(ModelLds) / 16;
-        static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds must be a multiple of 16 bytes");
-        for (int i = tid; i < n16; i += STEP_NT) dst[i] = src[i];
-    }
-    if (tid < 8 * 12) { (&L.gG[NJ][0])[tid] = 0.f; (&L.Mj[NJ][0])[tid] = 0.f; }     // "no child" rows
-    const int V = Q.V;
-    const size_t cb = Q.cam_batched ? (size_t)b * V : 0;
-    for (int i = tid; i < V * 9; i += STEP_NT) (&L.camR[0][0])[i] = Q.cam_R[cb * 9 + i];
-    for (int i = tid; i < V * 3; i += STEP_NT) (&L.camt[0][0])[i] = Q.cam_t[cb * 3 + i];
-    for (int i = tid; i < V; i += STEP_NT) L.camf[i] = Q.cam_f[cb + i];
-    for (int i = tid; i < V * 2; i += STEP_NT) (&L.camc[0][0])[i] = Q.cam_c[cb * 2 + i];
-    for (int i = tid; i < V * NKP * 2; i += STEP_NT) L.gt[i] = Q.gt_xy[(size_t)b * V * NKP * 2 + i];
-    for (int i = tid; i < V * NKP; i += STEP_NT) L.wc[i] = Q.w_conf[(size_t)b * V * NKP + i];
+// Kernel prologue: the LDS image blocks as 16-byte-word copies, all loads of a thread in flight before
+// the first wait.  Null pointers skip a block; x_g (flat parameters, DV floats) fills L.opt.x.
+__device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const ObsBlock* obs_g, const PoseBlock* pose_g,
+                                         const OptBlock* opt_g, const float* vposed_g, const float* xs_g,
+                                         const float* x_g, int tid) {
+    constexpr int n16 = sizeof(ModelLds) / 16;
+    constexpr int nobs = sizeof(ObsBlock) / 16, npose = sizeof(PoseBlock) / 16, nopt = sizeof(OptBlock) / 16;
+    static_assert(n16 <= 3 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
+    const int4* src = reinterpret_cast<const int4*>(M.mlds);
+    const int4 zi = make_int4(0, 0, 0, 0);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (clamped indices instead of predicated loads: the surplus words are simply not stored)
+    const int4 m0 = src[min(tid, n16 - 1)];
+    const int4 m1 = src[min(tid + STEP_NT, n16 - 1)];
+    const int4 m2 = src[min(tid + 2 * STEP_NT, n16 - 1)];
+    (void)zi;
+    const float4 vobs = (obs_g && tid < nobs) ? reinterpret_cast<const float4*>(obs_g)[tid] : z;
+    const float4 vpose = (pose_g && tid < npose) ? reinterpret_cast<const float4*>(pose_g)[tid] : z;
+    const float4 vopt = (opt_g && tid < nopt) ? reinterpret_cast<const float4*>(opt_g)[tid] : z;
+    const float4 vvps = (vposed_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(vposed_g)[tid] : z;
+    const float4 vxss = (xs_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(xs_g)[tid] : z;
+    const float xv = (x_g && tid < DV) ? x_g[tid] : 0.f;
+    int4* dst = reinterpret_cast<int4*>(&L.M);
+    if (tid < n16) dst[tid] = m0;
+    if (tid + STEP_NT < n16) dst[tid + STEP_NT] = m1;
+    if (tid + 2 * STEP_NT < n16) dst[tid + 2 * STEP_NT] = m2;
+    if (obs_g && tid < nobs) reinterpret_cast<float4*>(&L.obs)[tid] = vobs;
+    if (pose_g) { if (tid < npose) reinterpret_cast<float4*>(&L.pose)[tid] = vpose; }
+    else if (tid >= 256 && tid < 256 + 8 * 12) (&L.pose.Mj[NJ][0])[tid - 256] = 0.f;     // "no child" rows
+    if (opt_g && tid < nopt) reinterpret_cast<float4*>(&L.opt)[tid] = vopt;
+    if (vposed_g && tid < NC_MAX / 4) { reinterpret_cast<float4*>(L.vposed)[tid] = vvps; reinterpret_cast<float4*>(L.xs)[tid] = vxss; }
+    if (x_g && tid < DPAD) L.opt.x[tid] = xv;
+    if (tid >= 384 && tid < 384 + 8 * 12) (&L.gG[NJ][0])[tid - 384] = 0.f;               // "no child" rows
 }
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {   // c = a b
@@ -154,8 +179,8 @@ __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 v = w[i];
-            s = fmaf(v.x, L.x[X_EMB + 4 * i], s); s = fmaf(v.y, L.x[X_EMB + 4 * i + 1], s);
-            s = fmaf(v.z, L.x[X_EMB + 4 * i + 2], s); s = fmaf(v.w, L.x[X_EMB + 4 * i + 3], s);
+            s = fmaf(v.x, L.opt.x[X_EMB + 4 * i], s); s = fmaf(v.y, L.opt.x[X_EMB + 4 * i + 1], s);
+            s = fmaf(v.z, L.opt.x[X_EMB + 4 * i + 2], s); s = fmaf(v.w, L.opt.x[X_EMB + 4 * i + 3], s);
         }
         L.vp_pre1[o] = s;
         L.vp_h[o] = s > 0.f ? s : 0.2f * s;
@@ -224,9 +249,9 @@ __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
         float s = sqrtf(s2), c = qn[0];
         float tt = 2.0f * (c < 0.f ? atan2f(-s, -c) : atan2f(s, c));
         float kk = s2 > 0.f ? tt / s : 2.0f;
-        L.theta[3 + 3 * j + 0] = qn[1] * kk;
-        L.theta[3 + 3 * j + 1] = qn[2] * kk;
-        L.theta[3 + 3 * j + 2] = qn[3] * kk;
+        L.pose.theta[3 + 3 * j + 0] = qn[1] * kk;
+        L.pose.theta[3 + 3 * j + 1] = qn[2] * kk;
+        L.pose.theta[3 + 3 * j + 2] = qn[3] * kk;
         // cache for the backward
         C[0] = n1; C[1] = b1[0]; C[2] = b1[1]; C[3] = b1[2]; C[4] = d; C[5] = n2;
         C[6] = b2[0]; C[7] = b2[1]; C[8] = b2[2]; C[9] = a2[0]; C[10] = a2[1]; C[11] = a2[2];
@@ -354,10 +379,10 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
 __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     if (flags & MVFIT_F_VPOSER) {
         vposer_forward(M, L, tid);
-        if (tid < 3) L.theta[tid] = L.x[X_GO + tid];
+        if (tid < 3) L.pose.theta[tid] = L.opt.x[X_GO + tid];
         __syncthreads();
     } else {
-        if (tid < 72) L.theta[tid] = L.x[X_GO + tid];      // global_orient | body_pose are contiguous in x
+        if (tid < 72) L.pose.theta[tid] = L.opt.x[X_GO + tid];      // global_orient | body_pose are contiguous in x
         __syncthreads();
     }
     if (tid < KROWS) {
@@ -367,13 +392,13 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
         if (p < 207) {
             const int j = 1 + p / 9, e = p % 9;
             float R[9], rod[3];
-            rodrigues(&L.theta[3 * j], R, rod);
+            rodrigues(&L.pose.theta[3 * j], R, rod);
             float sel = R[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
             v = sel - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
         } else if (p < 217) {
-            v = L.x[X_BETAS + p - 207];
+            v = L.opt.x[X_BETAS + p - 207];
         }
         L.coef[p] = v;
     } else {
@@ -382,28 +407,28 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
         const int j = i / 12, e = i - j * 12;
         if (e < 9) {
             float R[9], rod[3];
-            rodrigues(&L.theta[3 * j], R, rod);
+            rodrigues(&L.pose.theta[3 * j], R, rod);
             float sel = R[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
-            L.R[j][e] = sel;
-            L.Mj[j][4 * (e / 3) + (e % 3)] = (j == 0 ? L.x[X_SC] : 1.0f) * sel;
-            if (e < 3) L.rod[j][e] = rod[e];
+            L.pose.R[j][e] = sel;
+            L.pose.Mj[j][4 * (e / 3) + (e % 3)] = (j == 0 ? L.opt.x[X_SC] : 1.0f) * sel;
+            if (e < 3) L.pose.rod[j][e] = rod[e];
         } else {
             // J = J_t + J_S beta   (== J_regressor (v_template + shapedirs beta), lbs.py:179-183)
             const int a = e - 9;
             const int pa = L.M.parents[j];
             float s = L.M.J_t[3 * j + a];
 #pragma unroll
-            for (int l = 0; l < 10; ++l) s = fmaf(L.M.J_S[3 * j + a][l], L.x[X_BETAS + l], s);
+            for (int l = 0; l < 10; ++l) s = fmaf(L.M.J_S[3 * j + a][l], L.opt.x[X_BETAS + l], s);
             float sp = 0.f;
             if (j > 0) {
                 sp = L.M.J_t[3 * pa + a];
 #pragma unroll
-                for (int l = 0; l < 10; ++l) sp = fmaf(L.M.J_S[3 * pa + a][l], L.x[X_BETAS + l], sp);
+                for (int l = 0; l < 10; ++l) sp = fmaf(L.M.J_S[3 * pa + a][l], L.opt.x[X_BETAS + l], sp);
             }
-            L.J[j][a] = s;
-            L.Mj[j][4 * a + 3] = s - sp;
+            L.pose.J[j][a] = s;
+            L.pose.Mj[j][4 * a + 3] = s - sp;
         }
     }
     __syncthreads();
@@ -414,7 +439,7 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
 // column c); per pass one table word, one ds_read_b128 of the parent row and three FMAs, handed to
 // the next pass through LDS without s_barrier.
 __device__ void chain_forward_wave(ClosureLds& L, int lane) {
-    if (lane < 12) L.G[0][lane] = L.Mj[0][lane];
+    if (lane < 12) L.pose.G[0][lane] = L.pose.Mj[0][lane];
     const int q = lane / 12, e = lane - 12 * q, a = e >> 2, c = e & 3;
     const int npass = L.M.n_fwd;
     int w = (q < 5 && npass > 0) ? L.M.fwd_tab[0][q] : -1;
@@ -423,20 +448,20 @@ __device__ void chain_forward_wave(ClosureLds& L, int lane) {
         const int wn = (q < 5 && p + 1 < npass) ? L.M.fwd_tab[p + 1][q] : -1;    // next pass's word: off the critical path
         if (w >= 0) {
             const int j = w & 0xff, pa = w >> 8;
-            const float m0 = L.Mj[j][c], m1 = L.Mj[j][4 + c], m2 = L.Mj[j][8 + c];
-            const float4 g = *reinterpret_cast<const float4*>(&L.G[pa][4 * a]);
+            const float m0 = L.pose.Mj[j][c], m1 = L.pose.Mj[j][4 + c], m2 = L.pose.Mj[j][8 + c];
+            const float4 g = *reinterpret_cast<const float4*>(&L.pose.G[pa][4 * a]);
             float v = g.x * m0 + g.y * m1 + g.z * m2;
             if (c == 3) v += g.w;
-            L.G[j][e] = v;
+            L.pose.G[j][e] = v;
         }
         w = wn;
         wave_lds_fence();
     }
     for (int i = lane; i < NJ * 3; i += 64) {          // (joint, row a)
         const int j = i / 3, aa = i - 3 * j;
-        const float4 g = *reinterpret_cast<const float4*>(&L.G[j][4 * aa]);
-        const float t = g.w - (g.x * L.J[j][0] + g.y * L.J[j][1] + g.z * L.J[j][2]);
-        *reinterpret_cast<float4*>(&L.A[j][4 * aa]) = make_float4(g.x, g.y, g.z, t);
+        const float4 g = *reinterpret_cast<const float4*>(&L.pose.G[j][4 * aa]);
+        const float t = g.w - (g.x * L.pose.J[j][0] + g.y * L.pose.J[j][1] + g.z * L.pose.J[j][2]);
+        *reinterpret_cast<float4*>(&L.pose.A[j][4 * aa]) = make_float4(g.x, g.y, g.z, t);
     }
 }
 
@@ -476,16 +501,16 @@ __device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int
 }
 
 // E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
-// from_pass != nullptr: v_posed / xs of the selected vertices come from the vertex pass (full mode).
-__device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* vposed_pass, const float* xs_pass,
-                               int tid) {
+// from_pass: L.vposed / L.xs of the selected vertices were written by the kernel prologue from the
+// vertex pass's side outputs (full mode); run_chain = false when the pose block (G, A) is already in LDS.
+__device__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass, int tid, bool run_chain = true) {
     const int nc = L.M.nc, nc_pad = L.M.nc_pad;
     const int nks = fwd_slices(nc_pad, STEP_NT - 64);
-    if (tid < 64) { chain_forward_wave(L, tid); PH_T(22); }
-    else if (vposed_pass == nullptr) contraction_forward(M, L, tid - 64, STEP_NT - 64);
-    float vp_in = 0.f, xs_in = 0.f;
-    if (vposed_pass != nullptr && tid < nc) { vp_in = vposed_pass[tid]; xs_in = xs_pass[tid]; }
-    __syncthreads();
+    if (run_chain || !from_pass) {
+        if (tid < 64) { if (run_chain) chain_forward_wave(L, tid); PH_T(22); }
+        else if (!from_pass) contraction_forward(M, L, tid - 64, STEP_NT - 64);
+        __syncthreads();
+    }
     PH_T(1);
     // thread per coordinate c = 3 s + a: T row a of vertex s, v_posed[c], xs[c]
     if (tid < nc) {
@@ -494,15 +519,12 @@ __device__ void sparse_forward(const DevModel& M, ClosureLds& L, const float* vp
 #pragma unroll 8
         for (int j = 0; j < NJ; ++j) {
             const float w = L.M.wT[j][s];
-            const float4 av = *reinterpret_cast<const float4*>(&L.A[j][4 * a]);
+            const float4 av = *reinterpret_cast<const float4*>(&L.pose.A[j][4 * a]);
             tr.x = fmaf(w, av.x, tr.x); tr.y = fmaf(w, av.y, tr.y);
             tr.z = fmaf(w, av.z, tr.z); tr.w = fmaf(w, av.w, tr.w);
         }
         *reinterpret_cast<float4*>(&L.T[s][4 * a]) = tr;
-        if (vposed_pass != nullptr) {
-            L.vposed[c] = vp_in;
-            L.xs[c] = xs_in;
-        } else {
+        if (!from_pass) {
             float vp[3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
@@ -539,18 +561,18 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
             const float w = L.M.kp_w[t];
             X = fmaf(w, L.xs[3 * s], X); Y = fmaf(w, L.xs[3 * s + 1], Y); Z = fmaf(w, L.xs[3 * s + 2], Z);
         }
-        X += L.x[X_TR]; Y += L.x[X_TR + 1]; Z += L.x[X_TR + 2];
+        X += L.opt.x[X_TR]; Y += L.opt.x[X_TR + 1]; Z += L.opt.x[X_TR + 2];
         if (v == 0) { L.kp[k][0] = X; L.kp[k][1] = Y; L.kp[k][2] = Z; }
-        const float* Rc = L.camR[v];
-        const float* tc = L.camt[v];
-        const float f = L.camf[v];
-        const float cx = L.camc[v][0], cy = L.camc[v][1];
+        const float* Rc = L.obs.camR[v];
+        const float* tc = L.obs.camt[v];
+        const float f = L.obs.camf[v];
+        const float cx = L.obs.camc[v][0], cy = L.obs.camc[v][1];
         const float px = Rc[0] * X + Rc[1] * Y + Rc[2] * Z + tc[0];            // camera.py:106-110
         const float py = Rc[3] * X + Rc[4] * Y + Rc[5] * Z + tc[1];
         const float pz = Rc[6] * X + Rc[7] * Y + Rc[8] * Z + tc[2];
         const float u = f * (px / pz) + cx, w_ = f * (py / pz) + cy;            // camera.py:112-116
-        const float rx = L.gt[tid * 2] - u, ry = L.gt[tid * 2 + 1] - w_;
-        const float wcf = L.wc[tid];
+        const float rx = L.obs.gt[tid * 2] - u, ry = L.obs.gt[tid * 2 + 1] - w_;
+        const float wcf = L.obs.wc[tid];
         const float w2 = wcf * wcf;
         const float rx2 = rx * rx, ry2 = ry * ry;
         const float gmx = W.rho2 * (rx2 / (rx2 + W.rho2)), gmy = W.rho2 * (ry2 / (ry2 + W.rho2));   // utils.py:435-438
@@ -579,17 +601,17 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
         // priors on the last wave: |body_pose|^2 or |z|^2, |beta|^2, angle prior
         const int lane = tid & 63;
         double pp = 0.0, bb = 0.0, an = 0.0;
-        if (use_vp) { if (lane < 32) { const double v = (double)L.x[X_EMB + lane]; pp = v * v; } }
+        if (use_vp) { if (lane < 32) { const double v = (double)L.opt.x[X_EMB + lane]; pp = v * v; } }
         else {
-            { const double v = (double)L.theta[3 + lane]; pp = v * v; }
-            if (lane < 5) { const double v = (double)L.theta[3 + 64 + lane]; pp += v * v; }
+            { const double v = (double)L.pose.theta[3 + lane]; pp = v * v; }
+            if (lane < 5) { const double v = (double)L.pose.theta[3 + 64 + lane]; pp += v * v; }
         }
-        if (lane < 10) { const double v = (double)L.x[X_BETAS + lane]; bb = v * v; }
+        if (lane < 10) { const double v = (double)L.opt.x[X_BETAS + lane]; bb = v * v; }
         if (lane < 4) {
             // angle prior (prior.py:73-89): exp(pose[idx]*sgn)^2 on full_pose[3:66] idx 52,55,9,12
             const int idx = lane == 0 ? 52 : lane == 1 ? 55 : lane == 2 ? 9 : 12;
             const float sg = lane == 0 ? 1.f : -1.f;
-            const float e0 = expf(sg * L.theta[3 + idx]);
+            const float e0 = expf(sg * L.pose.theta[3 + idx]);
             an = (double)(e0 * e0);
         }
         const double spp = wave64_sum(pp), sbb = wave64_sum(bb), san = wave64_sum(an);
@@ -606,7 +628,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
             const float* prow = M.gmm_prec + ((size_t)m * 69 + r) * 72;
             const float* mu = M.gmm_means + m * 69;
             float s = 0.f;
-            for (int c = l16; c < 69; c += 16) s = fmaf(prow[c], L.theta[3 + c] - mu[c], s);
+            for (int c = l16; c < 69; c += 16) s = fmaf(prow[c], L.pose.theta[3 + c] - mu[c], s);
             s = row16_sum(s);
             if (l16 == 0) L.gmm_t[m][r] = s;
         }
@@ -615,7 +637,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
             const int m = tid >> 4;
             const float* mu = M.gmm_means + m * 69;
             float qd = 0.f;
-            for (int r = l16; r < 69; r += 16) qd = fmaf(L.gmm_t[m][r], L.theta[3 + r] - mu[r], qd);
+            for (int r = l16; r < 69; r += 16) qd = fmaf(L.gmm_t[m][r], L.pose.theta[3 + r] - mu[r], qd);
             qd = row16_sum(qd);
             if (l16 == 0) L.gmm_ll[m] = 0.5f * qd - M.gmm_lognw[m];
         }
@@ -677,9 +699,9 @@ __device__ void chain_backward_wave(ClosureLds& L, int lane) {
         if (w != -1) {
             const int p = w & 0xff, c0 = (w >> 8) & 0xff, c1 = (w >> 16) & 0xff, c2 = (w >> 24) & 0xff;
             // child rows 24..31 are zero: absent children contribute nothing
-            const float4 k0 = *reinterpret_cast<const float4*>(&L.Mj[c0][4 * (m < 3 ? m : 0)]);
-            const float4 k1 = *reinterpret_cast<const float4*>(&L.Mj[c1][4 * (m < 3 ? m : 0)]);
-            const float4 k2 = *reinterpret_cast<const float4*>(&L.Mj[c2][4 * (m < 3 ? m : 0)]);
+            const float4 k0 = *reinterpret_cast<const float4*>(&L.pose.Mj[c0][4 * (m < 3 ? m : 0)]);
+            const float4 k1 = *reinterpret_cast<const float4*>(&L.pose.Mj[c1][4 * (m < 3 ? m : 0)]);
+            const float4 k2 = *reinterpret_cast<const float4*>(&L.pose.Mj[c2][4 * (m < 3 ? m : 0)]);
             const float4 g0 = *reinterpret_cast<const float4*>(&L.gG[c0][4 * a]);
             const float4 g1 = *reinterpret_cast<const float4*>(&L.gG[c1][4 * a]);
             const float4 g2 = *reinterpret_cast<const float4*>(&L.gG[c2][4 * a]);
@@ -778,13 +800,13 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         for (int e = 0; e < 12; ++e) acc[e] = row16_sum(acc[e]);
         if (g == 0) {
             // A_j = [Gr_j | Gt_j - Gr_j J_j]:  g_Gt = g_At ; g_Gr = g_Ar - g_At J^T ; g_J = -Gr^T g_At
-            const float J0 = L.J[j][0], J1 = L.J[j][1], J2 = L.J[j][2];
+            const float J0 = L.pose.J[j][0], J1 = L.pose.J[j][1], J2 = L.pose.J[j][2];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 *reinterpret_cast<float4*>(&L.gG[j][4 * a]) =
                     make_float4(acc[3 * a + 0] - acc[9 + a] * J0, acc[3 * a + 1] - acc[9 + a] * J1,
                                 acc[3 * a + 2] - acc[9 + a] * J2, acc[9 + a]);
-                L.gJ[j][a] = -(L.G[j][0 + a] * acc[9] + L.G[j][4 + a] * acc[10] + L.G[j][8 + a] * acc[11]);
+                L.gJ[j][a] = -(L.pose.G[j][0 + a] * acc[9] + L.pose.G[j][4 + a] * acc[10] + L.pose.G[j][8 + a] * acc[11]);
             }
         }
     }
@@ -803,12 +825,12 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         if (j == 0) v = L.gG[0][e];
         else {
             const int pa = L.M.parents[j];
-            v = L.G[pa][mm] * L.gG[j][c] + L.G[pa][4 + mm] * L.gG[j][4 + c] + L.G[pa][8 + mm] * L.gG[j][8 + c];
+            v = L.pose.G[pa][mm] * L.gG[j][c] + L.pose.G[pa][4 + mm] * L.gG[j][4 + c] + L.pose.G[pa][8 + mm] * L.gG[j][8 + c];
         }
         L.gM[j][e] = v;
         if (c < 3) {
             float gr;
-            if (j == 0) gr = L.x[X_SC] * v;
+            if (j == 0) gr = L.opt.x[X_SC] * v;
             else {
                 float gc = 0.f;
                 for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + 3 * mm + c];
@@ -825,7 +847,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
             const float* mu = M.gmm_means + m * 69;
             const float* PT = M.gmm_precT + ((size_t)m * 69 + i) * 72;
             float s = 0.f;
-            for (int r = l16; r < 69; r += 16) s = fmaf(PT[r], L.theta[3 + r] - mu[r], s);
+            for (int r = l16; r < 69; r += 16) s = fmaf(PT[r], L.pose.theta[3 + r] - mu[r], s);
             s = row16_sum(s);
             if (l16 == 0) L.gmm_d[i] = 0.5f * (L.gmm_t[m][i] + s);
         }
@@ -849,18 +871,18 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
             float gc = 0.f;
             for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
             s += gc;
-            if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.x[X_BETAS + l] * W.shape_w * W.shape_w;
+            if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
         }
     } else if (tid == 448) {
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) s += L.gM[0][4 * (e / 3) + (e % 3)] * L.R[0][e];
+        for (int e = 0; e < 9; ++e) s += L.gM[0][4 * (e / 3) + (e % 3)] * L.pose.R[0][e];
         L.gscale = s;
     } else if (tid < NJ) {
-        const float rx = L.theta[3 * tid], ry = L.theta[3 * tid + 1], rz = L.theta[3 * tid + 2];
+        const float rx = L.pose.theta[3 * tid], ry = L.pose.theta[3 * tid + 1], rz = L.pose.theta[3 * tid + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
-        const float a = L.rod[tid][0], sn = L.rod[tid][1], cs = L.rod[tid][2];
+        const float a = L.pose.rod[tid][0], sn = L.pose.rod[tid][1], cs = L.pose.rod[tid][2];
         const float kx = rx / a, ky = ry / a, kz = rz / a;
         const float oc = 1.f - cs;
         const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
@@ -892,7 +914,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int i = 3 * (tid - 1) + q;               // body_pose index
-                const float bp = L.theta[3 + i];
+                const float bp = L.pose.theta[3 + i];
                 float gq = gth[q];
                 if (W.flags & MVFIT_F_PRIOR_GMM) { if (!(L.flags_dropped & 1)) gq += L.gmm_d[i] * wp2; }
                 else if (!(L.flags_dropped & 1)) gq += 2.f * bp * wp2;
@@ -907,7 +929,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
                 const int i = 3 * (tid - 1) + q;
                 if (i == 52 || i == 55 || i == 9 || i == 12) {
                     const float sg = (i == 52) ? 1.f : -1.f;
-                    gth[q] += 2.f * expf(2.f * L.theta[3 + i] * sg) * sg * W.bend_w;
+                    gth[q] += 2.f * expf(2.f * L.pose.theta[3 + i] * sg) * sg * W.bend_w;
                 }
             }
         }
@@ -923,7 +945,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         else if (i < X_TR) g = use_vp ? 0.f : L.gtheta[3 + i - X_BP];
         else if (i < X_SC) g = L.gtau[i - X_TR];
         else if (i == X_SC) g = (W.flags & MVFIT_F_FIX_SCALE) ? 0.f : L.gscale;
-        else if (i < DV) g = use_vp ? 2.f * L.x[i] * wp2 : 0.f;              // fitting.py:328 (d/dz |z|^2 w^2)
+        else if (i < DV) g = use_vp ? 2.f * L.opt.x[i] * wp2 : 0.f;              // fitting.py:328 (d/dz |z|^2 w^2)
         L.grad[i] = g;
     }
     __syncthreads();
@@ -934,8 +956,8 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
 __device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid) {
     float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
     for (int p = tid; p < KROWS; p += STEP_NT) ct[p * 32] = L.coef[p];
-    for (int i = tid; i < NJ * 12; i += STEP_NT) P.Amat[(size_t)b * 288 + i] = (&L.A[0][0])[i];
-    if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.x[X_TR + tid];
+    for (int i = tid; i < NJ * 12; i += STEP_NT) P.Amat[(size_t)b * 288 + i] = (&L.pose.A[0][0])[i];
+    if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.opt.x[X_TR + tid];
 }
 
 }  // namespace mvfit

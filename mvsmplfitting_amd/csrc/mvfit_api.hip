@@ -30,12 +30,10 @@ struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
 
 // per-problem optimiser storage in HBM
 struct FitBuffers {
-    LbState* S;          // [B]
-    float* vecs;         // [B][LB_NVEC][LB_D]: x d g pg gprev bg0 bg1 (compact order)
-    float* xt;           // [B][DPAD]: current trial point, flat parameter layout
+    OptBlock* opt;       // [B] trial point + L-BFGS scalars / working vectors / ro (LDS image block)
+    PoseBlock* pose;     // [B] pose state of the current trial point (handed from launch to launch)
     float* dirs;         // [B][100][LB_D]
     float* stps;         // [B][100][LB_D]
-    float* ro;           // [B][100]
     float* grow;         // [B][LB_GSIZE] pre-scaled Gram matrices (lbfgs_device.h:LbHist)
     float* gcol;         // [B][LB_GSIZE]
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
@@ -49,10 +47,6 @@ __device__ __forceinline__ int cmap(int i, bool use_vp) {
 }
 __device__ __forceinline__ int dact(bool use_vp) { return use_vp ? 49 : 86; }
 
-__device__ __forceinline__ void load_x(ClosureLds& L, const float* src, int tid) {
-    if (tid < DPAD) L.x[tid] = (tid < DV) ? src[tid] : 0.f;
-}
-
 // pose operands of the vertex pass only: E1 + chain
 __device__ __forceinline__ void pose_and_chain(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     pose_prep(M, L, flags, tid);
@@ -60,38 +54,55 @@ __device__ __forceinline__ void pose_and_chain(const DevModel& M, ClosureLds& L,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, DevProblems Q, DevPose P,
+__device__ __forceinline__ void store_block16(void* dst_g, const void* src_l, int nbytes, int tid) {
+    const int n = nbytes / 16;
+    for (int i = tid; i < n; i += STEP_NT) reinterpret_cast<float4*>(dst_g)[i] = reinterpret_cast<const float4*>(src_l)[i];
+}
+
+// per-problem observations -> ObsBlock image (one launch per mvfit_set_problems)
+__global__ void pack_obs_kernel(DevProblems Q, ObsBlock* __restrict__ obs) {
+    const int b = blockIdx.x, V = Q.V;
+    const size_t cb = Q.cam_batched ? (size_t)b * V : 0;
+    ObsBlock& O = obs[b];
+    for (int i = threadIdx.x; i < (int)(sizeof(ObsBlock) / 4); i += blockDim.x) reinterpret_cast<float*>(&O)[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * 9; i += blockDim.x) (&O.camR[0][0])[i] = Q.cam_R[cb * 9 + i];
+    for (int i = threadIdx.x; i < V * 3; i += blockDim.x) (&O.camt[0][0])[i] = Q.cam_t[cb * 3 + i];
+    for (int i = threadIdx.x; i < V; i += blockDim.x) O.camf[i] = Q.cam_f[cb + i];
+    for (int i = threadIdx.x; i < V * 2; i += blockDim.x) (&O.camc[0][0])[i] = Q.cam_c[cb * 2 + i];
+    for (int i = threadIdx.x; i < V * NKP * 2; i += blockDim.x) O.gt[i] = Q.gt_xy[(size_t)b * V * NKP * 2 + i];
+    for (int i = threadIdx.x; i < V * NKP; i += blockDim.x) O.wc[i] = Q.w_conf[(size_t)b * V * NKP + i];
+}
+
+__global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBlock* __restrict__ obs, DevPose P,
                                                        const float* __restrict__ params, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    lds_load_constants(L, M, Q, b, tid);
-    load_x(L, params + (size_t)b * DV, tid);
+    prologue(L, M, obs + b, nullptr, nullptr, nullptr, nullptr, params + (size_t)b * DV, tid);
     __syncthreads();
     pose_and_chain(M, L, flags, tid);
     publish_pose(L, P, b, tid);
 }
 
-__global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, DevProblems Q, DevWeights W, DevPose P,
-                                                          const float* __restrict__ params, int from_pass,
-                                                          float* __restrict__ loss, float* __restrict__ grad,
-                                                          float* __restrict__ joints) {
+__global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
+                                                          DevWeights W, DevPose P, const float* __restrict__ params,
+                                                          int from_pass, float* __restrict__ loss,
+                                                          float* __restrict__ grad, float* __restrict__ joints) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    lds_load_constants(L, M, Q, b, tid);
-    load_x(L, params + (size_t)b * DV, tid);
+    prologue(L, M, obs + b, nullptr, nullptr, from_pass ? P.vposed_sel + (size_t)b * NC_MAX : nullptr,
+             from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr, params + (size_t)b * DV, tid);
     __syncthreads();
     pose_prep(M, L, W.flags, tid);
-    const float* vpp = from_pass ? P.vposed_sel + (size_t)b * NC_MAX : nullptr;
-    const float* xsp = from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr;
-    sparse_forward(M, L, vpp, xsp, tid);
+    sparse_forward(M, L, from_pass != 0, tid);
     const bool want_grad = grad != nullptr;
-    const double total = loss_and_keypoint_grad(M, L, Q.V, W, want_grad, tid);
+    const double total = loss_and_keypoint_grad(M, L, nviews, W, want_grad, tid);
     if (tid == 0 && loss) loss[b] = (float)total;
     if (joints && tid < NKP * 3) joints[(size_t)b * NKP * 3 + tid] = (&L.kp[0][0])[tid];
     if (want_grad) {
-        closure_backward(M, L, Q.V, W, tid);
+        closure_backward(M, L, nviews, W, tid);
         if (tid < DV) grad[(size_t)b * DV + tid] = L.grad[tid];
     }
 }
@@ -132,74 +143,53 @@ __device__ __forceinline__ void lb_store(const LbVecs<float>& V, float* base, in
         }
     }
 }
-// optimiser state global <-> LDS (all threads; followed by a barrier at the call site)
-__device__ __forceinline__ void lb_state_in(ClosureLds& L, const FitBuffers& F, int b, int tid) {
-    const float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
-    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) (&L.lbV[0][0])[i] = vb[i];
-    constexpr int nw = sizeof(LbState) / 4;
-    const int* src = reinterpret_cast<const int*>(F.S + b);
-    if (tid < nw) reinterpret_cast<int*>(&L.lbS)[tid] = src[tid];
-    if (tid >= 64 && tid < 64 + LB_HIST) L.lb_ro[tid - 64] = F.ro[(size_t)b * LB_HIST + tid - 64];
-    if (tid == 0) { L.sh_stage = F.S[b].stage; L.sh_status = 0; }
-}
 __device__ __forceinline__ void opts_in(ClosureLds& L, const StageWeights& SW, const LbOpts& O, int tid) {
     constexpr int nsw = sizeof(StageWeights) / 4, nop = sizeof(LbOpts) / 4;
     if (tid < nsw) reinterpret_cast<int*>(&L.sw[0])[tid] = reinterpret_cast<const int*>(&SW)[tid];
     if (tid >= 128 && tid < 128 + nop) reinterpret_cast<int*>(&L.opts)[tid - 128] = reinterpret_cast<const int*>(&O)[tid - 128];
 }
-__device__ __forceinline__ void lb_state_out(const ClosureLds& L, const FitBuffers& F, int b, int tid) {
-    float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
-    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) vb[i] = (&L.lbV[0][0])[i];
-    constexpr int nw = sizeof(LbState) / 4;
-    int* dst = reinterpret_cast<int*>(F.S + b);
-    if (tid < nw) dst[tid] = reinterpret_cast<const int*>(&L.lbS)[tid];
-    if (tid >= 64 && tid < 64 + LB_HIST) F.ro[(size_t)b * LB_HIST + tid - 64] = L.lb_ro[tid - 64];
-    if (tid < DPAD) F.xt[(size_t)b * DPAD + tid] = L.x[tid];
-}
 
 // initialise the optimiser state of every problem: x = params, first trial point = x
-__global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, DevProblems Q, DevPose P, FitBuffers F,
-                                                           const float* __restrict__ params, uint32_t flags,
-                                                           int publish) {
+__global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const ObsBlock* __restrict__ obs, DevPose P,
+                                                           FitBuffers F, const float* __restrict__ params,
+                                                           uint32_t flags, int publish) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     const bool use_vp = (flags & MVFIT_F_VPOSER) != 0;
-    float* vb = F.vecs + (size_t)b * LB_NVEC * LB_D;
-    for (int i = tid; i < LB_NVEC * LB_D; i += STEP_NT) {
-        const int r = i / LB_D, e = i - r * LB_D;
-        vb[i] = (r == 0 && e < dact(use_vp)) ? params[(size_t)b * DV + cmap(e, use_vp)] : 0.f;
-    }
-    if (tid < DPAD) F.xt[(size_t)b * DPAD + tid] = tid < DV ? params[(size_t)b * DV + tid] : 0.f;
-    if (tid == 0) {
-        LbState s;
-        memset(&s, 0, sizeof(s));
-        s.phase = PH_STEP_START;
-        s.H = 1.0;
-        F.S[b] = s;
-    }
+    const float xv = (tid < DV) ? params[(size_t)b * DV + tid] : 0.f;
+    const float xc = (tid < dact(use_vp)) ? params[(size_t)b * DV + cmap(tid, use_vp)] : 0.f;
+    prologue(L, M, obs + b, nullptr, nullptr, nullptr, nullptr, nullptr, tid);
+    for (int i = tid; i < (int)(sizeof(OptBlock) / 4); i += STEP_NT) reinterpret_cast<float*>(&L.opt)[i] = 0.f;
+    __syncthreads();
+    if (tid < DPAD) L.opt.x[tid] = xv;
+    if (tid < LB_D) L.opt.lbV[0][tid] = xc;
+    if (tid == 0) { L.opt.lbS.phase = PH_STEP_START; L.opt.lbS.H = 1.0; }
     if (tid < MVFIT_MAX_STAGES) F.stage_final[(size_t)b * MVFIT_MAX_STAGES + tid] = (double)NAN;
+    __syncthreads();
+    store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (publish) {
-        lds_load_constants(L, M, Q, b, tid);
-        load_x(L, params + (size_t)b * DV, tid);
-        __syncthreads();
         pose_and_chain(M, L, flags, tid);
         publish_pose(L, P, b, tid);
+        store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
     }
 }
 
-// shared by the two fit kernels: evaluate the closure at L.x, advance the optimiser, leave the
-// next trial point in L.x.  Returns true when the problem is finished.
+// shared by the two fit kernels: evaluate the closure at L.opt.x, advance the optimiser, leave the
+// next trial point in L.opt.x.  Returns true when the problem is finished.
 __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
-                          const float* vposed_pass, const float* xs_pass, double* stage_final, int tid) {
+                          bool from_pass, bool have_pose, double* stage_final, int tid) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     PH_T0();
-    pose_prep(M, L, W.flags, tid);
+    // have_pose: the previous launch left the pose block of this x (not the VPoser activations, which
+    // the adjoint needs: with VPoser the decoder is re-run)
+    have_pose = have_pose && !use_vp;
+    if (!have_pose) pose_prep(M, L, W.flags, tid);
     PH_T(0);
-    sparse_forward(M, L, vposed_pass, xs_pass, tid);
+    sparse_forward(M, L, from_pass, tid, !have_pose);
     PH_T(2);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     PH_T(3);
@@ -209,8 +199,8 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     LbVecs<float> V;
     const int D = dact(use_vp);
     if (tid < 64) {
-        S = L.lbS;
-        lb_load(V, &L.lbV[0][0], tid);
+        S = L.opt.lbS;
+        lb_load(V, &L.opt.lbV[0][0], tid);
         PH_T(9);
         float gnew[LB_EPL], xt[LB_EPL];
 #pragma unroll
@@ -225,7 +215,7 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
 #pragma unroll
             for (int e = 0; e < LB_EPL; ++e) {
                 const int i = LB_EPL * tid + e;
-                if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+                if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
             }
         }
     }
@@ -242,13 +232,13 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
 #pragma unroll
             for (int e = 0; e < LB_EPL; ++e) {
                 const int i = LB_EPL * tid + e;
-                if (i < D) L.x[cmap(i, use_vp)] = xt[e];
+                if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
             }
         }
     }
     if (tid < 64) {
-        lb_store(V, &L.lbV[0][0], tid);
-        if (tid == 0) { L.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
+        lb_store(V, &L.opt.lbV[0][0], tid);
+        if (tid == 0) { L.opt.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
         PH_ADD(13, 1); PH_ADD(14, S.hist_len);
     }
     __syncthreads();
@@ -258,47 +248,48 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
 
 // one closure round per launch (full mode): the objective reads the vertex pass's output for its
 // vertices; afterwards the pose operands of the NEXT trial point are published for the next pass.
-__global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
-                                                           DevPose P, FitBuffers F) {
+__global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
+                                                           StageWeights SW, LbOpts O, DevPose P, FitBuffers F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (F.S[b].status != 0) return;                       // uniform per block
-    lds_load_constants(L, M, Q, b, tid);
-    load_x(L, F.xt + (size_t)b * DPAD, tid);
-    lb_state_in(L, F, b, tid);
+    prologue(L, M, obs + b, F.pose + b, F.opt + b, P.vposed_sel + (size_t)b * NC_MAX, P.xs_sel + (size_t)b * NC_MAX, nullptr, tid);
     opts_in(L, SW, O, tid);
-    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.lb_ro,
+    __syncthreads();
+    if (L.opt.lbS.status != 0) return;                    // uniform per block
+    if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
+    LbHist<float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.opt.lb_ro,
                     F.grow + (size_t)b * LB_GSIZE, F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
-    const bool done = fit_round(M, L, Q.V, H, P.vposed_sel + (size_t)b * NC_MAX,
-                                P.xs_sel + (size_t)b * NC_MAX, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
-    lb_state_out(L, F, b, tid);
+    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
+    store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
     // pose operands of the next trial point (also after the last round: final vertices)
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
+    store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
 }
 
 // the whole fit of one problem in a single launch (objective-vertices-only closure): the L-BFGS
 // history ring lives in LDS behind the closure workspace.
-__global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, DevProblems Q, StageWeights SW, LbOpts O,
-                                                                 DevPose P, FitBuffers F, int max_rounds) {
+__global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
+                                                                 StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
+                                                                 int max_rounds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (F.S[b].status != 0) return;
-    lds_load_constants(L, M, Q, b, tid);
-    load_x(L, F.xt + (size_t)b * DPAD, tid);
-    lb_state_in(L, F, b, tid);
+    prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid);
     opts_in(L, SW, O, tid);
+    __syncthreads();
+    if (L.opt.lbS.status != 0) return;
+    if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
     float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
     float* gs = F.stps + (size_t)b * LB_HIST * LB_D;
-    const bool resume = F.S[b].n_closure > 0;             // relaunch after a round cap: restore the ring
+    const bool resume = L.opt.lbS.n_closure > 0;          // relaunch after a round cap: restore the ring
     if (resume)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { hist[i] = gd[i]; hist[LB_HIST * LB_D + i] = gs[i]; }
-    LbHist<float> H{hist, hist + LB_HIST * LB_D, L.lb_ro, F.grow + (size_t)b * LB_GSIZE,
+    LbHist<float> H{hist, hist + LB_HIST * LB_D, L.opt.lb_ro, F.grow + (size_t)b * LB_GSIZE,
                     F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
     bool done = false;
@@ -307,10 +298,10 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, Dev
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round(M, L, Q.V, H, nullptr, nullptr, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t);
+        done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t);
         if (done) break;                                  // block-uniform
     }
-    lb_state_out(L, F, b, tid);
+    store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
     if (!done)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
@@ -322,9 +313,9 @@ __global__ void fit_finish_kernel(FitBuffers F, float* __restrict__ params, floa
                                   int32_t* __restrict__ n_closure, int32_t* __restrict__ n_iter, int B,
                                   int num_stages) {
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < DV; i += blockDim.x) params[(size_t)b * DV + i] = F.xt[(size_t)b * DPAD + i];
+    for (int i = threadIdx.x; i < DV; i += blockDim.x) params[(size_t)b * DV + i] = F.opt[b].x[i];
     if (threadIdx.x == 0) {
-        const LbState& s = F.S[b];
+        const LbState& s = F.opt[b].lbS;
         if (final_loss) final_loss[b] = (float)F.stage_final[(size_t)b * MVFIT_MAX_STAGES + num_stages - 1];
         if (n_closure) n_closure[b] = s.n_closure;
         if (n_iter) n_iter[b] = s.n_lbfgs;
@@ -435,6 +426,7 @@ struct mvfit_ctx {
     DevProblems Q{};
     int B = 0, Bpad = 0, V = 0;
     float *d_camR = nullptr, *d_camt = nullptr, *d_camf = nullptr, *d_camc = nullptr, *d_gt = nullptr, *d_wc = nullptr;
+    ObsBlock* d_obs = nullptr;         // [B] packed observations (LDS image block)
     // per-problem work buffers
     DevPose P{};
     float* d_verts = nullptr;          // [B][nv][3] internal vertex buffer
@@ -753,10 +745,11 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
 static void free_problem_buffers(mvfit_ctx* c) {
     drop_graph(c);
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
-                  c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->F.S, c->F.vecs, c->F.xt, c->F.dirs, c->F.stps, c->F.ro,
+                  c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done};
     for (void* p : ps) if (p) hipFree(p);
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
+    c->d_obs = nullptr;
     c->P = DevPose{};
     c->d_verts = nullptr;
     c->F = FitBuffers{};
@@ -800,13 +793,11 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->P.xs_sel, (size_t)Bpad * NC_MAX * 4));
         HIP_OK(c, hipMemset(c->P.coefT, 0, (size_t)Bpad * KROWS * 4));
         HIP_OK(c, hipMalloc(&c->d_verts, (size_t)B * c->nv * 3 * 4));
-        HIP_OK(c, hipMalloc(&c->F.S, (size_t)B * sizeof(LbState)));
-        HIP_OK(c, hipMalloc(&c->F.vecs, (size_t)B * LB_NVEC * LB_D * 4));
-        HIP_OK(c, hipMalloc(&c->F.xt, (size_t)B * DPAD * 4));
+        HIP_OK(c, hipMalloc(&c->d_obs, (size_t)B * sizeof(ObsBlock)));
+        HIP_OK(c, hipMalloc(&c->F.opt, (size_t)B * sizeof(OptBlock)));
+        HIP_OK(c, hipMalloc(&c->F.pose, (size_t)B * sizeof(PoseBlock)));
         HIP_OK(c, hipMalloc(&c->F.dirs, (size_t)B * LB_HIST * LB_D * 4));
         HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * LB_D * 4));
-        HIP_OK(c, hipMalloc(&c->F.ro, (size_t)B * LB_HIST * 4));
-        HIP_OK(c, hipMemset(c->F.ro, 0, (size_t)B * LB_HIST * 4));
         HIP_OK(c, hipMalloc(&c->F.grow, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.gcol, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMemset(c->F.grow, 0, (size_t)B * LB_GSIZE * 4));
@@ -822,8 +813,10 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
     HIP_OK(c, hipMemcpyAsync(c->d_camc, cam_c, nc * 2 * 4, hipMemcpyDefault, c->stream));
     HIP_OK(c, hipMemcpyAsync(c->d_gt, gt_xy, (size_t)B * V * NKP * 2 * 4, hipMemcpyDefault, c->stream));
     HIP_OK(c, hipMemcpyAsync(c->d_wc, w_conf, (size_t)B * V * NKP * 4, hipMemcpyDefault, c->stream));
-    HIP_OK(c, hipStreamSynchronize(c->stream));
     c->Q = DevProblems{B, V, cam_batched ? 1 : 0, c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc};
+    hipLaunchKernelGGL(pack_obs_kernel, dim3(B), dim3(256), 0, c->stream, c->Q, c->d_obs);
+    HIP_OK(c, hipGetLastError());
+    HIP_OK(c, hipStreamSynchronize(c->stream));
     return MVFIT_OK;
 }
 
@@ -867,7 +860,7 @@ extern "C" int mvfit_vertices(mvfit_ctx* c, const float* params, uint32_t flags,
     int rc = check_flags(c, flags);
     if (rc) return rc;
     HIP_OK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, params, flags);
+    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, flags);
     HIP_OK(c, hipGetLastError());
     rc = run_vertex_pass(c, verts);
     if (rc) return rc;
@@ -889,13 +882,14 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     float* vbuf = verts ? verts : c->d_verts;
     const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0;
     if (!sparse || verts) {
-        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, params, w->flags);
+        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, w->flags);
         HIP_OK(c, hipGetLastError());
         rc = run_vertex_pass(c, vbuf);
         if (rc) return rc;
     }
     prof_begin(c, c->ev_step);
-    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, to_dev(*w), c->P, params,
+    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V,
+                       to_dev(*w), c->P, params,
                        sparse ? 0 : 1, loss, grad, joints);
     prof_end(c, c->ev_step);
     HIP_OK(c, hipGetLastError());
@@ -949,7 +943,8 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     if (e == hipSuccess) {
         for (int r = 0; r < kGraphRounds && e == hipSuccess; ++r) {
             e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, cs);
-            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), cs, c->M, c->Q, SW, O, c->P, c->F);
+            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+                               c->P, c->F);
         }
         hipError_t e2 = hipStreamEndCapture(cs, &g);
         if (e == hipSuccess) e = e2;
@@ -984,7 +979,8 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0;
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
-    hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, c->P, c->F, (const float*)params,
+    hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
+                       (const float*)params,
                        sw[0].flags, sparse ? 0 : 1);
     HIP_OK(c, hipGetLastError());
     int* h_done = c->h_done;
@@ -994,7 +990,8 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     if (sparse) {
         while (rounds < cap) {
             const int chunk = std::min(cap - rounds, 1 << 20);
-            hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M, c->Q, SW, O, c->P,
+            hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
+                               (const ObsBlock*)c->d_obs, c->V, SW, O, c->P,
                                c->F, chunk);
             HIP_OK(c, hipGetLastError());
             rounds += chunk;
@@ -1009,7 +1006,8 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                 rc = run_vertex_pass(c, c->d_verts);
                 if (rc) return rc;
                 prof_begin(c, c->ev_step);
-                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, c->Q, SW, O, c->P, c->F);
+                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+                                   c->P, c->F);
                 prof_end(c, c->ev_step);
             }
             HIP_OK(c, hipGetLastError());
