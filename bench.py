@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 from mvsmplfitting_amd import _lib                      # noqa: E402
 from mvsmplfitting_amd import synthetic as syn          # noqa: E402
 from mvsmplfitting_amd.engine import MvFit, stage_weights   # noqa: E402
+from mvsmplfitting_amd.sharding import gather_results, shard_range   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 CONST_BYTES = 82680 + 826800 + 17114760 + 661440      # v_template + shapedirs + posedirs + lbs_weights
@@ -122,8 +123,12 @@ def main():
     if args.sparse:
         flags |= _lib.F_SPARSE_VERTS
     stages = stage_weights(1536.0, flags=flags)
-    B = args.frames
-    cams, gt, conf, x0 = build_inputs(eng, B, args.views, seed0=1000 + 100000 * rank)
+    B = args.frames                                   # weak scaling: frames per GPU
+    # rank r owns the contiguous global frames shard_range(B * world, world, r); seeds follow the
+    # global frame index, so the job is the same set of frames however it is sharded
+    lo, hi = shard_range(B * world, world, rank)
+    assert hi - lo == B
+    cams, gt, conf, x0 = build_inputs(eng, B, args.views, seed0=1000 + lo)
     x0_d = torch.tensor(x0, device=dev)
 
     def barrier():
@@ -140,10 +145,12 @@ def main():
     n_iter = 0
     finals = None
     xf = None
+    n_max = 0
     for _ in range(args.steps):
         xf, st = eng.fit(x0_d, stages)
         n_closure += int(st['n_closure'].sum().item())      # tiny D2H per step, after the fit finished
         n_iter += int(st['n_iter'].sum().item())
+        n_max = int(st['n_closure'].max().item())
         finals = st['final_loss']
     barrier()
     dt = time.perf_counter() - t0
@@ -156,8 +163,8 @@ def main():
         dist.all_reduce(red)
         tm = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        gathered = [torch.empty_like(xf) for _ in range(world)]
-        dist.all_gather(gathered, xf)
+        gathered = gather_results(xf, B * world)      # the path's only collective (RCCL over xGMI)
+        assert gathered.shape[0] == B * world
         tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
 
     # roofline of the dominant kernel (LBS vertex pass): one more identical fit with per-launch
@@ -199,6 +206,7 @@ def main():
             'ms_to_convergence_per_frame': round(1e3 * tmax / args.steps / B, 4),
             'lbfgs_iters_per_s': round(tot_iter / tmax, 1),
             'closures_per_fit_per_frame': round(tot_closure / args.steps / (B * world), 1),
+            'closure_rounds_per_fit': n_max,      # = closures of the slowest frame of rank 0's batch (the batch advances in lock-step rounds)
             'final_loss_median': float(np.median(fl)),
             'roofline': roof, 'cpu_baseline': cpu,
         }

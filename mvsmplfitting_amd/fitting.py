@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's operator interface for the fitting hot path.
+
+Same names, argument meaning and error behaviour as the reference seams that
+``non_linear_solver`` calls (reference code/utils/non_linear_solver.py:127-143,172-203):
+
+=====================================  ==========================================================
+reference                              here
+=====================================  ==========================================================
+fitting.create_loss (fitting.py:208)   :func:`create_loss` -> :class:`SMPLifyLoss` (weights holder;
+                                       the arithmetic of ``forward`` runs in libmvfit)
+FittingMonitor (fitting.py:37-52)      :class:`FittingMonitor`
+  .create_fitting_closure (:144-205)     returns ``fitting_func(backward=True)``: reads the CURRENT
+                                         values of the torch Parameters, evaluates the HIP closure,
+                                         writes ``.grad`` of every optimised Parameter, returns the
+                                         loss as a 0-d CUDA tensor (``float()``, ``.item()``,
+                                         ``torch.isnan`` work as in the reference)
+  .run_fitting (:71-142)                 with an :class:`LBFGSHip` optimiser: the whole stage runs
+                                         device-resident (mvfit_fit); with any other optimiser:
+                                         the reference's Python loop, verbatim semantics
+optim_factory.create_optimizer (:27)   :func:`create_optimizer` adds ``optim_type='lbfgs_hip'``;
+                                       unknown types raise ValueError like the reference
+=====================================  ==========================================================
+
+Nothing in here computes: PyTorch only holds device memory (``data_ptr()`` crosses the C ABI).
+If libmvfit.so is missing or no HIP device is present, constructing the engine raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import MvFit, MvFitError, SL, D
+
+__all__ = ['create_loss', 'SMPLifyLoss', 'FittingMonitor', 'create_optimizer', 'LBFGSHip', 'BodyModel',
+           'model_arrays', 'patch_reference']
+
+
+# ---------------------------------------------------------------------------------------------- model side
+def _np(t, dtype=np.float32):
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=dtype)
+
+
+def model_arrays(body_model) -> dict:
+    """The constant arrays libmvfit needs, from a reference ``SMPL`` module of the 'smpllsp' kind
+    (buffers registered by reference code/smplx/body_models_scale.py:197-305) or from a
+    :class:`BodyModel`.  Raises AttributeError naming the missing buffer otherwise."""
+    if isinstance(body_model, BodyModel):
+        return body_model.arrays
+    sel = body_model.vertex_joint_selector.extra_joints_idxs          # vertex_joint_selector.py:38-43
+    maps = body_model.joint_mapper.joint_maps                          # utils/utils.py:411-424
+    return dict(
+        v_template=_np(body_model.v_template), shapedirs=_np(body_model.shapedirs),
+        posedirs=_np(body_model.posedirs), J_regressor=_np(body_model.J_regressor),
+        parents=_np(body_model.parents, np.int32), lbs_weights=_np(body_model.lbs_weights),
+        kp_regressor=_np(body_model.joint_regressor), face_vertex_ids=_np(sel, np.int32),
+        joint_map=_np(maps, np.int32),
+        faces=_np(body_model.faces_tensor, np.int32) if hasattr(body_model, 'faces_tensor') else None)
+
+
+def _vposer_arrays(vposer):
+    """Decoder weights of a reference ``VPoser`` module (code/model/VPoser.py:188-195) or a dict."""
+    if vposer is None or isinstance(vposer, dict):
+        return vposer
+    return dict(fc1_w=_np(vposer.bodyprior_dec_fc1.weight), fc1_b=_np(vposer.bodyprior_dec_fc1.bias),
+                fc2_w=_np(vposer.bodyprior_dec_fc2.weight), fc2_b=_np(vposer.bodyprior_dec_fc2.bias),
+                out_w=_np(vposer.bodyprior_dec_out.weight), out_b=_np(vposer.bodyprior_dec_out.bias))
+
+
+def _gmm_arrays(prior):
+    """(means, precisions, nll_weights) of a reference ``MaxMixturePrior`` (code/prior.py:135-160)."""
+    if prior is None or not hasattr(prior, 'precisions'):
+        return None
+    if isinstance(prior, tuple):
+        return prior
+    return (_np(prior.means), _np(prior.precisions), _np(prior.nll_weights).reshape(-1))
+
+
+class BodyModel(torch.nn.Module):
+    """Parameter container with the reference SMPL's parameter names, shapes and registration order
+    (body_models_scale.py:202-268: betas[1,10], global_orient[1,3], body_pose[1,69], transl[1,3],
+    scale[1,1]) for callers that do not have the reference module (tests on the GPU box)."""
+
+    def __init__(self, arrays: dict, device='cuda', use_vposer=False):
+        super().__init__()
+        self.arrays = arrays
+        z = lambda n: torch.nn.Parameter(torch.zeros(1, n, device=device))    # noqa: E731
+        self.betas = z(10)
+        self.global_orient = z(3)
+        if not use_vposer:
+            self.body_pose = z(69)
+        self.transl = z(3)
+        self.scale = torch.nn.Parameter(torch.ones(1, 1, device=device))
+
+    def reset_params(self, **kw):                  # body_models_scale.py:310-316
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name in kw:
+                    p.copy_(torch.as_tensor(kw[name], dtype=p.dtype, device=p.device).reshape(p.shape))
+
+
+# ---------------------------------------------------------------------------------------------- loss holder
+class SMPLifyLoss:
+    """Weights and prior selection of reference ``SMPLifyLoss`` (fitting.py:215-280).  ``forward`` is
+    evaluated inside libmvfit; this object only carries what it is configured with."""
+
+    def __init__(self, rho=100, body_pose_prior=None, shape_prior=None, angle_prior=None,
+                 use_joints_conf=True, interpenetration=False, dtype=torch.float32, data_weight=1.0,
+                 body_pose_weight=0.0, shape_weight=0.0, bending_prior_weight=0.0,
+                 coll_loss_weight=0.0, reduction='sum', use_3d=False, **kwargs):
+        if use_3d:
+            raise NotImplementedError('use_3d (3-D joint term, fitting.py:319-324) is not built in libmvfit yet')
+        self.rho = float(rho)
+        self.body_pose_prior = body_pose_prior
+        self.shape_prior = shape_prior
+        self.angle_prior = angle_prior
+        self.use_joints_conf = use_joints_conf
+        self.interpenetration = interpenetration
+        self.fix_shape = kwargs.get('fix_shape')
+        self.data_weight = float(data_weight)
+        self.body_pose_weight = float(body_pose_weight)
+        self.shape_weight = float(shape_weight)
+        self.bending_prior_weight = float(bending_prior_weight)
+        self.coll_loss_weight = float(coll_loss_weight)
+
+    def reset_loss_weights(self, loss_weight_dict):        # fitting.py:270-280 (unknown keys ignored)
+        for key in loss_weight_dict:
+            if hasattr(self, key):
+                v = loss_weight_dict[key]
+                setattr(self, key, float(v.item() if isinstance(v, torch.Tensor) else v))
+
+    def weights(self, flags: int) -> dict:
+        coll = self.coll_loss_weight if self.interpenetration else 0.0
+        return dict(data_weight=self.data_weight, body_pose_weight=self.body_pose_weight,
+                    shape_weight=self.shape_weight, bending_prior_weight=self.bending_prior_weight,
+                    coll_loss_weight=coll, rho=self.rho, flags=flags)
+
+
+def create_loss(loss_type='smplify', **kwargs):             # fitting.py:208-212
+    if loss_type == 'smplify':
+        return SMPLifyLoss(**kwargs)
+    raise ValueError('Unknown loss type: {}'.format(loss_type))
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+class LBFGSHip:
+    """Settings holder for the device-resident strong-Wolfe L-BFGS (reference ``LBFGS``,
+    optimizers/lbfgs_ls.py:199-207).  It is consumed by :meth:`FittingMonitor.run_fitting`, which runs
+    the whole stage inside libmvfit; ``step`` exists for interface completeness and refuses to run a
+    host-driven loop (there is no CPU fallback of the optimiser)."""
+
+    def __init__(self, params, lr=1.0, max_iter=20, history_size=100, tolerance_grad=1e-5,
+                 tolerance_change=1e-9, line_search_fn='strong_Wolfe'):
+        if line_search_fn != 'strong_Wolfe':
+            raise ValueError("only line_search_fn='strong_Wolfe' is implemented on the device")
+        self.params = list(params)
+        self.lr, self.max_iter, self.history_size = lr, max_iter, history_size
+        self.tolerance_grad, self.tolerance_change = tolerance_grad, tolerance_change
+        self.param_groups = [dict(params=self.params)]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, closure):
+        raise MvFitError('LBFGSHip is device resident: hand it to FittingMonitor.run_fitting '
+                         '(or use the reference LBFGSLs with the HIP closure)')
+
+
+def create_optimizer(parameters, optim_type='lbfgs', lr=1e-3, maxiters=20, gtol=1e-6, ftol=1e-9, **kwargs):
+    """reference optimizers/optim_factory.py:27-65 + the new ``'lbfgs_hip'`` type."""
+    if optim_type == 'lbfgs_hip':
+        return LBFGSHip(parameters, lr=lr, max_iter=maxiters), False
+    if optim_type == 'lbfgs':
+        return torch.optim.LBFGS(parameters, lr=lr, max_iter=maxiters), False
+    if optim_type == 'adam':
+        return torch.optim.Adam(parameters, lr=lr, betas=(kwargs.get('beta1', 0.9), kwargs.get('beta2', 0.999)),
+                                weight_decay=kwargs.get('weight_decay', 0.0)), False
+    if optim_type == 'sgd':
+        return torch.optim.SGD(parameters, lr=lr, momentum=kwargs.get('momentum', 0.9),
+                               weight_decay=kwargs.get('weight_decay', 0.0),
+                               nesterov=kwargs.get('use_nesterov', True)), False
+    raise ValueError('Optimizer {} not supported!'.format(optim_type))
+
+
+# ---------------------------------------------------------------------------------------------- closure
+class _HipClosure:
+    """``fitting_func`` of reference fitting.py:162-203 for one (subject, frame) problem."""
+
+    def __init__(self, optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
+                 use_vposer, vposer, pose_embedding):
+        self.optimizer, self.body_model, self.loss = optimizer, body_model, loss
+        self.use_vposer, self.pose_embedding = use_vposer, pose_embedding
+        eng = getattr(body_model, '_mvfit_engine', None)
+        if eng is None:
+            eng = MvFit(model_arrays(body_model), vposer=_vposer_arrays(vposer) if use_vposer else None,
+                        gmm=_gmm_arrays(loss.body_pose_prior))
+            body_model._mvfit_engine = eng
+        self.eng = eng
+        dev = eng.device
+        # cameras: fixed R, t, f (fx == fy), c per view (reference code/camera.py:55-117, init.py:112-131)
+        R = torch.stack([c.rotation.reshape(3, 3) for c in camera]).to(dev, torch.float32)
+        t = torch.stack([c.translation.reshape(3) for c in camera]).to(dev, torch.float32)
+        f = torch.stack([c.focal_length_x.reshape(()) for c in camera]).to(dev, torch.float32)
+        c2 = torch.stack([c.center.reshape(2) for c in camera]).to(dev, torch.float32)
+        V = len(camera)
+        gt = torch.as_tensor(gt_joints, dtype=torch.float32, device=dev).reshape(V, -1, 17, 2)[:, 0][None]   # [1,V,17,2]
+        if joints_conf is None:
+            raise NameError("name 'joints_conf' is not defined")        # the reference fails the same way (quirk 7)
+        conf = torch.stack([torch.as_tensor(jc, dtype=torch.float32, device=dev).reshape(-1)[:17] for jc in joints_conf])
+        jw = torch.as_tensor(joint_weights, dtype=torch.float32, device=dev).reshape(-1)[:17]
+        eng.set_problems((R, t, f, c2), gt, (conf * jw[None])[None])
+        self.x = torch.zeros(1, D, device=dev)
+        self.x[0, 85] = 1.0
+        self.params = dict(body_model.named_parameters())
+        if use_vposer:
+            self.params['pose_embedding'] = pose_embedding
+        self.flags = (_lib.F_VPOSER if use_vposer else 0)
+        if isinstance(loss.body_pose_prior, object) and hasattr(loss.body_pose_prior, 'precisions'):
+            self.flags |= _lib.F_PRIOR_GMM
+        if not self.params['betas'].requires_grad or loss.fix_shape:
+            self.flags |= _lib.F_FIX_SHAPE
+        if not self.params['scale'].requires_grad:
+            self.flags |= _lib.F_FIX_SCALE
+
+    def pack(self):
+        for name, p in self.params.items():
+            if name in SL:
+                a, b = SL[name]
+                self.x[0, a:b] = p.detach().reshape(-1)
+        return self.x
+
+    def unpack(self, x):
+        with torch.no_grad():
+            for name, p in self.params.items():
+                if name in SL:
+                    a, b = SL[name]
+                    p.copy_(x[0, a:b].reshape(p.shape))
+
+    def __call__(self, backward=True):
+        if backward and self.optimizer is not None:
+            self.optimizer.zero_grad()
+        out = self.eng.closure(self.pack(), self.loss.weights(self.flags), want_grad=backward)
+        if backward:
+            g = out['grad']
+            for name, p in self.params.items():
+                if name in SL and p.requires_grad:
+                    a, b = SL[name]
+                    p.grad = g[0, a:b].reshape(p.shape).clone()
+        return out['loss'][0]
+
+
+class FittingMonitor:
+    def __init__(self, summary_steps=1, visualize=False, maxiters=100, ftol=2e-09, gtol=1e-05,
+                 body_color=(1.0, 1.0, 0.9, 1.0), model_type='smpl', **kwargs):
+        self.maxiters, self.ftol, self.gtol = maxiters, ftol, gtol
+        self.visualize, self.summary_steps, self.model_type = visualize, summary_steps, model_type
+
+    def create_fitting_closure(self, optimizer, body_model, camera=None, gt_joints=None, loss=None,
+                               joints_conf=None, gt_joints3d=None, joints3d_conf=None, joint_weights=None,
+                               return_verts=True, return_full_pose=False, use_vposer=False, vposer=None,
+                               pose_embedding=None, create_graph=False, use_3d=False, **kwargs):
+        if create_graph:
+            raise NotImplementedError('create_graph=True (second-order optimisers) is not supported')
+        return _HipClosure(optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
+                           use_vposer, vposer, pose_embedding)
+
+    def run_fitting(self, optimizer, closure, params, body_model, use_vposer=True, pose_embedding=None,
+                    vposer=None, camera=None, img_path=None, **kwargs):
+        """reference fitting.py:71-142.  Returns the last loss value (python float) or None."""
+        if isinstance(optimizer, LBFGSHip):
+            if not isinstance(closure, _HipClosure):
+                raise MvFitError('LBFGSHip needs the closure made by FittingMonitor.create_fitting_closure')
+            w = closure.loss.weights(closure.flags)
+            x, st = closure.eng.fit(closure.pack(), [w], lr=optimizer.lr, max_iter=optimizer.max_iter,
+                                    history=optimizer.history_size, tolerance_grad=optimizer.tolerance_grad,
+                                    tolerance_change=optimizer.tolerance_change, maxiters=self.maxiters,
+                                    ftol=self.ftol, gtol=self.gtol)
+            closure.unpack(x)                        # results are read from the torch Parameters (:284-287)
+            v = float(st['final_loss'][0].item())
+            return None if np.isnan(v) else v
+        prev_loss = None
+        for n in range(self.maxiters):               # verbatim control flow of the reference loop
+            loss = optimizer.step(closure)
+            if torch.isnan(loss).sum() > 0:
+                print('NaN loss value, stopping!')
+                break
+            if torch.isinf(loss).sum() > 0:
+                print('Infinite loss value, stopping!')
+                break
+            if n > 0 and prev_loss is not None and self.ftol > 0:
+                cur = loss.item()
+                rel = (prev_loss - cur) / max(abs(prev_loss), abs(cur), 1)        # utils.rel_change
+                if rel <= self.ftol:
+                    break
+            if all(abs(p.grad.view(-1).max().item()) < self.gtol for p in params if p.grad is not None):
+                break
+            prev_loss = loss.item()
+        return prev_loss
+
+
+def patch_reference(fitting_module, optim_factory_module):
+    """Monkey-patch the reference modules (the three names ``non_linear_solver`` resolves at call time)
+    so that ``optim_type: 'lbfgs_hip'`` in the yaml runs the stage loop on libmvfit."""
+    fitting_module.create_loss = create_loss
+    fitting_module.FittingMonitor = FittingMonitor
+    optim_factory_module.create_optimizer = create_optimizer
