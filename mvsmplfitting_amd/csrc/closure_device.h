@@ -442,20 +442,33 @@ __device__ void chain_forward_wave(ClosureLds& L, int lane) {
     if (lane < 12) L.pose.G[0][lane] = L.pose.Mj[0][lane];
     const int q = lane / 12, e = lane - 12 * q, a = e >> 2, c = e & 3;
     const int npass = L.M.n_fwd;
-    int w = (q < 5 && npass > 0) ? L.M.fwd_tab[0][q] : -1;
+    constexpr int CH = 8;           // passes per chunk: everything that does not depend on the chain
+                                    // (table words, the joints' own M columns) is loaded up front, so the
+                                    // dependent part of a pass is ds_read_b128 -> 3 FMA -> ds_write
     wave_lds_fence();
-    for (int p = 0; p < npass; ++p) {
-        const int wn = (q < 5 && p + 1 < npass) ? L.M.fwd_tab[p + 1][q] : -1;    // next pass's word: off the critical path
-        if (w >= 0) {
-            const int j = w & 0xff, pa = w >> 8;
-            const float m0 = L.pose.Mj[j][c], m1 = L.pose.Mj[j][4 + c], m2 = L.pose.Mj[j][8 + c];
-            const float4 g = *reinterpret_cast<const float4*>(&L.pose.G[pa][4 * a]);
-            float v = g.x * m0 + g.y * m1 + g.z * m2;
-            if (c == 3) v += g.w;
-            L.pose.G[j][e] = v;
+    for (int p0 = 0; p0 < npass; p0 += CH) {
+        int w[CH];
+        float m0[CH], m1[CH], m2[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) w[u] = (q < 5 && p0 + u < npass) ? L.M.fwd_tab[p0 + u][q] : -1;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int j = w[u] >= 0 ? (w[u] & 0xff) : 0;
+            m0[u] = L.pose.Mj[j][c]; m1[u] = L.pose.Mj[j][4 + c]; m2[u] = L.pose.Mj[j][8 + c];
         }
-        w = wn;
-        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (p0 + u < npass) {                                  // uniform
+                if (w[u] >= 0) {
+                    const int j = w[u] & 0xff, pa = w[u] >> 8;
+                    const float4 g = *reinterpret_cast<const float4*>(&L.pose.G[pa][4 * a]);
+                    float v = g.x * m0[u] + g.y * m1[u] + g.z * m2[u];
+                    if (c == 3) v += g.w;
+                    L.pose.G[j][e] = v;
+                }
+                wave_lds_fence();
+            }
+        }
     }
     for (int i = lane; i < NJ * 3; i += 64) {          // (joint, row a)
         const int j = i / 3, aa = i - 3 * j;
@@ -466,38 +479,35 @@ __device__ void chain_forward_wave(ClosureLds& L, int lane) {
 }
 
 // k-split partial sums of v_posed = v_template + coef . pd_sub  (lbs.py:179,192-203 on the selected
-// vertices).  Threads [t0, t0 + nthreads) take part; partials land in L.scratch[ks][nc_pad].
-__device__ __forceinline__ int fwd_slices(int nc_pad, int nthreads) { return max(1, min(nthreads / (nc_pad >> 2), 8)); }
+// vertices): 8 slices of 28 basis rows x nc_pad/4 float4 column groups = items; threads [0, nthreads)
+// take items round-robin (one each for the SMPL keypoint set).  All 28 loads of an item are issued
+// before the first FMA: the stream is then limited by bandwidth, not by one L2 round trip per row pair.
+constexpr int FWD_SLICES = 8, FWD_RPS = KROWS / FWD_SLICES;      // 28 rows per slice
+__device__ __forceinline__ int fwd_slices(int, int) { return FWD_SLICES; }
 
 __device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
     const int nc_pad = L.M.nc_pad;
     const int ncq = nc_pad >> 2;                   // float4 column groups
-    const int nks = fwd_slices(nc_pad, nthreads);
-    const int rps = (KROWS / 4 + nks - 1) / nks * 4;   // rows per slice, multiple of 4
-    const int cq = t % ncq, ks = t / ncq;
-    if (ks >= nks) return;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    const int r0 = ks * rps, r1 = min(KROWS, r0 + rps);
-    const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + cq;
-    int p = r0;
-#pragma unroll 4
-    for (; p + 1 < r1; p += 2) {
-        const float4 v0 = src[(size_t)p * ncq];
-        const float4 v1 = src[(size_t)(p + 1) * ncq];
-        const float c0 = L.coef[p], c1 = L.coef[p + 1];
-        acc0.x = fmaf(c0, v0.x, acc0.x); acc0.y = fmaf(c0, v0.y, acc0.y);
-        acc0.z = fmaf(c0, v0.z, acc0.z); acc0.w = fmaf(c0, v0.w, acc0.w);
-        acc1.x = fmaf(c1, v1.x, acc1.x); acc1.y = fmaf(c1, v1.y, acc1.y);
-        acc1.z = fmaf(c1, v1.z, acc1.z); acc1.w = fmaf(c1, v1.w, acc1.w);
+    for (int item = t; item < ncq * FWD_SLICES; item += nthreads) {
+        // workgroups of one XCD run in near lock-step on the same matrix: start each at a different slice
+        // so that they do not queue on the same L2 channel
+        const int cq = item % ncq, ks = (item / ncq + (int)blockIdx.x) & (FWD_SLICES - 1);
+        const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + (size_t)(ks * FWD_RPS) * ncq + cq;
+        float4 v[FWD_RPS];
+#pragma unroll
+        for (int r = 0; r < FWD_RPS; ++r) v[r] = src[(size_t)r * ncq];
+        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+        for (int r = 0; r < FWD_RPS; r += 2) {
+            const float c0 = L.coef[ks * FWD_RPS + r], c1 = L.coef[ks * FWD_RPS + r + 1];
+            acc0.x = fmaf(c0, v[r].x, acc0.x); acc0.y = fmaf(c0, v[r].y, acc0.y);
+            acc0.z = fmaf(c0, v[r].z, acc0.z); acc0.w = fmaf(c0, v[r].w, acc0.w);
+            acc1.x = fmaf(c1, v[r + 1].x, acc1.x); acc1.y = fmaf(c1, v[r + 1].y, acc1.y);
+            acc1.z = fmaf(c1, v[r + 1].z, acc1.z); acc1.w = fmaf(c1, v[r + 1].w, acc1.w);
+        }
+        float4* dst = reinterpret_cast<float4*>(L.scratch + ks * nc_pad + 4 * cq);
+        *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
     }
-    if (p < r1) {
-        const float4 v0 = src[(size_t)p * ncq];
-        const float c0 = L.coef[p];
-        acc0.x = fmaf(c0, v0.x, acc0.x); acc0.y = fmaf(c0, v0.y, acc0.y);
-        acc0.z = fmaf(c0, v0.z, acc0.z); acc0.w = fmaf(c0, v0.w, acc0.w);
-    }
-    float4* dst = reinterpret_cast<float4*>(L.scratch + ks * nc_pad + 4 * cq);
-    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
 }
 
 // E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
@@ -691,67 +701,86 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
 // g_G_p[a][m] += sum_children sum_col g_G_c[a][col] M_c[m][col]  (m < 3),  g_G_p[a][3] += g_G_c[a][3].
 __device__ void chain_backward_wave(ClosureLds& L, int lane) {
     const int q = lane / 12, e = lane - 12 * q, a = e >> 2, m = e & 3;
+    const int mr = m < 3 ? m : 0;
     const int npass = L.M.n_bwd;
-    int w = (q < 5 && npass > 0) ? L.M.bwd_tab[0][q] : -1;
+    constexpr int CH = 4;           // passes per chunk (operands independent of the chain are preloaded)
     wave_lds_fence();
-    for (int ps = 0; ps < npass; ++ps) {
-        const int wn = (q < 5 && ps + 1 < npass) ? L.M.bwd_tab[ps + 1][q] : -1;
-        if (w != -1) {
-            const int p = w & 0xff, c0 = (w >> 8) & 0xff, c1 = (w >> 16) & 0xff, c2 = (w >> 24) & 0xff;
-            // child rows 24..31 are zero: absent children contribute nothing
-            const float4 k0 = *reinterpret_cast<const float4*>(&L.pose.Mj[c0][4 * (m < 3 ? m : 0)]);
-            const float4 k1 = *reinterpret_cast<const float4*>(&L.pose.Mj[c1][4 * (m < 3 ? m : 0)]);
-            const float4 k2 = *reinterpret_cast<const float4*>(&L.pose.Mj[c2][4 * (m < 3 ? m : 0)]);
-            const float4 g0 = *reinterpret_cast<const float4*>(&L.gG[c0][4 * a]);
-            const float4 g1 = *reinterpret_cast<const float4*>(&L.gG[c1][4 * a]);
-            const float4 g2 = *reinterpret_cast<const float4*>(&L.gG[c2][4 * a]);
-            float acc;
-            if (m < 3) {
-                acc = (g0.x * k0.x + g0.y * k0.y + g0.z * k0.z + g0.w * k0.w) +
-                      (g1.x * k1.x + g1.y * k1.y + g1.z * k1.z + g1.w * k1.w) +
-                      (g2.x * k2.x + g2.y * k2.y + g2.z * k2.z + g2.w * k2.w);
-            } else {
-                acc = g0.w + g1.w + g2.w;
-            }
-            L.gG[p][e] += acc;
+    for (int p0 = 0; p0 < npass; p0 += CH) {
+        int w[CH];
+        float4 k0[CH], k1[CH], k2[CH];
+        float own[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) w[u] = (q < 5 && p0 + u < npass) ? L.M.bwd_tab[p0 + u][q] : -1;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            // absent entries / children point at the zero rows 24..31
+            const int ww = w[u] != -1 ? w[u] : 0x1f1f1f00;
+            const int c0 = (ww >> 8) & 0xff, c1 = (ww >> 16) & 0xff, c2 = (ww >> 24) & 0xff;
+            k0[u] = *reinterpret_cast<const float4*>(&L.pose.Mj[c0][4 * mr]);
+            k1[u] = *reinterpret_cast<const float4*>(&L.pose.Mj[c1][4 * mr]);
+            k2[u] = *reinterpret_cast<const float4*>(&L.pose.Mj[c2][4 * mr]);
+            own[u] = L.gG[ww & 0x1f][e];              // E6's value of the parent entry (see flag 0x80 below)
         }
-        w = wn;
-        wave_lds_fence();
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (p0 + u < npass) {                                  // uniform
+                if (w[u] != -1) {
+                    const int p = w[u] & 0x1f, c0 = (w[u] >> 8) & 0xff, c1 = (w[u] >> 16) & 0xff, c2 = (w[u] >> 24) & 0xff;
+                    const float4 g0 = *reinterpret_cast<const float4*>(&L.gG[c0][4 * a]);
+                    const float4 g1 = *reinterpret_cast<const float4*>(&L.gG[c1][4 * a]);
+                    const float4 g2 = *reinterpret_cast<const float4*>(&L.gG[c2][4 * a]);
+                    float acc;
+                    if (m < 3) {
+                        acc = (g0.x * k0[u].x + g0.y * k0[u].y + g0.z * k0[u].z + g0.w * k0[u].w) +
+                              (g1.x * k1[u].x + g1.y * k1[u].y + g1.z * k1[u].z + g1.w * k1[u].w) +
+                              (g2.x * k2[u].x + g2.y * k2[u].y + g2.z * k2[u].z + g2.w * k2[u].w);
+                    } else {
+                        acc = g0.w + g1.w + g2.w;
+                    }
+                    // 0x80: a further entry of a parent with more than three children - add to the live value
+                    const float base = (w[u] & 0x80) ? L.gG[p][e] : own[u];
+                    L.gG[p][e] = base + acc;
+                }
+                wave_lds_fence();
+            }
+        }
     }
 }
 
-// g_coef partials = pd_subT . g_vposed, column-split; threads [0, nthreads) -> L.scratch[cs][KROWS]
-__device__ __forceinline__ int bwd_slices(int nthreads) { return max(1, min(nthreads / (KROWS >> 2), 8)); }
+// g_coef partials = pd_subT . g_vposed: 8 column slices x 56 float4 row groups = 448 items, one per
+// thread of waves 1-7; partials in L.scratch[cs][KROWS].  Loads first, as in the forward stream.
+constexpr int BWD_SLICES = 8, BWD_CPS = NC_MAX / BWD_SLICES;     // up to 36 columns per slice
+__device__ __forceinline__ int bwd_slices(int) { return BWD_SLICES; }
 
 __device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
     constexpr int npq = KROWS >> 2;                 // 56 float4 row groups
     const int nc_pad = L.M.nc_pad;
-    const int ncs = bwd_slices(nthreads);
-    const int cps = (nc_pad / 4 + ncs - 1) / ncs * 4;
-    const int pq = t % npq, cs = t / npq;
-    if (cs >= ncs) return;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    const int c0 = cs * cps, c1 = min(nc_pad, c0 + cps);
-    const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
-    int c = c0;
-#pragma unroll 4
-    for (; c + 1 < c1; c += 2) {
-        const float4 v0 = src[(size_t)c * npq];
-        const float4 v1 = src[(size_t)(c + 1) * npq];
-        const float g0 = L.gvp[c], g1 = L.gvp[c + 1];
-        acc0.x = fmaf(g0, v0.x, acc0.x); acc0.y = fmaf(g0, v0.y, acc0.y);
-        acc0.z = fmaf(g0, v0.z, acc0.z); acc0.w = fmaf(g0, v0.w, acc0.w);
-        acc1.x = fmaf(g1, v1.x, acc1.x); acc1.y = fmaf(g1, v1.y, acc1.y);
-        acc1.z = fmaf(g1, v1.z, acc1.z); acc1.w = fmaf(g1, v1.w, acc1.w);
+    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;     // columns per slice (multiple of 4)
+    for (int item = t; item < npq * BWD_SLICES; item += nthreads) {
+        const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
+        const int c0 = cs * cps;
+        const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
+        float4 v[BWD_CPS];
+#pragma unroll
+        for (int r = 0; r < BWD_CPS; ++r) {
+            const int c = min(c0 + r, nc_pad - 1);              // clamped: surplus columns get a zero coefficient
+            if (r < cps) v[r] = src[(size_t)c * npq];
+        }
+        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+        for (int r = 0; r < BWD_CPS; r += 2) {
+            if (r < cps) {
+                const float g0 = (c0 + r < nc_pad) ? L.gvp[c0 + r] : 0.f;
+                const float g1 = (c0 + r + 1 < nc_pad) ? L.gvp[c0 + r + 1] : 0.f;
+                acc0.x = fmaf(g0, v[r].x, acc0.x); acc0.y = fmaf(g0, v[r].y, acc0.y);
+                acc0.z = fmaf(g0, v[r].z, acc0.z); acc0.w = fmaf(g0, v[r].w, acc0.w);
+                acc1.x = fmaf(g1, v[r + 1].x, acc1.x); acc1.y = fmaf(g1, v[r + 1].y, acc1.y);
+                acc1.z = fmaf(g1, v[r + 1].z, acc1.z); acc1.w = fmaf(g1, v[r + 1].w, acc1.w);
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
+        *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
     }
-    if (c < c1) {
-        const float4 v0 = src[(size_t)c * npq];
-        const float g0 = L.gvp[c];
-        acc0.x = fmaf(g0, v0.x, acc0.x); acc0.y = fmaf(g0, v0.y, acc0.y);
-        acc0.z = fmaf(g0, v0.z, acc0.z); acc0.w = fmaf(g0, v0.w, acc0.w);
-    }
-    float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
-    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -229,6 +229,9 @@ __device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int l
     s0 = s0 >= LB_HIST ? s0 - LB_HIST : s0;
     s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
     s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
+    // lanes that own no live age read column LB_HIST (never written, zero in every row): their x stays 0
+    if (lane >= n) s0 = LB_HIST;
+    if (lane + 64 >= n) s1 = LB_HIST;
     // row of age i is physical row LB_GPAD + head + i (doubled layout: no wrap for i < 100)
     const T* p0 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s0;
     const T* p1 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s1;
@@ -236,18 +239,18 @@ __device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int l
     T g0[LB_PD], g1[LB_PD];
 #pragma unroll
     for (int u = 0; u < LB_PD; ++u) { g0[u] = p0[u * RS]; g1[u] = TWO ? p1[u * RS] : (T)0; }
+    // Steps st >= n of the last group run unguarded: the broadcast then reads a lane that owns no live
+    // age (index >= n, or negative & 127), whose x is exactly 0, so x is left unchanged.
     for (int base = 0; base < n; base += LB_PD) {
         p0 += LB_PD * RS;
         p1 += LB_PD * RS;
 #pragma unroll
         for (int u = 0; u < LB_PD; ++u) {
             const int st = base + u;
-            if (st < n) {
-                const int i = DESC ? n - 1 - st : st;
-                const T v = TWO ? lane_read(i < 64 ? x0 : x1, i & 63) : lane_read(x0, i);
-                x0 = fma(-v, g0[u], x0);
-                if (TWO) x1 = fma(-v, g1[u], x1);
-            }
+            const int i = (DESC ? n - 1 - st : st) & 127;
+            const T v = TWO ? lane_read(i < 64 ? x0 : x1, i & 63) : lane_read(x0, i & 63);
+            x0 = fma(-v, g0[u], x0);
+            if (TWO) x1 = fma(-v, g1[u], x1);
             g0[u] = p0[u * RS];                 // row st + LB_PD (pad rows keep this in bounds)
             if (TWO) g1[u] = p1[u * RS];
         }

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
+    PH_T0();
     prologue(L, M, obs + b, F.pose + b, F.opt + b, P.vposed_sel + (size_t)b * NC_MAX, P.xs_sel + (size_t)b * NC_MAX, nullptr, tid);
     opts_in(L, SW, O, tid);
     __syncthreads();
@@ -261,13 +262,16 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     LbHist<float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.opt.lb_ro,
                     F.grow + (size_t)b * LB_GSIZE, F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
+    PH_T(24);
     const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
+    PH_T0();
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
     // pose operands of the next trial point (also after the last round: final vertices)
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
     store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
+    PH_T(25);
 }
 
 // the whole fit of one problem in a single launch (objective-vertices-only closure): the L-BFGS
@@ -669,7 +673,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 for (int k = 0; k < nc; k += 3) {
                     int ch[3] = {31, 31, 31};
                     for (int t = 0; t < 3 && k + t < nc; ++t) ch[t] = G.child_list[G.child_start[p] + k + t];
-                    entries.push_back(p | (ch[0] << 8) | (ch[1] << 16) | (ch[2] << 24));
+                    entries.push_back(p | (k > 0 ? 0x80 : 0) | (ch[0] << 8) | (ch[1] << 16) | (ch[2] << 24));
                 }
             }
             // greedy packing into passes: at most 5 entries, no repeated parent inside a pass
@@ -681,7 +685,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 std::vector<int> parents_in_pass;
                 for (size_t i = 0; i < entries.size() && q < 5; ++i) {
                     if (used[i]) continue;
-                    const int p = entries[i] & 0xff;
+                    const int p = entries[i] & 0x1f;
                     bool clash = false;
                     for (int pp : parents_in_pass) clash |= pp == p;
                     if (clash) continue;

@@ -48,7 +48,7 @@ struct ModelLds {
     int child_list[NJ];
     // kinematic chain schedules for ONE wave (12 lanes per joint, 5 joints per pass):
     //   fwd_tab[pass][q] = j | parent << 8 (or -1): joints whose parent transform is complete
-    //   bwd_tab[pass][q] = parent | c0 << 8 | c1 << 16 | c2 << 24 (or -1), children 31 = none
+    //   bwd_tab[pass][q] = parent | 0x80 if not its first entry | c0 << 8 | c1 << 16 | c2 << 24 (or -1), child 31 = none
     int n_fwd, n_bwd;
     int fwd_tab[NJ][5];
     int bwd_tab[NJ][5];

@@ -25,6 +25,7 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     names = ['pose_prep','chain||stream','T/xs','loss','E5 gx','E6 gA','E7 chainT||streamT','E8 gR/gbeta','E9 rodT+asm(+vpbwd)','lb load','lb advance A','lb direction','lb advance B+store']
     print(name, 'rounds(block0)=%d avg hist=%.1f two-loops=%d' % (n, buf[14]/n, buf[15]))
     print('   ', ' | '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(13)), '| total=%.0f cycles/round' % (sum(buf[i] for i in range(13))/n))
+    print('    step-kernel prologue=%.0f epilogue (state store + pose/chain of next x + publish)=%.0f' % (buf[24]/n, buf[25]/n))
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
     if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
     print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
