@@ -67,6 +67,7 @@ struct ClosureLds {
     __attribute__((aligned(16))) float T[NS_MAX][12];
     float kp[NKP][3];
     float gkp_part[MVFIT_MAX_VIEWS][NKP][3];
+    float gkp[NKP][3];              // summed over views
     float gx[NC_MAX];
     __attribute__((aligned(16))) float gvp[NC_MAX];
     __attribute__((aligned(16))) float gG[32][12];     // adjoint of G (rows NJ.. zero)
@@ -154,7 +155,8 @@ __device__ __forceinline__ void rodrigues(const float* r, float* R, float* rod) 
     const float rx = r[0], ry = r[1], rz = r[2];
     const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
     const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-    const float kx = rx / a, ky = ry / a, kz = rz / a;
+    const float ia = 1.0f / a;
+    const float kx = rx * ia, ky = ry * ia, kz = rz * ia;
     float sn, cs;
     sincosf(a, &sn, &cs);
     const float oc = 1.0f - cs;
@@ -510,6 +512,29 @@ __device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int
     }
 }
 
+// keypoint k = selection row . xs + transl  (body_models_scale.py:393-403): thread per (keypoint, coordinate).
+// Ends with __syncthreads.
+__device__ void keypoints_from_xs(ClosureLds& L, int tid) {
+    if (tid < NKP * 3) {
+        const int k = tid / 3, a = tid - 3 * k;
+        float acc = 0.f;
+        if (L.M.padded) {
+            int si[KP_NZ];
+            float wi[KP_NZ], xv[KP_NZ];
+#pragma unroll
+            for (int t = 0; t < KP_NZ; ++t) { si[t] = L.M.kpp_s[k][t]; wi[t] = L.M.kpp_w[k][t]; }
+#pragma unroll
+            for (int t = 0; t < KP_NZ; ++t) xv[t] = L.xs[3 * si[t] + a];
+#pragma unroll
+            for (int t = 0; t < KP_NZ; ++t) acc = fmaf(wi[t], xv[t], acc);
+        } else {
+            for (int t = L.M.kp_start[k]; t < L.M.kp_start[k + 1]; ++t) acc = fmaf(L.M.kp_w[t], L.xs[3 * L.M.kp_s[t] + a], acc);
+        }
+        L.kp[k][a] = acc + L.opt.x[X_TR + a];
+    }
+    __syncthreads();
+}
+
 // E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
 // from_pass: L.vposed / L.xs of the selected vertices were written by the kernel prologue from the
 // vertex pass's side outputs (full mode); run_chain = false when the pose block (G, A) is already in LDS.
@@ -547,6 +572,7 @@ __device__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass,
         }
     }
     __syncthreads();
+    keypoints_from_xs(L, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,15 +590,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (tid < ndata) {
         const int v = tid / NKP, k = tid - v * NKP;
-        // keypoint k = selection row . xs + transl  (body_models_scale.py:393-403)
-        float X = 0.f, Y = 0.f, Z = 0.f;
-        for (int t = L.M.kp_start[k]; t < L.M.kp_start[k + 1]; ++t) {
-            const int s = L.M.kp_s[t];
-            const float w = L.M.kp_w[t];
-            X = fmaf(w, L.xs[3 * s], X); Y = fmaf(w, L.xs[3 * s + 1], Y); Z = fmaf(w, L.xs[3 * s + 2], Z);
-        }
-        X += L.opt.x[X_TR]; Y += L.opt.x[X_TR + 1]; Z += L.opt.x[X_TR + 2];
-        if (v == 0) { L.kp[k][0] = X; L.kp[k][1] = Y; L.kp[k][2] = Z; }
+        const float X = L.kp[k][0], Y = L.kp[k][1], Z = L.kp[k][2];      // computed once per closure (keypoints_from_xs)
         const float* Rc = L.obs.camR[v];
         const float* tc = L.obs.camt[v];
         const float f = L.obs.camf[v];
@@ -580,19 +598,20 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
         const float px = Rc[0] * X + Rc[1] * Y + Rc[2] * Z + tc[0];            // camera.py:106-110
         const float py = Rc[3] * X + Rc[4] * Y + Rc[5] * Z + tc[1];
         const float pz = Rc[6] * X + Rc[7] * Y + Rc[8] * Z + tc[2];
-        const float u = f * (px / pz) + cx, w_ = f * (py / pz) + cy;            // camera.py:112-116
+        const float ipz = 1.0f / pz;
+        const float u = f * (px * ipz) + cx, w_ = f * (py * ipz) + cy;          // camera.py:112-116
         const float rx = L.obs.gt[tid * 2] - u, ry = L.obs.gt[tid * 2 + 1] - w_;
         const float wcf = L.obs.wc[tid];
         const float w2 = wcf * wcf;
         const float rx2 = rx * rx, ry2 = ry * ry;
-        const float gmx = W.rho2 * (rx2 / (rx2 + W.rho2)), gmy = W.rho2 * (ry2 / (ry2 + W.rho2));   // utils.py:435-438
+        const float idx = 1.0f / (rx2 + W.rho2), idy = 1.0f / (ry2 + W.rho2);
+        const float gmx = W.rho2 * (rx2 * idx), gmy = W.rho2 * (ry2 * idy);     // utils.py:435-438
         part = (double)(w2 * (gmx + gmy));
         if (want_grad) {
-            const float dx = rx2 + W.rho2, dy = ry2 + W.rho2;
-            const float gu = -w2 * W.data_w2 * (2.f * rx * W.rho2 * W.rho2 / (dx * dx));
-            const float gv = -w2 * W.data_w2 * (2.f * ry * W.rho2 * W.rho2 / (dy * dy));
-            const float gpx = f * gu / pz, gpy = f * gv / pz;
-            const float gpz = -f * (gu * px + gv * py) / (pz * pz);
+            const float gu = -w2 * W.data_w2 * (2.f * rx * W.rho2 * W.rho2 * (idx * idx));
+            const float gv = -w2 * W.data_w2 * (2.f * ry * W.rho2 * W.rho2 * (idy * idy));
+            const float gpx = f * gu * ipz, gpy = f * gv * ipz;
+            const float gpz = -f * (gu * px + gv * py) * (ipz * ipz);
             g0 = Rc[0] * gpx + Rc[3] * gpy + Rc[6] * gpz;
             g1 = Rc[1] * gpx + Rc[4] * gpy + Rc[7] * gpz;
             g2 = Rc[2] * gpx + Rc[5] * gpy + Rc[8] * gpz;
@@ -694,6 +713,15 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
         for (int w = 0; w < ndw; ++w) s += L.red_f[w][tid];
         L.gtau[tid] = s;                                                       // g_tau = sum_k g_kp
     }
+    if (want_grad && tid >= 64 && tid < 64 + NKP * 3) {
+        // g_kp[k][a] = sum over views, ascending (independent loads; the adjoint's first phase reads it
+        // after its own barrier)
+        const int i = tid - 64;
+        float s = 0.f;
+#pragma unroll
+        for (int vv = 0; vv < MVFIT_MAX_VIEWS; ++vv) if (vv < V) s += (&L.gkp_part[vv][0][0])[i];
+        (&L.gkp[0][0])[i] = s;
+    }
     return total;
 }
 
@@ -790,18 +818,27 @@ __device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, in
 __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
-    // ---- E5: g_x = Ksel^T g_kp (g_kp summed over views here) ; g_vposed = Tr^T g_x ----
+    __syncthreads();                  // L.gkp (view sums) and L.gtau are written after E4's last barrier
+    // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
     if (tid < nc_pad) {
         float v = 0.f;
         if (tid < nc) {
             const int s = tid / 3, bq = tid - 3 * s;
             float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
-            for (int t = L.M.vs_start[s]; t < L.M.vs_start[s + 1]; ++t) {
-                const int k = L.M.vs_k[t];
-                const float w = L.M.vs_w[t];
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                for (int vv = 0; vv < V; ++vv) { a0 += L.gkp_part[vv][k][0]; a1 += L.gkp_part[vv][k][1]; a2 += L.gkp_part[vv][k][2]; }
-                gx0 = fmaf(w, a0, gx0); gx1 = fmaf(w, a1, gx1); gx2 = fmaf(w, a2, gx2);
+            // g_kp[k] = sum over views (ascending) of the per-view parts: L.gkp (summed once in E4b)
+            if (L.M.padded) {
+#pragma unroll
+                for (int t = 0; t < VS_NZ; ++t) {
+                    const int k = L.M.vsp_k[s][t];
+                    const float w = L.M.vsp_w[s][t];
+                    gx0 = fmaf(w, L.gkp[k][0], gx0); gx1 = fmaf(w, L.gkp[k][1], gx1); gx2 = fmaf(w, L.gkp[k][2], gx2);
+                }
+            } else {
+                for (int t = L.M.vs_start[s]; t < L.M.vs_start[s + 1]; ++t) {
+                    const int k = L.M.vs_k[t];
+                    const float w = L.M.vs_w[t];
+                    gx0 = fmaf(w, L.gkp[k][0], gx0); gx1 = fmaf(w, L.gkp[k][1], gx1); gx2 = fmaf(w, L.gkp[k][2], gx2);
+                }
             }
             v = L.T[s][0 + bq] * gx0 + L.T[s][4 + bq] * gx1 + L.T[s][8 + bq] * gx2;
             L.gx[tid] = bq == 0 ? gx0 : (bq == 1 ? gx1 : gx2);
@@ -912,7 +949,8 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         const float rx = L.pose.theta[3 * tid], ry = L.pose.theta[3 * tid + 1], rz = L.pose.theta[3 * tid + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
         const float a = L.pose.rod[tid][0], sn = L.pose.rod[tid][1], cs = L.pose.rod[tid][2];
-        const float kx = rx / a, ky = ry / a, kz = rz / a;
+        const float ia = 1.0f / a;
+        const float kx = rx * ia, ky = ry * ia, kz = rz * ia;
         const float oc = 1.f - cs;
         const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
         float KK[9];
@@ -936,8 +974,8 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
                 gKt[i * 3 + jq] = sn * g[i * 3 + jq] + oc * (s1 + s2);
             }
         const float gkx = gKt[7] - gKt[5], gky = gKt[2] - gKt[6], gkz = gKt[3] - gKt[1];
-        ga -= (gkx * rx + gky * ry + gkz * rz) / (a * a);
-        float gth[3] = {gkx / a + ga * ex / a, gky / a + ga * ey / a, gkz / a + ga * ez / a};
+        ga -= (gkx * rx + gky * ry + gkz * rz) * (ia * ia);
+        float gth[3] = {(gkx + ga * ex) * ia, (gky + ga * ey) * ia, (gkz + ga * ez) * ia};
         if (tid > 0 && !use_vp) {
             // priors on body_pose (fitting.py:330-337)
 #pragma unroll

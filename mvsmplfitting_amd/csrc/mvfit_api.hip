@@ -612,6 +612,18 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
             }
         }
         for (int s = M.ns; s <= NS_MAX; ++s) G.vs_start[s] = nnz;
+        // fixed-length zero-padded copies (entry 0 / weight 0 pads: fmaf(0, x, acc) == acc)
+        G.padded = 1;
+        for (int k = 0; k < NKP; ++k) {
+            const int n0 = G.kp_start[k], cnt = G.kp_start[k + 1] - n0;
+            if (cnt > KP_NZ) G.padded = 0;
+            for (int t = 0; t < KP_NZ; ++t) { G.kpp_s[k][t] = t < cnt ? G.kp_s[n0 + t] : 0; G.kpp_w[k][t] = t < cnt ? G.kp_w[n0 + t] : 0.f; }
+        }
+        for (int s = 0; s < NS_MAX; ++s) {
+            const int n0 = G.vs_start[s], cnt = G.vs_start[s + 1] - n0;
+            if (cnt > VS_NZ) G.padded = 0;
+            for (int t = 0; t < VS_NZ; ++t) { G.vsp_k[s][t] = t < cnt ? G.vs_k[n0 + t] : 0; G.vsp_w[s][t] = t < cnt ? G.vs_w[n0 + t] : 0.f; }
+        }
         // per-tile lists for the vertex pass side outputs
         std::vector<int> tstart(M.ntiles + 1, 0), tlocal(std::max(M.ns, 1)), tslot(std::max(M.ns, 1));
         int pos = 0;

@@ -20,6 +20,8 @@ constexpr int NS_STRIDE = 112;    // row stride of the transposed skinning weigh
                                   // 16-lane rows of a wave hit disjoint LDS banks)
 constexpr int NC_MAX = NS_MAX * 3;
 constexpr int KNNZ_MAX = 160;     // non-zeros of the 17 x ns keypoint selection
+constexpr int KP_NZ = 12;         // padded per-keypoint list length (LSP regressor rows have 4-9 non-zeros)
+constexpr int VS_NZ = 2;          // padded per-vertex list length (a vertex usually feeds one keypoint)
 constexpr int A_STRIDE = 292;     // per-problem stride of the 24x12 skinning transforms in LDS (vertex pass)
 constexpr int STEP_NT = 512;      // threads of the per-problem kernels (8 waves)
 constexpr int STEP_NW = STEP_NT / 64;
@@ -40,6 +42,13 @@ struct ModelLds {
     int vs_start[NS_MAX + 1];         // transpose: selected vertex s feeds keypoints vs_k[t] (ascending k)
     int vs_k[KNNZ_MAX];
     float vs_w[KNNZ_MAX];
+    // the same selection as fixed-length zero-padded lists (all index loads of a thread in one LDS round
+    // trip instead of one per CSR entry); padded = 0 when a row is longer than the padding (CSR is used)
+    int kpp_s[NKP][KP_NZ];
+    float kpp_w[NKP][KP_NZ];
+    int vsp_k[NS_MAX][VS_NZ];
+    float vsp_w[NS_MAX][VS_NZ];
+    int padded, padx0, padx1, padx2;
     int parents[NJ];
     int nlevels;
     int level_start[NJ + 1];
