@@ -57,6 +57,7 @@ extern "C" {
 #define MVFIT_F_PRIOR_GMM 2u   /* body_prior_type 'gmm' (code/prior.py:100-231) instead of 'l2' */
 #define MVFIT_F_FIX_SHAPE 4u   /* fix_shape: code/utils/fitting.py:340, init_guess.py:208-210 */
 #define MVFIT_F_FIX_SCALE 8u   /* fix_scale: init_guess.py:205-207 */
+#define MVFIT_F_USE_3D 32u      /* use_3d: 3-D joint term (code/utils/fitting.py:319-324); needs mvfit_set_joints3d */
 #define MVFIT_F_SPARSE_VERTS 16u /* evaluate only the vertices the objective reads (same loss /
                                     gradient; skips the full 6890-vertex pass inside the closure) */
 
@@ -131,6 +132,10 @@ int mvfit_set_problems(mvfit_ctx* ctx, int B, int V, int cam_batched,
                        const float* cam_R /*[.,V,3,3] dev|host*/, const float* cam_t /*[.,V,3]*/,
                        const float* cam_f /*[.,V]*/, const float* cam_c /*[.,V,2]*/,
                        const float* gt_xy /*dev|host*/, const float* w_conf /*dev|host*/);
+
+/* Optional 3-D joint targets of the use_3d term (code/utils/non_linear_solver.py:86-99):
+ * gt3d[B,17,3], conf3d[B,17] (dev|host).  Call after mvfit_set_problems (which clears them). */
+int mvfit_set_joints3d(mvfit_ctx* ctx, const float* gt3d, const float* conf3d);
 
 /* One closure evaluation for all B problems: fitting_func(backward=True)
  * (code/utils/fitting.py:162-203) = SMPL.forward + SMPLifyLoss.forward + backward.

@@ -20,6 +20,7 @@ F_PRIOR_GMM = 2
 F_FIX_SHAPE = 4
 F_FIX_SCALE = 8
 F_SPARSE_VERTS = 16
+F_USE_3D = 32
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -50,7 +51,7 @@ class LbfgsOpts(C.Structure):
                 ('num_stages', C.c_int32), ('max_rounds', C.c_int32)]
 
 
-EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems',
+EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',
            'mvfit_closure', 'mvfit_vertices', 'mvfit_fit', 'mvfit_profile', 'mvfit_profile_read',
            'mvfit_lbfgs_kat']
 
@@ -75,6 +76,8 @@ def load():
     lib.mvfit_sync.restype = C.c_int
     lib.mvfit_set_problems.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.mvfit_set_problems.restype = C.c_int
+    lib.mvfit_set_joints3d.argtypes = [vp, vp, vp]
+    lib.mvfit_set_joints3d.restype = C.c_int
     lib.mvfit_closure.argtypes = [vp, C.POINTER(Weights), vp, vp, vp, vp, vp]
     lib.mvfit_closure.restype = C.c_int
     lib.mvfit_vertices.argtypes = [vp, vp, C.c_uint32, vp, vp]

@@ -36,6 +36,8 @@ struct ObsBlock {                   // per-problem observations, packed by mvfit
     float camc[MVFIT_MAX_VIEWS][2];
     float gt[MVFIT_MAX_VIEWS * NKP * 2];
     float wc[MVFIT_MAX_VIEWS * NKP];
+    float gt3d[NKP * 3];            // use_3d targets (zeros / zero confidence when unused)
+    float c3d[NKP];
 };
 struct PoseBlock {                  // everything pose_prep + the chain derive from x (handed from launch to launch)
     float theta[72];
@@ -68,6 +70,7 @@ struct ClosureLds {
     float kp[NKP][3];
     float gkp_part[MVFIT_MAX_VIEWS][NKP][3];
     float gkp[NKP][3];              // summed over views
+    float gkp3[NKP][3];             // use_3d part of d/d keypoint
     float gx[NC_MAX];
     __attribute__((aligned(16))) float gvp[NC_MAX];
     __attribute__((aligned(16))) float gG[32][12];     // adjoint of G (rows NJ.. zero)
@@ -83,7 +86,7 @@ struct ClosureLds {
     int gmm_sel;
     int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
     double total;
-    double red_d[STEP_NW];          // per-wave partial of the data term
+    double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
     __attribute__((aligned(16))) float grad[DPAD];
     // scratch for k-split partial sums: max(8 * nc_pad, 8 * KROWS)
@@ -626,6 +629,20 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
             const float s0 = wave64_sum(g0), s1 = wave64_sum(g1), s2 = wave64_sum(g2);
             if ((tid & 63) == 0) { L.red_f[wave][0] = s0; L.red_f[wave][1] = s1; L.red_f[wave][2] = s2; }
         }
+    } else if (wave == STEP_NW - 3 && (W.flags & MVFIT_F_USE_3D)) {
+        // 3-D joint term (fitting.py:319-324): sum conf3d^2 GMoF(gt3d - joints) data_weight^2, lane = (keypoint, coord)
+        const int lane = tid & 63;
+        double p3 = 0.0;
+        if (lane < NKP * 3) {
+            const int k = lane / 3;
+            const float r = L.obs.gt3d[lane] - (&L.kp[0][0])[lane];
+            const float c2 = L.obs.c3d[k] * L.obs.c3d[k];
+            const float id = 1.0f / (r * r + W.rho2);
+            p3 = (double)(c2 * (W.rho2 * (r * r * id)));
+            if (want_grad) (&L.gkp3[0][0])[lane] = -c2 * W.data_w2 * (2.f * r * W.rho2 * W.rho2 * (id * id));
+        }
+        const double s3 = wave64_sum(p3);
+        if (lane == 0) L.red_d[STEP_NW] = s3;
     } else if (wave == STEP_NW - 1) {
         // priors on the last wave: |body_pose|^2 or |z|^2, |beta|^2, angle prior
         const int lane = tid & 63;
@@ -675,7 +692,9 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
     // ---- every thread: combine (fixed order) ----
     double l_data = 0.0;
     for (int w = 0; w < ndw; ++w) l_data += L.red_d[w];
-    l_data *= (double)W.data_w2;                                               // fitting.py:311-316
+    const bool use_3d = (W.flags & MVFIT_F_USE_3D) != 0;
+    if (use_3d) l_data += L.red_d[STEP_NW];
+    l_data *= (double)W.data_w2;                                               // fitting.py:311-316, 319-324
     const double sq = L.red_d[STEP_NW - 1], sqb = L.red_d[STEP_NW - 2], san = L.red_d[STEP_NW - 3];
     const double wp2 = (double)W.pose_w * (double)W.pose_w;
     double l_pose;
@@ -711,6 +730,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
     if (want_grad && tid < 3) {
         float s = 0.f;
         for (int w = 0; w < ndw; ++w) s += L.red_f[w][tid];
+        if (use_3d) for (int k = 0; k < NKP; ++k) s += L.gkp3[k][tid];
         L.gtau[tid] = s;                                                       // g_tau = sum_k g_kp
     }
     if (want_grad && tid >= 64 && tid < 64 + NKP * 3) {
@@ -720,6 +740,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
         float s = 0.f;
 #pragma unroll
         for (int vv = 0; vv < MVFIT_MAX_VIEWS; ++vv) if (vv < V) s += (&L.gkp_part[vv][0][0])[i];
+        if (use_3d) s += (&L.gkp3[0][0])[i];
         (&L.gkp[0][0])[i] = s;
     }
     return total;

@@ -74,6 +74,13 @@ __global__ void pack_obs_kernel(DevProblems Q, ObsBlock* __restrict__ obs) {
     for (int i = threadIdx.x; i < V * NKP; i += blockDim.x) O.wc[i] = Q.w_conf[(size_t)b * V * NKP + i];
 }
 
+__global__ void pack_joints3d_kernel(const float* __restrict__ gt3d, const float* __restrict__ conf3d,
+                                     ObsBlock* __restrict__ obs) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < NKP * 3; i += blockDim.x) obs[b].gt3d[i] = gt3d[(size_t)b * NKP * 3 + i];
+    for (int i = threadIdx.x; i < NKP; i += blockDim.x) obs[b].c3d[i] = conf3d[(size_t)b * NKP + i];
+}
+
 __global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBlock* __restrict__ obs, DevPose P,
                                                        const float* __restrict__ params, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -438,6 +445,7 @@ struct mvfit_ctx {
     int* h_done = nullptr;             // pinned
     int ksplit = 4;
     bool has_vposer = false;
+    bool has_joints3d = false;
     int gmm_M = 0;
     // full-mode round loop captured as a graph: key = everything baked into the kernel nodes
     hipGraphExec_t round_graph = nullptr;
@@ -831,12 +839,31 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
     HIP_OK(c, hipMemcpyAsync(c->d_wc, w_conf, (size_t)B * V * NKP * 4, hipMemcpyDefault, c->stream));
     c->Q = DevProblems{B, V, cam_batched ? 1 : 0, c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc};
     hipLaunchKernelGGL(pack_obs_kernel, dim3(B), dim3(256), 0, c->stream, c->Q, c->d_obs);
+    c->has_joints3d = false;
     HIP_OK(c, hipGetLastError());
     HIP_OK(c, hipStreamSynchronize(c->stream));
     return MVFIT_OK;
 }
 
+extern "C" int mvfit_set_joints3d(mvfit_ctx* c, const float* gt3d, const float* conf3d) {
+    if (!c || !gt3d || !conf3d) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    HIP_OK(c, hipSetDevice(c->device));
+    float *d3 = nullptr, *c3 = nullptr;
+    HIP_OK(c, hipMalloc(&d3, (size_t)c->B * NKP * 3 * 4));
+    HIP_OK(c, hipMalloc(&c3, (size_t)c->B * NKP * 4));
+    HIP_OK(c, hipMemcpyAsync(d3, gt3d, (size_t)c->B * NKP * 3 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c3, conf3d, (size_t)c->B * NKP * 4, hipMemcpyDefault, c->stream));
+    hipLaunchKernelGGL(pack_joints3d_kernel, dim3(c->B), dim3(64), 0, c->stream, (const float*)d3, (const float*)c3, c->d_obs);
+    HIP_OK(c, hipGetLastError());
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    hipFree(d3); hipFree(c3);
+    c->has_joints3d = true;
+    return MVFIT_OK;
+}
+
 static int check_flags(mvfit_ctx* c, uint32_t flags) {
+    if ((flags & MVFIT_F_USE_3D) && !c->has_joints3d) return fail(c, MVFIT_E_STATE, "MVFIT_F_USE_3D set but mvfit_set_joints3d was not called");
     if ((flags & MVFIT_F_VPOSER) && !c->has_vposer) return fail(c, MVFIT_E_STATE, "MVFIT_F_VPOSER set but the model has no VPoser decoder");
     if ((flags & MVFIT_F_PRIOR_GMM) && c->gmm_M == 0) return fail(c, MVFIT_E_STATE, "MVFIT_F_PRIOR_GMM set but the model has no GMM");
     return MVFIT_OK;

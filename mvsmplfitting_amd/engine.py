@@ -149,6 +149,12 @@ class MvFit:
             gt.data_ptr(), wc.data_ptr()))
         self.B, self.V = B, V
 
+    def set_joints3d(self, gt3d, conf3d):
+        """use_3d targets: gt3d[B,17,3], conf3d[B,17] (reference non_linear_solver.py:86-99)."""
+        g = self._dev(gt3d, (self.B, 17, 3))
+        c = self._dev(conf3d, (self.B, 17))
+        self._check(self._lib.mvfit_set_joints3d(self._ctx, g.data_ptr(), c.data_ptr()))
+
     # ------------------------------------------------------------------ compute
     def closure(self, params, weights: dict, want_grad=True, want_verts=False, want_joints=False):
         """One closure evaluation of all B problems.  params [B,118] (tensor or array).

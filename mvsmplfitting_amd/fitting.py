@@ -110,8 +110,7 @@ class SMPLifyLoss:
                  use_joints_conf=True, interpenetration=False, dtype=torch.float32, data_weight=1.0,
                  body_pose_weight=0.0, shape_weight=0.0, bending_prior_weight=0.0,
                  coll_loss_weight=0.0, reduction='sum', use_3d=False, **kwargs):
-        if use_3d:
-            raise NotImplementedError('use_3d (3-D joint term, fitting.py:319-324) is not built in libmvfit yet')
+        self.use_3d = bool(use_3d)
         self.rho = float(rho)
         self.body_pose_prior = body_pose_prior
         self.shape_prior = shape_prior
@@ -190,7 +189,7 @@ class _HipClosure:
     """``fitting_func`` of reference fitting.py:162-203 for one (subject, frame) problem."""
 
     def __init__(self, optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
-                 use_vposer, vposer, pose_embedding):
+                 use_vposer, vposer, pose_embedding, gt_joints3d=None, joints3d_conf=None):
         self.optimizer, self.body_model, self.loss = optimizer, body_model, loss
         self.use_vposer, self.pose_embedding = use_vposer, pose_embedding
         eng = getattr(body_model, '_mvfit_engine', None)
@@ -218,6 +217,11 @@ class _HipClosure:
         if use_vposer:
             self.params['pose_embedding'] = pose_embedding
         self.flags = (_lib.F_VPOSER if use_vposer else 0)
+        if loss.use_3d:                                  # fitting.py:319-324
+            g3 = torch.as_tensor(gt_joints3d, dtype=torch.float32, device=dev).reshape(1, 17, 3)
+            c3 = torch.as_tensor(joints3d_conf, dtype=torch.float32, device=dev).reshape(1, 17)
+            eng.set_joints3d(g3, c3)
+            self.flags |= _lib.F_USE_3D
         if isinstance(loss.body_pose_prior, object) and hasattr(loss.body_pose_prior, 'precisions'):
             self.flags |= _lib.F_PRIOR_GMM
         if not self.params['betas'].requires_grad or loss.fix_shape:
@@ -265,7 +269,7 @@ class FittingMonitor:
         if create_graph:
             raise NotImplementedError('create_graph=True (second-order optimisers) is not supported')
         return _HipClosure(optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
-                           use_vposer, vposer, pose_embedding)
+                           use_vposer, vposer, pose_embedding, gt_joints3d, joints3d_conf)
 
     def run_fitting(self, optimizer, closure, params, body_model, use_vposer=True, pose_embedding=None,
                     vposer=None, camera=None, img_path=None, **kwargs):

@@ -279,7 +279,7 @@ class ClosureOracle:
 
     # -- SMPLifyLoss.forward: fitting.py:290-415 (no SDF term here; see oracle/sdf_np.py)
     def loss_terms(self, out, cams, gt_xy, w_conf, wts, use_vposer, pose_embedding=None,
-                   prior=PRIOR_L2, fix_shape=False, beta=None):
+                   prior=PRIOR_L2, fix_shape=False, beta=None, joints3d=None):
         dt = self.dtype
         cam_R, cam_t, cam_f, cam_c = (np.asarray(a, dt) for a in cams)
         kp = out['joints']
@@ -292,6 +292,12 @@ class ClosureOracle:
         gm = rho2 * r2 / (r2 + rho2)                                          # utils.py:435-438
         w2 = (np.asarray(w_conf, dt) ** 2)[..., None]
         L_data = (w2 * gm).sum() * dw2                                        # fitting.py:311-316
+        r3 = None
+        if joints3d is not None:                                              # fitting.py:319-324 (use_3d)
+            gt3d, conf3d = joints3d
+            r3 = np.asarray(gt3d, dt) - kp
+            gm3 = rho2 * r3 * r3 / (r3 * r3 + rho2)
+            L_data = L_data + ((np.asarray(conf3d, dt) ** 2)[:, None] * gm3).sum() * dw2
         wp = dt(wts['body_pose_weight'])
         bp = out['body_pose']
         gmm_sel = -1
@@ -325,11 +331,11 @@ class ClosureOracle:
             L_angle = dt(0.0)
         total = L_data + L_pose + L_shape + L_angle
         return total, dict(L_data=L_data, L_pose=L_pose, L_shape=L_shape, L_angle=L_angle,
-                           p=p, uv=uv, r=r, pose_dropped=pose_dropped,
+                           p=p, uv=uv, r=r, r3=r3, pose_dropped=pose_dropped,
                            angle_dropped=angle_dropped, gmm_sel=gmm_sel)
 
     def closure(self, x_flat, cams, gt_xy, w_conf, wts, use_vposer=False, prior=PRIOR_L2,
-                fix_shape=False, g_verts_extra=None):
+                fix_shape=False, g_verts_extra=None, joints3d=None):
         """loss, grad[D], out   for one problem.  ``g_verts_extra`` [6890,3] optionally adds
         an external dL/dvertices (used by the SDF term's oracle)."""
         dt = self.dtype
@@ -339,14 +345,14 @@ class ClosureOracle:
         out = self.body(p)
         z = p.get('pose_embedding')
         total, aux = self.loss_terms(out, cams, gt_xy, w_conf, wts, use_vposer, z, prior,
-                                     fix_shape, p['betas'])
+                                     fix_shape, p['betas'], joints3d=joints3d)
         grad = self._backward(out, aux, cams, w_conf, wts, use_vposer, z, prior, fix_shape,
-                              g_verts_extra)
+                              g_verts_extra, joints3d=joints3d)
         return total, grad, out
 
     # -- reverse mode (hand-derived; replaces autograd of fitting.py:190-192)
     def _backward(self, out, aux, cams, w_conf, wts, use_vposer, z, prior, fix_shape,
-                  g_verts_extra=None):
+                  g_verts_extra=None, joints3d=None):
         dt = self.dtype
         beta, theta, tau, s, J, R, rc, v_posed, Rm, tm, Gr, Gt, Tr, cache_vp = out['_cache']
         cam_R, cam_t, cam_f, cam_c = (np.asarray(a, dt) for a in cams)
@@ -363,6 +369,10 @@ class ClosureOracle:
                         -f * (g_uv[..., 0] * p[..., 0] + g_uv[..., 1] * p[..., 1]) / (pz * pz)],
                        axis=-1)
         g_kp = np.einsum('vab,vka->kb', cam_R, g_p)                           # [17,3]
+        if joints3d is not None:
+            r3 = aux['r3']
+            c2 = (np.asarray(joints3d[1], dt) ** 2)[:, None]
+            g_kp = g_kp - c2 * dw2 * 2.0 * r3 * rho2 * rho2 / (r3 * r3 + rho2) ** 2
         g_tau = g_kp.sum(0)
         gx = self.Ksel.T @ g_kp                                               # [Nv,3]
         if g_verts_extra is not None:

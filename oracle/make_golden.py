@@ -58,6 +58,7 @@ CASES = {
                          vp=dict(seed=12, gain=4.0, identity_bias=False)),
     'l2_fixshape_v8': dict(use_vposer=False, prior='l2', stage=1, V=8, sig=0.15, fix_shape=True),
     'l2_angle_drop_v8': dict(use_vposer=False, prior='l2', stage=0, V=8, sig=0.15, big_knee=True),
+    'l2_3d_v8': dict(use_vposer=False, prior='l2', stage=1, V=8, sig=0.15, use_3d=True),
 }
 B_CASE = 4
 
@@ -72,7 +73,7 @@ def build_case(name, cfg, lsp):
                            gmm=None if gmm is None else syn.gmm_constants(gmm, np.float64))
     frames = syn.make_frames(B_CASE, seed0=2000 + sum(map(ord, name)))
     lay, D = cn.param_layout(use_vp)
-    xs, gts, confs = [], [], []
+    xs, gts, confs, j3s = [], [], [], []
     for b in range(B_CASE):
         p = {k: frames[k][b] for k in frames}
         p['use_vposer'] = False
@@ -91,12 +92,20 @@ def build_case(name, cfg, lsp):
             a0 = lay['body_pose'][0]
             x[a0 + 9] = -6.0       # exp(2*6)*w_bend > 1e4  -> angle prior dropped (fitting.py:349)
         xs.append(x); gts.append(gt); confs.append(cf)
-    return model, cams, vpw, gmm, np.asarray(xs), np.asarray(gts), np.asarray(confs)
+        if cfg.get('use_3d'):      # gt_joints3d [17,3] + joints3d_conf [17] (non_linear_solver.py:86-99)
+            r3 = np.random.default_rng(700 + b)
+            c3 = r3.uniform(0.2, 1.0, 17)
+            c3[11] = c3[12] = 0.0                      # the hips are zeroed (non_linear_solver.py:92-94)
+            j3s.append(np.concatenate([out['joints'] + r3.normal(0, 0.04, (17, 3)), c3[:, None]], 1))
+    j3 = np.asarray(j3s) if j3s else None
+    return model, cams, vpw, gmm, np.asarray(xs), np.asarray(gts), np.asarray(confs), j3
 
 
-def gen_closure_goldens(lsp):
+def gen_closure_goldens(lsp, only=None):
     for name, cfg in CASES.items():
-        model, cams, vpw, gmm, xs, gts, confs = build_case(name, cfg, lsp)
+        if only and name not in only:
+            continue
+        model, cams, vpw, gmm, xs, gts, confs, j3 = build_case(name, cfg, lsp)
         wts = stage_weights(cfg['stage'])
         res = {}
         for dtn in ('float64', 'float32'):
@@ -104,7 +113,8 @@ def gen_closure_goldens(lsp):
             for b in range(B_CASE):
                 rp = ri.RefProblem(model, cams, gts[b], confs[b], dtn, use_vposer=cfg['use_vposer'],
                                    vposer_weights=vpw, prior=cfg['prior'], gmm=gmm,
-                                   fix_shape=cfg.get('fix_shape', False))
+                                   fix_shape=cfg.get('fix_shape', False),
+                                   joints3d=None if j3 is None else (j3[b][:, :3], j3[b][:, 3]))
                 if cfg.get('fix_shape'):
                     rp.smpl.betas.requires_grad = False     # init_guess.py:205-210
                 x = xs[b]
@@ -126,6 +136,8 @@ def gen_closure_goldens(lsp):
                    loss32=res['float32'][0], grad32=res['float32'][1],
                    joints32=res['float32'][2].astype(np.float32),
                    model_checksum=np.array(syn.model_checksum(model)))
+        if j3 is not None:
+            out['joints3d'] = j3.astype(np.float32)
         np.savez_compressed(os.path.join(GOLD, 'closure_%s.npz' % name), **out)
         e_l = np.abs(res['float32'][0] - res['float64'][0]) / np.abs(res['float64'][0])
         print('%-18s loss64 %s  fp32-vs-fp64 rel %.1e' % (name, res['float64'][0], e_l.max()))

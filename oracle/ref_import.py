@@ -94,7 +94,7 @@ class RefProblem:
 
     def __init__(self, model: dict, cams, gt_xy, conf, dtype='float64', use_vposer=False,
                  vposer_weights=None, prior='l2', gmm=None, fix_shape=False, rho=100.0,
-                 joint_weights=None):
+                 joint_weights=None, joints3d=None):
         import torch
         ref = load()
         self.ref = ref
@@ -160,7 +160,12 @@ class RefProblem:
         self.loss = ref.fitting.create_loss(
             loss_type='smplify', rho=rho, use_joints_conf=True, body_pose_prior=body_prior,
             shape_prior=shape_prior, angle_prior=angle_prior, interpenetration=False,
-            dtype=dt, use_3d=False, fix_shape=fix_shape)
+            dtype=dt, use_3d=joints3d is not None, fix_shape=fix_shape)
+        self.use_3d = joints3d is not None
+        self.gt_joints3d = self.joints3d_conf = None
+        if joints3d is not None:      # non_linear_solver.py:86-99: gt_joints3d [17,3], joints3d_conf [1,17]
+            self.gt_joints3d = torch.tensor(np.asarray(joints3d[0]), dtype=dt)
+            self.joints3d_conf = torch.tensor(np.asarray(joints3d[1]), dtype=dt).reshape(1, -1)
         self.gt_joints = torch.tensor(np.asarray(gt_xy)[:, None, :, :], dtype=dt)   # [V,1,17,2]
         self.joints_conf = [torch.tensor(np.asarray(conf)[v][None, :], dtype=dt)
                             for v in range(cam_R.shape[0])]
@@ -199,9 +204,10 @@ class RefProblem:
         return self.monitor.create_fitting_closure(
             optimizer, self.smpl, camera=self.cameras, gt_joints=self.gt_joints,
             joints_conf=self.joints_conf, joint_weights=self.joint_weights, loss=self.loss,
+            gt_joints3d=self.gt_joints3d, joints3d_conf=self.joints3d_conf,
             create_graph=False, use_vposer=self.use_vposer, vposer=self.vposer,
             pose_embedding=self.pose_embedding, return_verts=True, return_full_pose=True,
-            use_3d=False)
+            use_3d=self.use_3d)
 
     def eval_closure(self, x, wts):
         """loss, grad, vertices, joints at flat params x (the reference's own code path)."""

@@ -32,6 +32,8 @@ def flags_for(cfg):
         f |= _lib.F_PRIOR_GMM
     if cfg.get('fix_shape'):
         f |= _lib.F_FIX_SHAPE
+    if cfg.get('use_3d'):
+        f |= _lib.F_USE_3D
     return f
 
 

@@ -13,8 +13,9 @@ def test_oracle_matches_reference_golden(name):
     prior = cn.PRIOR_GMM if cfg['prior'] == 'gmm' else cn.PRIOR_L2
     fix_shape = cfg.get('fix_shape', False)
     for b in range(g['x'].shape[0]):
+        j3 = (g['joints3d'][b][:, :3], g['joints3d'][b][:, 3]) if 'joints3d' in g else None
         L, grad, out = orc.closure(g['x'][b], cams, g['gt_xy'][b], g['conf'][b], wts,
-                                   use_vposer=cfg['use_vposer'], prior=prior, fix_shape=fix_shape)
+                                   use_vposer=cfg['use_vposer'], prior=prior, fix_shape=fix_shape, joints3d=j3)
         assert abs(L - g['loss64'][b]) <= 1e-12 * abs(g['loss64'][b])
         gref = g['grad64'][b]
         gmine = grad[10:] if fix_shape else grad

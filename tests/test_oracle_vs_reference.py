@@ -32,3 +32,28 @@ def test_live_reference_fp64(use_vp):
     assert np.abs(g - gr).max() <= 1e-11 * np.abs(gr).max()
     assert np.abs(out['vertices'] - vr).max() < 1e-13
     assert np.abs(out['joints'] - jr).max() < 1e-13
+
+
+def test_live_reference_3d_joint_term():
+    """use_3d (fitting.py:319-324): oracle vs the reference with gt_joints3d / joints3d_conf."""
+    model = body_model()
+    cams = syn.make_camera_ring(4)
+    orc = cn.ClosureOracle(model, np.float64)
+    fr = syn.make_frames(1, seed0=77)
+    p = {k: fr[k][0] for k in fr}
+    p['use_vposer'] = False
+    kp = orc.body(p, want_cache=False)['joints']
+    gt, cf = syn.make_observations(kp[None], cams, seed=2)
+    rng = np.random.default_rng(9)
+    j3 = (kp + rng.normal(0, 0.05, kp.shape), rng.uniform(0.2, 1.0, 17))
+    lay, D = cn.param_layout(False)
+    x = rng.normal(0, 0.2, D)
+    x[lay['scale'][0]] = 1.05
+    wts = stage_weights(1)
+    L, g, out = orc.closure(x, cams, gt[0], cf[0], wts, joints3d=j3)
+    rp = ri.RefProblem(model, cams, gt[0], cf[0], 'float64', joints3d=j3)
+    Lr, gr, vr, jr = rp.eval_closure(x, wts)
+    assert abs(L - Lr) <= 1e-13 * abs(Lr)
+    assert np.abs(g - gr).max() <= 1e-11 * np.abs(gr).max()
+    L0, _, _ = orc.closure(x, cams, gt[0], cf[0], wts)
+    assert L > L0          # the term is really there
