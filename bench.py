@@ -141,8 +141,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.fit(x0_d, stages)
+    for _ in range(max(args.warmup, 1) if args.warmup else 0):
+        _, st = eng.fit(x0_d, stages)
+    # torch loads its own reduction / copy kernels lazily on first use (~80 ms): touch the exact ops of
+    # the timed loop once here (also with --warmup 0), so that module loading is not billed to a fit
+    _z = torch.zeros(B, device=dev, dtype=torch.int32)
+    int(_z.sum().item()); int(_z.max().item())
     barrier()
     t0 = time.perf_counter()
     n_closure = 0
