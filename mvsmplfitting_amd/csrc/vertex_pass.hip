@@ -38,13 +38,15 @@ constexpr int VP_NT = 512;
 constexpr int VP_KSPLIT = 4;
 constexpr int VP_GPS = KGROUPS / VP_KSPLIT;      // 7 groups of 4 k-steps per slice
 
-__global__ __launch_bounds__(VP_NT) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
+// one workgroup per CU (LDS-limited): 2 waves per SIMD, so let the allocator use 256 VGPRs instead of
+// spilling to keep a third wave possible
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
                                                                 float* __restrict__ verts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* coefT_l = smem;                          // [KROWS][32]
     float* A_l = coefT_l + KROWS * 32;              // [32][A_STRIDE]
-    float* Wt_l = A_l + 32 * A_STRIDE;              // [24][32]
-    float* tau_l = Wt_l + NJ * 32;                  // [32][4]
+    float* Wt_l = A_l + 32 * A_STRIDE;              // [4 copies][24][32]
+    float* tau_l = Wt_l + 4 * NJ * 32;              // [32][4]
     float* part = tau_l + 32 * 4;                   // [KSPLIT][3][32][33]
     float* out_l = part + VP_KSPLIT * 3 * 32 * 33;  // [32 b][96]  skinned positions before "+ transl"
     float* vps_l = out_l + 32 * 96;                 // [32 b][96]  v_posed (only read for the side outputs)
@@ -62,49 +64,89 @@ __global__ __launch_bounds__(VP_NT) void lbs_vertex_pass_kernel(DevModel M, DevP
     const long long t_start = 0;
 #endif
 
-    // ---- contraction waves: the whole HBM stream of the wave goes out first ----
-    float4 bv[3][VP_GPS];
+    // Issue order of a wave: (contraction waves only) v_template row, coefficient slice, the 21 KiB basis
+    // stream; then (every wave) the skinning operands of its own blend items.  Each wave stages only what
+    // it reads itself (wave-private LDS regions), so there is no workgroup barrier before the compute phase.
+    // While the basis stream is in flight ALL eight waves run the skinning blend T = W . A on the VALU
+    // (the contraction waves would otherwise just wait for HBM); then waves 0-3 run the MFMA chain.
+    // Blend item of a thread: vertices {2 vp, 2 vp + 1} x problem bb, all three rows of T (24 accumulators).
+    const int vp2 = tid & 15, bb = tid >> 4;              // wave w blends problems [4 w, 4 w + 4)
     float vt_init[3] = {0.f, 0.f, 0.f};
+    float4 bv[3][VP_GPS];
+    float4 c40, c41, c42, c43, c44, c45, c46;
+    constexpr int SL4 = (KROWS / VP_KSPLIT) * 32 / 4;     // 448 float4 per coefficient slice
+    float4* cdst = reinterpret_cast<float4*>(coefT_l) + (wave & 3) * SL4;
     if (mfma_role) {
 #pragma unroll
-        for (int kc = 0; kc < 3; ++kc) {
-            const float4* bsrc = reinterpret_cast<const float4*>(M.bs4) +
-                                 ((size_t)(tile * 3 + kc) * KGROUPS + wave * VP_GPS) * 64 + lane;
+        for (int kc = 0; kc < 3; ++kc) vt_init[kc] = (wave == 0) ? M.vt_planes[kc * M.nv_pad + tile * TILE_V + (lane & 31)] : 0.f;
+        const float4* csrc = reinterpret_cast<const float4*>(P.coefT + (size_t)chunk * KROWS * 32) + wave * SL4;
+        c40 = csrc[lane]; c41 = csrc[lane + 64]; c42 = csrc[lane + 128]; c43 = csrc[lane + 192];
+        c44 = csrc[lane + 256]; c45 = csrc[lane + 320]; c46 = csrc[lane + 384];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < VP_GPS; ++g) bv[kc][g] = bsrc[g * 64];
-            if (wave == 0) vt_init[kc] = M.vt_planes[kc * M.nv_pad + tile * TILE_V + (lane & 31)];
-        }
+        for (int g = 0; g < VP_GPS; ++g)
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc)
+                bv[kc][g] = (reinterpret_cast<const float4*>(M.bs4) + ((size_t)(tile * 3 + kc) * KGROUPS + wave * VP_GPS) * 64 + lane)[g * 64];
+        __builtin_amdgcn_sched_barrier(0);
     }
-
-    // ---- stage the per-chunk operands in LDS: loads first, then the LDS writes ----
+    // copy (wave & 3) of the tile's weights: waves w and w + 4 write the identical words to the same copy,
+    // so each may read right after its own writes without waiting for the other
+    float* Wt_w = Wt_l + (wave & 3) * NJ * 32;
     {
-        const float4* csrc = reinterpret_cast<const float4*>(P.coefT + (size_t)chunk * KROWS * 32);
-        const float4* asrc4 = reinterpret_cast<const float4*>(P.Amat + (size_t)b0 * 288);   // Bpad rows exist
-        float4 c4[4], a4[5];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int i = tid + r * VP_NT; c4[r] = i < KROWS * 8 ? csrc[i] : make_float4(0, 0, 0, 0); }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) { const int i = tid + r * VP_NT; a4[r] = i < 32 * 72 ? asrc4[i] : make_float4(0, 0, 0, 0); }
-        float4 w4 = make_float4(0, 0, 0, 0), t4 = w4;
-        if (tid < NJ * 8) w4 = reinterpret_cast<const float4*>(M.wt_tiles + (size_t)tile * NJ * 32)[tid];
-        if (tid < 32) t4 = reinterpret_cast<const float4*>(P.tau + (size_t)b0 * 4)[tid];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int i = tid + r * VP_NT; if (i < KROWS * 8) reinterpret_cast<float4*>(coefT_l)[i] = c4[r]; }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int i = tid + r * VP_NT;
-            if (i < 32 * 72) { const int b = i / 72, q = i - b * 72; *reinterpret_cast<float4*>(A_l + b * A_STRIDE + 4 * q) = a4[r]; }
+        // A of this wave's 4 problems: 4 x 72 float4 = 288 -> 5 per lane (last partial); W: 192 float4 -> 3 per lane
+        const float4* asrc4 = reinterpret_cast<const float4*>(P.Amat + (size_t)(b0 + 4 * wave) * 288);   // Bpad rows exist
+        const float4* wsrc = reinterpret_cast<const float4*>(M.wt_tiles + (size_t)tile * NJ * 32);
+        // (named registers, not arrays: with the sched_barriers the allocator otherwise parks them in scratch)
+        const float4 a40 = asrc4[lane], a41 = asrc4[lane + 64], a42 = asrc4[lane + 128], a43 = asrc4[lane + 192],
+                     a44 = asrc4[min(lane + 256, 287)];
+        const float4 w40 = wsrc[lane], w41 = wsrc[lane + 64], w42 = wsrc[lane + 128];
+        if (wave == 7 && lane < 32) reinterpret_cast<float4*>(tau_l)[lane] = reinterpret_cast<const float4*>(P.tau + (size_t)b0 * 4)[lane];
+        __builtin_amdgcn_sched_barrier(0);
+        if (mfma_role) {      // counted waits: the coefficient slice has landed while 21 + 8 younger loads are in flight
+            cdst[lane] = c40; cdst[lane + 64] = c41; cdst[lane + 128] = c42; cdst[lane + 192] = c43;
+            cdst[lane + 256] = c44; cdst[lane + 320] = c45; cdst[lane + 384] = c46;
         }
-        if (tid < NJ * 8) reinterpret_cast<float4*>(Wt_l)[tid] = w4;
-        if (tid < 32) reinterpret_cast<float4*>(tau_l)[tid] = t4;
+        auto put_a = [&](int i, const float4& v) {
+            if (i < 288) { const int b = i / 72, q = i - b * 72; *reinterpret_cast<float4*>(A_l + (4 * wave + b) * A_STRIDE + 4 * q) = v; }
+        };
+        put_a(lane, a40); put_a(lane + 64, a41); put_a(lane + 128, a42); put_a(lane + 192, a43); put_a(lane + 256, a44);
+        reinterpret_cast<float4*>(Wt_w)[lane] = w40;
+        reinterpret_cast<float4*>(Wt_w)[lane + 64] = w41;
+        reinterpret_cast<float4*>(Wt_w)[lane + 128] = w42;
     }
-    VP_T(0, t_start);
-    __syncthreads();
+    wave_lds_fence();
     VP_T(1, t_start);
-
-    // skinning item of a blend thread: 4 vertices x 1 problem, all three rows of T
-    const int bt = tid - 256, vg = bt & 7, bb = bt >> 3;
-    float tr[3][4][4];
+    // ---- skinning blend T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213), all waves ----
+    float tr[3][2][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+    {
+        const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll 4
+        for (int j = 0; j < NJ; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
+            const float wv[2] = {w.x, w.y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
+                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
+                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
+                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
+                }
+            }
+        }
+    }
+    VP_T(2, t_start);
+    // (A workgroup barrier here - blend everywhere first, then MFMA - was measured slower: the fp32 MFMA
+    // chain and the VALU blend compete for the same FMA units either way, and overlap hides the skew.)
     if (mfma_role) {
         // ---- blendshape contraction: k-slice `wave` of the three coordinate planes ----
         floatx16 acc[3];
@@ -138,54 +180,26 @@ __global__ __launch_bounds__(VP_NT) void lbs_vertex_pass_kernel(DevModel M, DevP
                 pdst[b * 33] = acc[kc][r];
             }
         }
-    } else {
-        // ---- skinning blend T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213) ----
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
-        const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll 2
-        for (int j = 0; j < NJ; ++j) {
-            const float4 w = *reinterpret_cast<const float4*>(Wt_l + j * 32 + 4 * vg);
-            const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
-                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
-                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
-                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
-                }
-            }
-        }
     }
-    VP_T(2, t_start);
-    __syncthreads();
     VP_T(3, t_start);
+    __syncthreads();
 
-    // ---- blend waves: combine the k-slices (fixed order) and apply T ----
-    if (!mfma_role) {
+    // ---- all waves: combine the k-slices (fixed order) and apply T ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = 4 * vg + i;
-            float vp[3];
+    for (int i = 0; i < 2; ++i) {
+        const int v = 2 * vp2 + i;
+        float vp[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float sm = part[((0 * 3 + k) * 32 + bb) * 33 + v];
+        for (int k = 0; k < 3; ++k) {
+            float sm = part[((0 * 3 + k) * 32 + bb) * 33 + v];
 #pragma unroll
-                for (int q = 1; q < VP_KSPLIT; ++q) sm += part[((q * 3 + k) * 32 + bb) * 33 + v];
-                vp[k] = sm;
-            }
+            for (int q = 1; q < VP_KSPLIT; ++q) sm += part[((q * 3 + k) * 32 + bb) * 33 + v];
+            vp[k] = sm;
+        }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
-                vps_l[bb * 96 + v * 3 + k] = vp[k];
-            }
+        for (int k = 0; k < 3; ++k) {
+            out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+            vps_l[bb * 96 + v * 3 + k] = vp[k];
         }
     }
     VP_T(4, t_start);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(VP_NT) void lbs_vertex_pass_kernel(DevModel M, DevP
 }
 
 size_t vertex_pass_lds_bytes() {
-    return sizeof(float) * (size_t)(KROWS * 32 + 32 * A_STRIDE + NJ * 32 + 32 * 4 +
+    return sizeof(float) * (size_t)(KROWS * 32 + 32 * A_STRIDE + 4 * NJ * 32 + 32 * 4 +
                                     VP_KSPLIT * 3 * 32 * 33 + 2 * 32 * 96);
 }
 
