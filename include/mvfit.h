@@ -157,6 +157,15 @@ int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint
 int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
 
+/* The SDF voxelisation op (reference sdf/sdf/sdf.py:21-26 -> sdf_cuda.cpp:14-28 -> sdf_cuda_kernel.cu:242-335):
+ *   faces[num_faces,3] int32 dev ; vertices[B,num_vertices,3] dev, coordinates in [-1,1] ; phi[B,G,G,G] dev out
+ *   (phi[b,k,j,i]: i fastest = x).  num_faces is the caller's faces.size(0), exactly as the reference launcher
+ *   takes it (sdf_cuda_kernel.cu:314; the reference's own call site passes a [1,F,3] tensor, i.e. ONE triangle).
+ * Stand-alone op: the collision term of the loss (code/utils/fitting.py:352-393) is not wired into
+ * mvfit_closure yet (coll_loss_weight > 0 is rejected). */
+int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* vertices, int B,
+              int num_vertices, int G, float* phi);
+
 /* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
  * the last call, measured with hipEvents on the ctx stream; *launches = number measured.
  * Enable with mvfit_profile(ctx, 1) (adds two event records per launch). */

@@ -25,6 +25,8 @@ namespace mvfit {
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream);
 hipError_t vertex_pass_configure();
+hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
+                               float* phi, hipStream_t stream);
 
 struct StageWeights { DevWeights w[MVFIT_MAX_STAGES]; };
 
@@ -1086,6 +1088,17 @@ extern "C" int mvfit_debug_timing(long long* out32, int reset) {
     return 0;
 }
 #endif
+
+extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices,
+                         int G, float* phi) {
+    if (!c) return MVFIT_E_ARG;
+    if (!faces || !vertices || !phi || num_faces < 0 || B <= 0 || num_vertices <= 0 || G < 2 || G > 1024)
+        return fail(c, MVFIT_E_ARG, "mvfit_sdf: bad argument (num_faces=%d B=%d num_vertices=%d G=%d)", num_faces, B, num_vertices, G);
+    HIP_OK(c, hipSetDevice(c->device));
+    hipError_t e = launch_sdf_voxelize(faces, num_faces, vertices, B, num_vertices, G, phi, c->stream);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
 
 extern "C" int mvfit_profile(mvfit_ctx* c, int enable) {
     if (!c) return MVFIT_E_ARG;

@@ -200,6 +200,19 @@ class MvFit:
         self._check(rc)
         return x, dict(final_loss=final, n_closure=ncl, n_iter=nit)
 
+    def sdf(self, faces, vertices, grid_size=32):
+        """phi[B,G,G,G] of the SDF voxelisation op (include/mvfit.h:mvfit_sdf).  faces: int tensor whose
+        size(0) is taken as the number of triangles, like the reference binding does."""
+        f = faces if isinstance(faces, torch.Tensor) else torch.as_tensor(np.asarray(faces))
+        f = f.to(device=self.device, dtype=torch.int32).contiguous()
+        v = self._dev(vertices)
+        if v.dim() != 3 or v.shape[2] != 3:
+            raise MvFitError('vertices must be [B, Nv, 3]')
+        phi = torch.zeros(v.shape[0], grid_size, grid_size, grid_size, device=self.device)
+        self._check(self._lib.mvfit_sdf(self._ctx, f.data_ptr(), int(f.shape[0]), v.data_ptr(), int(v.shape[0]),
+                                        int(v.shape[1]), int(grid_size), phi.data_ptr()))
+        return phi
+
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):
         self._check(self._lib.mvfit_profile(self._ctx, 1 if enable else 0))
