@@ -5,22 +5,19 @@
 // "+ transl" of SMPL.forward (code/smplx/body_models_scale.py:401-403); the joint regression
 // J(beta) and the kinematic chain (lbs.py:183,205) are done per problem by the step kernel.
 //
-// MI355X mapping
-//   * one workgroup = one tile of 32 vertices x one chunk of 32 problems; 8 waves with two roles,
-//     one wave of each role per SIMD (matrix pipe and VALU are separate pipes and run concurrently):
-//       waves 0-3 "contraction": the blendshape contraction [32 problems x 224] . [224 x 32 verts x 3]
-//         on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  Wave w owns
-//         k-slice w (56 of the 224 rows) of all three coordinate planes: 3 accumulators, 84 MFMAs.  The
-//         basis is pre-tiled in HBM in B-operand order so every wave load is one contiguous 1 KiB
-//         global_load_dwordx4 covering 4 k-steps; all 21 loads of a wave are issued before anything
-//         else, so the HBM stream overlaps the operand staging; each basis element is read once per chunk.
-//       waves 4-7 "blend": the skinning transforms T = W . A (32 problems x 32 vertices x 12 entries x 24
-//         joints, 295 kFMA) on the VALU while the MFMAs run, kept in registers (48 per thread).
-//   * k-slice partials meet in LDS in a fixed order (deterministic); the blend waves add them up and
-//     apply their T; all waves store.
-//   * tile index = blockIdx.x, so the tile -> XCD assignment (block b -> XCD b%8) is the same in
-//     every launch: each XCD keeps its 1/8 of the 18 MB basis in its own 4 MiB L2 across the
-//     closure rounds of a fit.
+// MI355X mapping (details and the measured timeline: DESIGN.md 4.1)
+//   * one workgroup = one tile of 32 vertices x one chunk of 32 problems, 8 waves, 154 KB LDS.
+//   * waves 0-3 own the blendshape contraction [32 problems x 224] . [224 x 32 verts x 3] on the matrix
+//     cores in exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain): wave w = k-slice w (56 of the 224
+//     rows) of all three coordinate planes, 3 accumulators, 84 MFMAs.  The basis is pre-tiled in HBM in
+//     B-operand order so every wave load is one contiguous 1 KiB global_load_dwordx4 covering 4 k-steps;
+//     each basis element is read once per chunk.
+//   * every wave stages only the operands it reads itself (wave-private LDS regions): no workgroup barrier
+//     before the compute phase; load issue order is pinned (coefficients, basis stream, blend operands) and
+//     the first MFMA waits for the first basis group only (counted vmcnt).
+//   * while the basis streams, all 8 waves compute the skinning transforms T = W . A on the VALU and keep
+//     them in registers; k-slice partials then meet in LDS in a fixed order (deterministic), all waves
+//     apply T and store.
 #include "mvfit_device.h"
 
 namespace mvfit {
