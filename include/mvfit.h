@@ -161,10 +161,26 @@ int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lb
  *   faces[num_faces,3] int32 dev ; vertices[B,num_vertices,3] dev, coordinates in [-1,1] ; phi[B,G,G,G] dev out
  *   (phi[b,k,j,i]: i fastest = x).  num_faces is the caller's faces.size(0), exactly as the reference launcher
  *   takes it (sdf_cuda_kernel.cu:314; the reference's own call site passes a [1,F,3] tensor, i.e. ONE triangle).
- * Stand-alone op: the collision term of the loss (code/utils/fitting.py:352-393) is not wired into
- * mvfit_closure yet (coll_loss_weight > 0 is rejected). */
+ * Stand-alone op; the loss term below evaluates the same voxel function without materialising phi. */
 int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* vertices, int B,
               int num_vertices, int G, float* phi);
+
+/* The interpenetration term of SMPLifyLoss.forward (code/utils/fitting.py:352-393, boxes :282-288):
+ *   pen = (coll_loss_weight * sum_v grid_sample(phi, (v - c) / s))^2,  phi = SDF(faces, (v - c) / s, grid_size)
+ * switched on for mvfit_closure / mvfit_fit whenever a weight set has coll_loss_weight > 0 (fitting.py:354).
+ *   faces[num_faces,3] int32 (host or device), copied; num_faces = what the reference's call site makes the
+ *   op see: it passes body_model_faces.reshape(1, -1, 3) (fitting.py:367-368), so the op's faces.size(0)
+ *   is 1 and only the FIRST triangle is voxelised - pass num_faces = 1 for the reference's behaviour, the
+ *   full face count for the behaviour its author presumably intended.  grid_size: 128 in the reference (:368).
+ *   faces = NULL or num_faces = 0 removes the term.
+ * Every problem is one person (the reference asserts batch size 1, :366): boxes, phi and the sum are per problem.
+ * The term reads all vertices, so MVFIT_F_SPARSE_VERTS is ignored while it is active. */
+int mvfit_set_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, int grid_size);
+
+/* Diagnostics of the last evaluated interpenetration term (after mvfit_closure with coll_loss_weight > 0):
+ *   samples[B,num_verts,4] dev out = (phi_v, d phi_v / d local x, y, z) per vertex (may be NULL),
+ *   sums[B] dev out = S = sum_v phi_v (may be NULL). */
+int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 
 /* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
  * the last call, measured with hipEvents on the ctx stream; *launches = number measured.

@@ -85,6 +85,8 @@ struct ClosureLds {
     int flags_dropped;              // bit0: pose prior dropped, bit1: angle prior dropped
     int gmm_sel;
     int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
+    const SdfAdj* sdf_adj;          // SDF term of this problem (sdf_term.hip), or null
+    float sdf_fac, sdf_pad;         // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
     double total;
     double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
@@ -114,7 +116,7 @@ struct ClosureLds {
 // the first wait.  Null pointers skip a block; x_g (flat parameters, DV floats) fills L.opt.x.
 __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const ObsBlock* obs_g, const PoseBlock* pose_g,
                                          const OptBlock* opt_g, const float* vposed_g, const float* xs_g,
-                                         const float* x_g, int tid) {
+                                         const float* x_g, int tid, const SdfAdj* sdf_adj = nullptr) {
     constexpr int n16 = sizeof(ModelLds) / 16;
     constexpr int nobs = sizeof(ObsBlock) / 16, npose = sizeof(PoseBlock) / 16, nopt = sizeof(OptBlock) / 16;
     static_assert(n16 <= 3 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
@@ -143,6 +145,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     if (vposed_g && tid < NC_MAX / 4) { reinterpret_cast<float4*>(L.vposed)[tid] = vvps; reinterpret_cast<float4*>(L.xs)[tid] = vxss; }
     if (x_g && tid < DPAD) L.opt.x[tid] = xv;
     if (tid >= 384 && tid < 384 + 8 * 12) (&L.gG[NJ][0])[tid - 384] = 0.f;               // "no child" rows
+    if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; }
 }
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {   // c = a b
@@ -720,10 +723,20 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
     if (!(W.flags & MVFIT_F_FIX_SHAPE)) l_shape = sqb * (double)W.shape_w * (double)W.shape_w;   // :339-342
     double l_angle = san * (double)W.bend_w;
     if ((float)l_angle > 1e4f && !use_vp) { l_angle = 0.0; dropped |= 2; }     // fitting.py:349-350
-    const double total = l_data + l_pose + l_shape + l_angle;
+    // interpenetration term (fitting.py:352-393): pen = (w S / valid_people)^2 with S from sdf_term.hip
+    double l_coll = 0.0;
+    float sdf_fac = 0.f;
+    if (L.sdf_adj && W.coll_w > 0.f) {
+        const float S = L.sdf_adj->S;
+        const double ws = (double)W.coll_w * (double)S;
+        l_coll = ws * ws;
+        sdf_fac = 2.f * W.coll_w * W.coll_w * S;
+    }
+    const double total = l_data + l_pose + l_shape + l_angle + l_coll;
     if (tid == 0) {
+        L.sdf_fac = sdf_fac;
         L.loss_terms[0] = (float)l_data; L.loss_terms[1] = (float)l_pose; L.loss_terms[2] = (float)l_shape;
-        L.loss_terms[3] = (float)l_angle; L.loss_terms[5] = (float)total;
+        L.loss_terms[3] = (float)l_angle; L.loss_terms[4] = (float)l_coll; L.loss_terms[5] = (float)total;
         L.flags_dropped = dropped;
         L.total = total;
     }
@@ -840,6 +853,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
     __syncthreads();                  // L.gkp (view sums) and L.gtau are written after E4's last barrier
+    const float sdf_fac = L.sdf_fac;
     // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
     if (tid < nc_pad) {
         float v = 0.f;
@@ -886,6 +900,10 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
 #pragma unroll
         for (int e = 0; e < 12; ++e) acc[e] = row16_sum(acc[e]);
         if (g == 0) {
+            if (sdf_fac != 0.f) {                          // + the SDF term's dense-vertex part of g_A
+#pragma unroll
+                for (int e = 0; e < 12; ++e) acc[e] = fmaf(sdf_fac, L.sdf_adj->gA[j * 12 + e], acc[e]);
+            }
             // A_j = [Gr_j | Gt_j - Gr_j J_j]:  g_Gt = g_At ; g_Gr = g_Ar - g_At J^T ; g_J = -Gr^T g_At
             const float J0 = L.pose.J[j][0], J1 = L.pose.J[j][1], J2 = L.pose.J[j][2];
 #pragma unroll
@@ -921,6 +939,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
             else {
                 float gc = 0.f;
                 for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + 3 * mm + c];
+                if (sdf_fac != 0.f) gc = fmaf(sdf_fac, L.sdf_adj->gcoef[9 * (j - 1) + 3 * mm + c], gc);
                 gr = v + gc;
             }
             L.gR[j][3 * mm + c] = gr;
@@ -957,6 +976,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         if (g == 0) {
             float gc = 0.f;
             for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
+            if (sdf_fac != 0.f) gc = fmaf(sdf_fac, L.sdf_adj->gcoef[207 + l], gc);
             s += gc;
             if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
@@ -1031,7 +1051,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
         if (i < X_GO) g = (W.flags & MVFIT_F_FIX_SHAPE) ? 0.f : L.gbeta[i];
         else if (i < X_BP) g = L.gtheta[i - X_GO];
         else if (i < X_TR) g = use_vp ? 0.f : L.gtheta[3 + i - X_BP];
-        else if (i < X_SC) g = L.gtau[i - X_TR];
+        else if (i < X_SC) { g = L.gtau[i - X_TR]; if (sdf_fac != 0.f) g = fmaf(sdf_fac, L.sdf_adj->gtau[i - X_TR], g); }
         else if (i == X_SC) g = (W.flags & MVFIT_F_FIX_SCALE) ? 0.f : L.gscale;
         else if (i < DV) g = use_vp ? 2.f * L.opt.x[i] * wp2 : 0.f;              // fitting.py:328 (d/dz |z|^2 w^2)
         L.grad[i] = g;

@@ -25,6 +25,9 @@ namespace mvfit {
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream);
 hipError_t vertex_pass_configure();
+hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
+                           int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
+size_t sdf_entry_bytes();
 hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
                                float* phi, hipStream_t stream);
 
@@ -40,6 +43,8 @@ struct FitBuffers {
     float* gcol;         // [B][LB_GSIZE]
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
     int* n_done;         // [1]
+    const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
+    int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
 };
 
 // compact optimiser index (reference final_params order, non_linear_solver.py:164-170) -> flat x slot
@@ -97,12 +102,13 @@ __global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBloc
 __global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                           DevWeights W, DevPose P, const float* __restrict__ params,
                                                           int from_pass, float* __restrict__ loss,
-                                                          float* __restrict__ grad, float* __restrict__ joints) {
+                                                          float* __restrict__ grad, float* __restrict__ joints,
+                                                          const SdfAdj* __restrict__ sdf_adj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     prologue(L, M, obs + b, nullptr, nullptr, from_pass ? P.vposed_sel + (size_t)b * NC_MAX : nullptr,
-             from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr, params + (size_t)b * DV, tid);
+             from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr, params + (size_t)b * DV, tid, sdf_adj ? sdf_adj + b : nullptr);
     __syncthreads();
     pose_prep(M, L, W.flags, tid);
     sparse_forward(M, L, from_pass != 0, tid);
@@ -263,7 +269,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     PH_T0();
-    prologue(L, M, obs + b, F.pose + b, F.opt + b, P.vposed_sel + (size_t)b * NC_MAX, P.xs_sel + (size_t)b * NC_MAX, nullptr, tid);
+    prologue(L, M, obs + b, F.pose + b, F.opt + b, P.vposed_sel + (size_t)b * NC_MAX, P.xs_sel + (size_t)b * NC_MAX, nullptr, tid,
+             F.sdf_adj ? F.sdf_adj + b : nullptr);
     opts_in(L, SW, O, tid);
     __syncthreads();
     if (L.opt.lbS.status != 0) return;                    // uniform per block
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     PH_T0();
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
+    if (tid == 0 && F.sdf_adj) F.sdf_gate[b] = (!done && L.sw[L.sh_stage].coll_w > 0.f) ? 1 : 0;
     // pose operands of the next trial point (also after the last round: final vertices)
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
@@ -453,6 +461,13 @@ struct mvfit_ctx {
     hipGraphExec_t round_graph = nullptr;
     std::vector<unsigned char> graph_key;
     int graph_rounds = 0;
+    // SDF interpenetration term (mvfit_set_sdf): faces as the reference's caller hands them to the op
+    int32_t* d_sdf_faces = nullptr;
+    int sdf_num_faces = 0, sdf_grid = 0;
+    SdfBox* d_sdf_box = nullptr;       // [B]
+    float4* d_sdf_samp = nullptr;      // [B][nv]
+    void* d_sdf_entries = nullptr;     // [B][nv] entry list
+    SdfAdj* d_sdf_adj = nullptr;       // [B]
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
@@ -539,6 +554,18 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
             for (int j = 0; j < NJ; ++j)
                 wt[((size_t)(v / 32) * NJ + j) * 32 + (v % 32)] = m->lbs_weights[(size_t)v * NJ + j];
         M.wt_tiles = dev_upload(c, wt);
+        // vertex-major copies (SDF term pull-back): coefficient row order (posedirs 0..206, shapedirs 207..216)
+        std::vector<float> bsv((size_t)nv * 3 * KROWS, 0.f);
+        for (int v = 0; v < nv; ++v)
+            for (int k = 0; k < 3; ++k) {
+                float* row = &bsv[((size_t)v * 3 + k) * KROWS];
+                for (int pp = 0; pp < 207; ++pp) row[pp] = m->posedirs[(size_t)pp * nv * 3 + 3 * v + k];
+                for (int l = 0; l < 10; ++l) row[207 + l] = m->shapedirs[((size_t)v * 3 + k) * 10 + l];
+            }
+        M.bs_vm = dev_upload(c, bsv);
+        std::vector<float> wv((size_t)nv * NJ);
+        for (size_t i = 0; i < wv.size(); ++i) wv[i] = m->lbs_weights[i];
+        M.w_vm = dev_upload(c, wv);
     }
     // ---- the LDS image of the per-problem kernels ----
     std::vector<ModelLds> imgv(1);
@@ -772,13 +799,15 @@ static void free_problem_buffers(mvfit_ctx* c) {
     drop_graph(c);
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
-                  c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done};
+                  c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
+                  c->d_sdf_adj, c->F.sdf_gate};
     for (void* p : ps) if (p) hipFree(p);
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
     c->d_obs = nullptr;
     c->P = DevPose{};
     c->d_verts = nullptr;
     c->F = FitBuffers{};
+    c->d_sdf_box = nullptr; c->d_sdf_samp = nullptr; c->d_sdf_entries = nullptr; c->d_sdf_adj = nullptr;
 }
 
 extern "C" void mvfit_destroy(mvfit_ctx* c) {
@@ -786,6 +815,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
+    if (c->d_sdf_faces) hipFree(c->d_sdf_faces);
     for (void* p : c->allocs) if (p) hipFree(p);
     if (c->h_done) hipHostFree(c->h_done);
     for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -830,6 +860,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMemset(c->F.gcol, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
         HIP_OK(c, hipMalloc(&c->F.n_done, 4));
+        HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
         c->B = B; c->V = V; c->Bpad = Bpad;
     }
     const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
@@ -861,6 +892,55 @@ extern "C" int mvfit_set_joints3d(mvfit_ctx* c, const float* gt3d, const float* 
     HIP_OK(c, hipStreamSynchronize(c->stream));
     hipFree(d3); hipFree(c3);
     c->has_joints3d = true;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_set_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, int grid_size) {
+    if (!c) return MVFIT_E_ARG;
+    HIP_OK(c, hipSetDevice(c->device));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (c->d_sdf_faces) { hipFree(c->d_sdf_faces); c->d_sdf_faces = nullptr; }
+    c->sdf_num_faces = 0; c->sdf_grid = 0;
+    if (!faces || num_faces == 0) return MVFIT_OK;                 // term switched off
+    if (num_faces < 0 || grid_size < 2 || grid_size > 1024)
+        return fail(c, MVFIT_E_ARG, "mvfit_set_sdf: bad argument (num_faces=%d grid_size=%d)", num_faces, grid_size);
+    HIP_OK(c, hipMalloc(&c->d_sdf_faces, (size_t)num_faces * 3 * 4));
+    HIP_OK(c, hipMemcpy(c->d_sdf_faces, faces, (size_t)num_faces * 3 * 4, hipMemcpyDefault));
+    std::vector<int32_t> h((size_t)num_faces * 3);
+    HIP_OK(c, hipMemcpy(h.data(), c->d_sdf_faces, h.size() * 4, hipMemcpyDeviceToHost));
+    for (int32_t vi : h)
+        if (vi < 0 || vi >= c->nv) {
+            hipFree(c->d_sdf_faces); c->d_sdf_faces = nullptr;
+            return fail(c, MVFIT_E_ARG, "mvfit_set_sdf: face vertex index %d outside [0, %d)", (int)vi, c->nv);
+        }
+    c->sdf_num_faces = num_faces; c->sdf_grid = grid_size;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_sdf_term_read(mvfit_ctx* c, float* samples, float* sums) {
+    if (!c) return MVFIT_E_ARG;
+    if (!c->d_sdf_adj) return fail(c, MVFIT_E_STATE, "no interpenetration term has been evaluated yet");
+    HIP_OK(c, hipSetDevice(c->device));
+    if (samples) HIP_OK(c, hipMemcpyAsync(samples, c->d_sdf_samp, (size_t)c->B * c->nv * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    if (sums) HIP_OK(c, hipMemcpy2DAsync(sums, sizeof(float), c->d_sdf_adj, sizeof(SdfAdj), sizeof(float), c->B, hipMemcpyDeviceToDevice, c->stream));
+    return MVFIT_OK;
+}
+
+// work buffers of the SDF term for the current batch
+static int ensure_sdf_buffers(mvfit_ctx* c) {
+    if (c->d_sdf_adj) return MVFIT_OK;
+    HIP_OK(c, hipMalloc(&c->d_sdf_box, (size_t)c->B * sizeof(SdfBox)));
+    HIP_OK(c, hipMalloc(&c->d_sdf_samp, (size_t)c->B * c->nv * sizeof(float4)));
+    HIP_OK(c, hipMalloc(&c->d_sdf_entries, (size_t)c->B * c->nv * sdf_entry_bytes()));
+    HIP_OK(c, hipMalloc(&c->d_sdf_adj, (size_t)c->B * sizeof(SdfAdj)));
+    return MVFIT_OK;
+}
+
+static int run_sdf_term(mvfit_ctx* c, const float* verts, const int* gate, hipStream_t st) {
+    hipError_t e = launch_sdf_term(c->M, c->P, verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, gate, c->d_sdf_box,
+                                   c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, st);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf term launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
 
@@ -922,20 +1002,28 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
     int rc = check_flags(c, w->flags);
     if (rc) return rc;
-    if (w->coll_loss_weight > 0.f) return fail(c, MVFIT_E_UNSUPPORTED, "SDF collision term is not built yet (coll_loss_weight must be 0)");
+    const bool sdf = w->coll_loss_weight > 0.f;
+    if (sdf && !c->sdf_num_faces)
+        return fail(c, MVFIT_E_STATE, "coll_loss_weight > 0 needs the SDF term's faces: call mvfit_set_sdf first");
     HIP_OK(c, hipSetDevice(c->device));
     float* vbuf = verts ? verts : c->d_verts;
-    const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0;
+    // the interpenetration term reads every vertex: it forces the vertex pass
+    const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0 && !sdf;
     if (!sparse || verts) {
         hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, w->flags);
         HIP_OK(c, hipGetLastError());
         rc = run_vertex_pass(c, vbuf);
         if (rc) return rc;
     }
+    if (sdf) {
+        rc = ensure_sdf_buffers(c);
+        if (!rc) rc = run_sdf_term(c, vbuf, nullptr, c->stream);
+        if (rc) return rc;
+    }
     prof_begin(c, c->ev_step);
     hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V,
                        to_dev(*w), c->P, params,
-                       sparse ? 0 : 1, loss, grad, joints);
+                       sparse ? 0 : 1, loss, grad, joints, sdf ? (const SdfAdj*)c->d_sdf_adj : (const SdfAdj*)nullptr);
     prof_end(c, c->ev_step);
     HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
@@ -988,6 +1076,9 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     if (e == hipSuccess) {
         for (int r = 0; r < kGraphRounds && e == hipSuccess; ++r) {
             e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, cs);
+            if (e == hipSuccess && c->F.sdf_adj)
+                e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
+                                    c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs);
             hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                c->P, c->F);
         }
@@ -1010,20 +1101,30 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     HIP_OK(c, hipSetDevice(c->device));
     StageWeights SW;
     memset(&SW, 0, sizeof(SW));
+    bool any_sdf = false;
     if (o->num_stages <= 0 || o->num_stages > MVFIT_MAX_STAGES) return fail(c, MVFIT_E_ARG, "num_stages");
     for (int s = 0; s < o->num_stages; ++s) {
         int rc = check_flags(c, sw[s].flags);
         if (rc) return rc;
         if (sw[s].flags != sw[0].flags) return fail(c, MVFIT_E_ARG, "flags must be identical for all stages");
-        if (sw[s].coll_loss_weight > 0.f) return fail(c, MVFIT_E_UNSUPPORTED, "SDF collision term is not built yet");
+        any_sdf = any_sdf || sw[s].coll_loss_weight > 0.f;
         SW.w[s] = to_dev(sw[s]);
     }
+    if (any_sdf && !c->sdf_num_faces)
+        return fail(c, MVFIT_E_STATE, "coll_loss_weight > 0 needs the SDF term's faces: call mvfit_set_sdf first");
+    if (any_sdf) {
+        int rc = ensure_sdf_buffers(c);
+        if (rc) return rc;
+    }
+    c->F.sdf_adj = any_sdf ? c->d_sdf_adj : nullptr;
     LbOpts O;
     int rc = make_opts(c, o, sw[0].flags, O);
     if (rc) return rc;
-    const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0;
+    // the interpenetration term reads every vertex: it forces the (vertex pass, step) round structure
+    const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
                        (const float*)params,
                        sw[0].flags, sparse ? 0 : 1);
@@ -1049,6 +1150,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
         while (rounds < cap) {
             for (int r = 0; r < kGraphRounds; ++r) {
                 rc = run_vertex_pass(c, c->d_verts);
+                if (!rc && any_sdf) rc = run_sdf_term(c, c->d_verts, c->F.sdf_gate, c->stream);
                 if (rc) return rc;
                 prof_begin(c, c->ev_step);
                 hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,

@@ -70,6 +70,9 @@ struct DevModel {
     const float* bs4;        // [ntiles][3][KGROUPS][64][4]   MFMA-B-operand order (see vertex pass)
     const float* vt_planes;  // [3][nv_pad]
     const float* wt_tiles;   // [ntiles][24][32]
+    // vertex-major copies for the per-vertex pull-back of the SDF term (sdf_term.hip)
+    const float* bs_vm;      // [nv][3][KROWS]   same row order as the coefficient vector
+    const float* w_vm;       // [nv][24]
     // objective-relevant vertex subset
     int ns, nc, nc_pad;      // nc = 3*ns, nc_pad multiple of 4
     const ModelLds* mlds;    // LDS image (global copy)
@@ -130,5 +133,22 @@ struct DevPose {
     float* vposed_sel;
     float* xs_sel;
 };
+
+// SDF interpenetration term (fitting.py:352-393), per problem
+struct SdfBox {              // bounding box of the vertices: centre, scale, arg indices (fitting.py:282-288,356-359)
+    float c[3];
+    float s;
+    int imin[3];
+    int imax[3];
+    int amax;                // axis of the largest extent
+    int pad;
+};
+struct SdfAdj {              // S = sum_v phi_v and its adjoint w.r.t. the vertex pass operands
+    float S;
+    float gtau[3];
+    float gA[NJ * 12];       // per joint [g_Ar (a-major 3x3) | g_At (3)]: the accumulator order of the closure's E6
+    float gcoef[KROWS];
+};
+static_assert(sizeof(SdfAdj) % 16 == 0, "16-byte block");
 
 }  // namespace mvfit

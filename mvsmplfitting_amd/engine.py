@@ -213,6 +213,27 @@ class MvFit:
                                         int(v.shape[1]), int(grid_size), phi.data_ptr()))
         return phi
 
+    def set_sdf(self, faces, num_faces=1, grid_size=128):
+        """Configure the interpenetration term (include/mvfit.h:mvfit_set_sdf).  ``faces`` [F,3]; ``num_faces``
+        = how many leading triangles the op sees: 1 reproduces the reference's call site
+        (faces.reshape(1,-1,3), fitting.py:367-368), None = all of them.  faces=None removes the term."""
+        if faces is None:
+            self._check(self._lib.mvfit_set_sdf(self._ctx, None, 0, 0))
+            return
+        f = faces.detach().cpu().numpy() if isinstance(faces, torch.Tensor) else np.asarray(faces)
+        f = np.ascontiguousarray(f.reshape(-1, 3), dtype=np.int32)
+        n = f.shape[0] if num_faces is None else int(num_faces)
+        if n < 1 or n > f.shape[0]:
+            raise MvFitError(f'num_faces={n} outside [1, {f.shape[0]}]')
+        self._check(self._lib.mvfit_set_sdf(self._ctx, f.ctypes.data, n, int(grid_size)))
+
+    def sdf_term_read(self):
+        """(samples [B,Nv,4] = phi_v and its local-coordinate gradient, S [B]) of the last evaluated term."""
+        smp = torch.empty(self.B, self.nv, 4, device=self.device)
+        S = torch.empty(self.B, device=self.device)
+        self._check(self._lib.mvfit_sdf_term_read(self._ctx, smp.data_ptr(), S.data_ptr()))
+        return smp, S
+
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):
         self._check(self._lib.mvfit_profile(self._ctx, 1 if enable else 0))

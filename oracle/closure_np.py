@@ -335,9 +335,10 @@ class ClosureOracle:
                            angle_dropped=angle_dropped, gmm_sel=gmm_sel)
 
     def closure(self, x_flat, cams, gt_xy, w_conf, wts, use_vposer=False, prior=PRIOR_L2,
-                fix_shape=False, g_verts_extra=None, joints3d=None):
+                fix_shape=False, g_verts_extra=None, joints3d=None, sdf=None):
         """loss, grad[D], out   for one problem.  ``g_verts_extra`` [6890,3] optionally adds
-        an external dL/dvertices (used by the SDF term's oracle)."""
+        an external dL/dvertices.  ``sdf`` = dict(faces, num_faces, grid_size) adds the interpenetration
+        term of fitting.py:352-393 (oracle/sdf_term_np.py) with weight wts['coll_loss_weight']."""
         dt = self.dtype
         x_flat = np.asarray(x_flat, dt)
         p = dict(unpack(x_flat, use_vposer))
@@ -346,6 +347,13 @@ class ClosureOracle:
         z = p.get('pose_embedding')
         total, aux = self.loss_terms(out, cams, gt_xy, w_conf, wts, use_vposer, z, prior,
                                      fix_shape, p['betas'], joints3d=joints3d)
+        if sdf is not None and float(wts.get('coll_loss_weight', 0.0)) > 0:
+            from oracle import sdf_term_np
+            pen, g_sdf, sdf_aux = sdf_term_np.sdf_term(out['vertices'], sdf['faces'], wts['coll_loss_weight'],
+                                                       sdf.get('num_faces', 1), sdf.get('grid_size', 128), dt)
+            total = total + pen
+            out['sdf'] = sdf_aux
+            g_verts_extra = g_sdf if g_verts_extra is None else g_verts_extra + g_sdf
         grad = self._backward(out, aux, cams, w_conf, wts, use_vposer, z, prior, fix_shape,
                               g_verts_extra, joints3d=joints3d)
         return total, grad, out

@@ -1,0 +1,136 @@
+"""GPU parity: the interpenetration term of the loss (fitting.py:352-393) through the C ABI against the
+oracle (oracle/sdf_term_np.py on top of oracle/closure_np.py).  Tolerances as for the closure: loss 1e-5
+relative, gradient 2e-4 of its max.  The oracle's SDF op is "parity unpinned" (CUDA-only reference op).
+
+The term is only piecewise smooth in the vertices (trilinear cells; phi jumps at the mesh boundary), so the
+oracle's term is evaluated at the vertices the device produced (themselves checked to 1e-4 in
+test_gpu_closure.py): a vertex within float32 rounding of a cell face otherwise picks the neighbouring cell and a
+different - equally valid - one-sided gradient.  The per-vertex samples are compared as well."""
+import os
+
+import numpy as np
+import pytest
+
+from mvsmplfitting_amd import _lib
+from oracle import closure_np as cn
+from oracle import lbfgs_np as ln
+from oracle import sdf_term_np as st
+from tests.gpu_helpers import make_engine, to118
+from tests.helpers import GOLD, body_model, load_case, oracle_for
+from tests.test_gpu_lbfgs import eng_stage_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _closure_case(num_faces, G, coll_w, nprob, use_vp=False):
+    name = 'vp_s0_v8' if use_vp else 'l2_s3_v6'
+    cfg, g, model, vpw, gmm, wts, cams = load_case(name)
+    orc = oracle_for(model, vpw, gmm)
+    eng = make_engine(model, vpw, gmm)
+    eng.set_problems(cams, g['gt_xy'][:nprob], g['conf'][:nprob])
+    eng.set_sdf(model['faces'], num_faces=num_faces, grid_size=G)
+    x = np.stack([to118(g['x'][b], use_vp) for b in range(nprob)]).astype(np.float32)
+    w = dict(wts, coll_loss_weight=coll_w, flags=_lib.F_VPOSER if use_vp else 0)
+    out = eng.closure(x, w, want_grad=True, want_verts=True)
+    smp, S_dev = eng.sdf_term_read()
+    smp = smp.cpu().numpy().astype(np.float64)
+    verts = out['verts'].cpu().numpy().astype(np.float64)
+    out0 = eng.closure(x, dict(w, coll_loss_weight=0.0), want_grad=True)
+    loss = out['loss'].cpu().numpy().astype(np.float64)
+    grad = out['grad'].cpu().numpy().astype(np.float64)
+    loss0 = out0['loss'].cpu().numpy().astype(np.float64)
+    nf = model['faces'].shape[0] if num_faces is None else num_faces
+    sdf = dict(faces=model['faces'], num_faces=nf, grid_size=G)
+    res = []
+    for b in range(nprob):
+        pen_r, g_sdf, aux = st.sdf_term(verts[b], sdf['faces'], coll_w, nf, G)
+        Lr, gr, o = orc.closure(g['x'][b], cams, g['gt_xy'][b], g['conf'][b], dict(wts, coll_loss_weight=0.0),
+                                use_vposer=use_vp, g_verts_extra=g_sdf)
+        assert np.abs(o['vertices'] - verts[b]).max() < 1e-4
+        Lr = Lr + pen_r
+        # per-vertex samples: value everywhere; coordinate gradient away from cell faces
+        loc = (verts[b] - aux['c']) / aux['s']
+        val, gloc = st.sample_trilinear(np.asarray(aux['phi'], np.float64), loc)
+        assert np.abs(smp[b][:, 0] - val).max() <= 1e-5 * max(1.0, np.abs(val).max())
+        pix = ((loc + 1) * G - 1) / 2
+        interior = (np.abs(pix - np.round(pix)) > 1e-3).all(1)
+        assert interior.sum() >= loc.shape[0] - 60
+        assert np.abs(smp[b][interior, 1:] - gloc[interior]).max() <= 1e-3 * max(1.0, np.abs(gloc).max())
+        gm = grad[b][:86] if not use_vp else np.concatenate([grad[b][0:13], grad[b][82:86], grad[b][86:118]])
+        res.append(dict(L=loss[b], Lr=Lr, pen=loss[b] - loss0[b], pen_r=pen_r, g=gm, gr=gr, S=aux['S']))
+    eng.close()
+    return res
+
+
+@pytest.mark.parametrize('num_faces,G,coll_w', [(1, 128, 40.0), (64, 32, 20.0), (None, 16, 0.5)])
+def test_closure_with_sdf_term_matches_oracle(num_faces, G, coll_w):
+    res = _closure_case(num_faces, G, coll_w, nprob=1 if num_faces is None else 2)   # all faces: 20 s of oracle per problem
+    assert any(r['S'] > 0 for r in res), 'test case does not exercise the term'
+    for r in res:
+        assert abs(r['L'] - r['Lr']) <= 1e-5 * abs(r['Lr']), (r['L'], r['Lr'])
+        assert abs(r['pen'] - r['pen_r']) <= 1e-4 * max(r['pen_r'], 1e-3 * abs(r['Lr'])), (r['pen'], r['pen_r'])
+        assert np.abs(r['g'] - r['gr']).max() <= 2e-4 * np.abs(r['gr']).max(), (np.abs(r['g'] - r['gr']).max(), np.abs(r['gr']).max())
+
+
+def test_closure_with_sdf_term_and_vposer():
+    res = _closure_case(64, 32, 20.0, nprob=2, use_vp=True)
+    for r in res:
+        assert abs(r['L'] - r['Lr']) <= 1e-5 * abs(r['Lr'])
+        assert np.abs(r['g'] - r['gr']).max() <= 2e-4 * np.abs(r['gr']).max()
+
+
+def test_term_needs_faces_and_is_off_without_weight():
+    cfg, g, model, vpw, gmm, wts, cams = load_case('l2_s3_v6')
+    eng = make_engine(model)
+    eng.set_problems(cams, g['gt_xy'][:1], g['conf'][:1])
+    x = to118(g['x'][0], False)[None].astype(np.float32)
+    from mvsmplfitting_amd.engine import MvFitError
+    with pytest.raises(MvFitError):
+        eng.closure(x, dict(wts, coll_loss_weight=1.0, flags=0))
+    eng.set_sdf(model['faces'], num_faces=1, grid_size=128)
+    a = eng.closure(x, dict(wts, coll_loss_weight=0.0, flags=0))['loss'].cpu().numpy()
+    eng.set_sdf(None)
+    b = eng.closure(x, dict(wts, flags=0))['loss'].cpu().numpy()
+    assert a[0] == b[0]
+    eng.close()
+
+
+def test_fit_with_sdf_term_last_stage():
+    """Staged fit with the term on in the last two stages (weights as conf: coll_loss_weights grows with the
+    stage) against the oracle's fit driven by the same closure."""
+    g = dict(np.load(os.path.join(GOLD, 'fit_l2.npz')))
+    model = body_model()
+    cams = (g['cam_R'], g['cam_t'], g['cam_f'], g['cam_c'])
+    B = 2
+    G, nf = 16, 32
+    coll = [0.0, 0.0, 5.0, 20.0]
+    eng = make_engine(model)
+    eng.set_problems(cams, g['gt_xy'][:B], g['conf'][:B])
+    eng.set_sdf(model['faces'], num_faces=nf, grid_size=G)
+    x0 = np.stack([to118(g['x0'][b], False) for b in range(B)]).astype(np.float32)
+    stages = eng_stage_weights(1536.0, flags=0)
+    for s, cw in enumerate(coll):
+        stages[s]['coll_loss_weight'] = cw
+    xf, st = eng.fit(x0, stages)
+    final = st['final_loss'].cpu().numpy().astype(np.float64)
+    ncl = st['n_closure'].cpu().numpy()
+    # the returned loss is the objective (with the term) at the returned parameters
+    chk = eng.closure(xf, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
+    assert np.all(np.isfinite(final)) and np.all(chk <= final * (1 + 1e-3) + 1e-3)
+    eng.close()
+    # oracle fit, same schedule
+    orc = oracle_for(model, None, None)
+    sdf = dict(faces=model['faces'], num_faces=nf, grid_size=G)
+    for b in range(B):
+        x = np.asarray(g['x0'][b], np.float64)
+        f_last, n_cl = None, 0
+        for s in range(4):
+            wts = {k: stages[s][k] for k in ('data_weight', 'body_pose_weight', 'shape_weight', 'bending_prior_weight',
+                                             'rho', 'coll_loss_weight')}
+            opt = ln.LbfgsOracle(x, lambda xx, wts=wts: orc.closure(xx, cams, g['gt_xy'][b], g['conf'][b], wts, sdf=sdf)[:2])
+            prev, losses = ln.run_fitting(opt, segments=[(0, 10), (10, 13), (13, 82), (82, 85), (85, 86)])
+            f_last = prev if prev is not None else losses[-1]
+            x = opt.x.copy()
+            n_cl += opt.func_evals
+        assert final[b] <= 1.25 * f_last + 1.0, (final[b], f_last)
+        assert 0.25 * n_cl < ncl[b] < 4 * n_cl, (ncl[b], n_cl)
