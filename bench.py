@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--prior', default='l2', choices=['l2', 'vposer', 'gmm'])
     ap.add_argument('--sparse', action='store_true',
                     help='objective-vertices-only closure (no full vertex pass inside the loop)')
+    ap.add_argument('--sdf', action='store_true',
+                    help='configs[2]: SDF interpenetration term on (as wired: first triangle, grid 128; yaml coll_loss_weights)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -126,7 +128,9 @@ def main():
         flags |= _lib.F_PRIOR_GMM
     if args.sparse:
         flags |= _lib.F_SPARSE_VERTS
-    stages = stage_weights(1536.0, flags=flags)
+    stages = stage_weights(1536.0, flags=flags, coll_w=[0.0, 0.0, 1000.0, 4500.0] if args.sdf else None)
+    if args.sdf:
+        eng.set_sdf(model['faces'], num_faces=1, grid_size=128)      # fit_smpl.yaml:55-59, fitting.py:367-368
     B = args.frames                                   # weak scaling: frames per GPU
     # rank r owns the contiguous global frames shard_range(B * world, world, r); seeds follow the
     # global frame index, so the job is the same set of frames however it is sharded
@@ -207,9 +211,11 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * tmax / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic (seeded SMPL-shaped body, camera ring, noisy projected keypoints)',
-            'config': {'workload': 'configs[1]: 1 person x %d views x %d synthetic frames per GPU, '
-                                   'GMoF + pose prior (%s) + shape + angle priors, no SDF, 4 yaml stages'
-                                   % (args.views, B, args.prior),
+            'config': {'workload': '%s: 1 person x %d views x %d synthetic frames per GPU, '
+                                   'GMoF + pose prior (%s) + shape + angle priors, %s, 4 yaml stages'
+                                   % ('configs[2]' if args.sdf else 'configs[1]', args.views, B, args.prior,
+                                      'SDF term as wired (first triangle, grid 128, yaml coll_loss_weights)' if args.sdf
+                                      else 'no SDF'),
                        'frames_per_gpu': B, 'views': args.views, 'prior': args.prior,
                        'closure_mode': 'objective-vertices-only' if args.sparse else 'full 6890-vertex pass per closure',
                        'parallelism': 'frame-sharded x%d, RCCL all_gather of results' % world},

@@ -905,6 +905,7 @@ extern "C" int mvfit_set_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, 
     if (!faces || num_faces == 0) return MVFIT_OK;                 // term switched off
     if (num_faces < 0 || grid_size < 2 || grid_size > 1024)
         return fail(c, MVFIT_E_ARG, "mvfit_set_sdf: bad argument (num_faces=%d grid_size=%d)", num_faces, grid_size);
+    if (c->nv > 8192) return fail(c, MVFIT_E_UNSUPPORTED, "the SDF term supports up to 8192 vertices (model has %d)", c->nv);
     HIP_OK(c, hipMalloc(&c->d_sdf_faces, (size_t)num_faces * 3 * 4));
     HIP_OK(c, hipMemcpy(c->d_sdf_faces, faces, (size_t)num_faces * 3 * 4, hipMemcpyDefault));
     std::vector<int32_t> h((size_t)num_faces * 3);

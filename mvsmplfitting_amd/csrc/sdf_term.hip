@@ -17,8 +17,9 @@
 // are differentiable functions of the arg-min / arg-max vertices).  Only vertices whose 8 corners touch a
 // non-zero voxel - plus the <= 6 box vertices - carry gradient; they are compacted into an entry list and
 // pulled back through skinning and the blendshape basis (vertex-major copies M.bs_vm / M.w_vm) entry by
-// entry: phase 1 (wave per entry) recomputes v_posed and the blended transform, phase 2 (thread per output)
-// accumulates g_A[24][12] and g_coef[224] in entry order, i.e. deterministically.
+// entry, a batch of 256 entries at a time in LDS: thread per (entry, coordinate) recomputes v_posed, thread per
+// (entry, element) the blended transform, then thread per output accumulates g_A[24][12] and g_coef[224] in
+// entry order, i.e. deterministically.
 #include "sdf_device.h"
 #include "mvfit_device.h"
 #include "wave_ops.h"
@@ -30,45 +31,78 @@ namespace mvfit {
 constexpr int SDF_ADJ_NT = 512;
 constexpr int SDF_EB = 256;          // entries staged per batch in phase 2
 
-__device__ __forceinline__ void better_min(float& v, int& i, float ov, int oi) { if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; } }
-__device__ __forceinline__ void better_max(float& v, int& i, float ov, int oi) { if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+// order-preserving map float -> uint32 (total order of the finite values)
+__device__ __forceinline__ unsigned ord_bits(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __builtin_bit_cast(float, u);
+}
+typedef unsigned long long u64;
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) { return __builtin_bit_cast(u64, dpp_mov<CTRL>(__builtin_bit_cast(double, v))); }
+// whole-wave min / max of 64-bit keys on the DPP path (wave_ops.h), same result in every lane
+template <bool MIN>
+__device__ __forceinline__ u64 wave64_key(u64 v) {
+    auto pick = [](u64 p, u64 q) { return MIN ? (p < q ? p : q) : (p > q ? p : q); };
+    v = pick(v, dpp_u64<DPP_XOR1>(v));
+    v = pick(v, dpp_u64<DPP_XOR2>(v));
+    v = pick(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    v = pick(v, dpp_u64<DPP_MIRROR>(v));
+    double p, q;
+    swap_pair<false>(__builtin_bit_cast(double, v), p, q); v = pick(__builtin_bit_cast(u64, p), __builtin_bit_cast(u64, q));
+    swap_pair<true>(__builtin_bit_cast(double, v), p, q);  v = pick(__builtin_bit_cast(u64, p), __builtin_bit_cast(u64, q));
+    return v;
+}
 
-// fitting.py:282-288 + :356-359.  First-occurrence arg indices (ties: lowest vertex index).
+// fitting.py:282-288 + :356-359.  First-occurrence arg indices (ties: lowest vertex index): the reductions
+// run on keys (ordered value << 32 | index) for the minima and (ordered value << 32 | ~index) for the maxima.
 __global__ __launch_bounds__(512) void sdf_bbox_kernel(const float* __restrict__ verts, int nv, const int* __restrict__ gate,
                                                        SdfBox* __restrict__ box) {
-    __shared__ float s_v[8][6];
-    __shared__ int s_i[8][6];
+    __shared__ u64 s_k[8][6];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;                       // the problem's current stage has no SDF term (uniform)
     const float* vb = verts + (size_t)b * nv * 3;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    int ilo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, ihi[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-    for (int v = tid; v < nv; v += 512)
+    u64 kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
+    for (int vbase = 0; vbase < nv; vbase += 512 * 16) {
+        // 16 rows of 512 vertices with every load issued before the first compare (clamped index: a vertex
+        // seen twice does not change a min / max, and its index is the same)
+        float x[16][3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float x = vb[3 * v + a];
-            better_min(lo[a], ilo[a], x, v);
-            better_max(hi[a], ihi[a], x, v);
+        for (int i = 0; i < 16; ++i) {
+            const int v = min(vbase + i * 512 + tid, nv - 1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) x[i][a] = vb[3 * v + a];
         }
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-        for (int off = 32; off > 0; off >>= 1) {
-            better_min(lo[a], ilo[a], __shfl_xor(lo[a], off), __shfl_xor(ilo[a], off));
-            better_max(hi[a], ihi[a], __shfl_xor(hi[a], off), __shfl_xor(ihi[a], off));
+        for (int i = 0; i < 16; ++i) {
+            const int v = min(vbase + i * 512 + tid, nv - 1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const u64 o = (u64)ord_bits(x[i][a]) << 32;
+                const u64 lo = o | (unsigned)v, hi = o | (unsigned)~v;
+                kmin[a] = lo < kmin[a] ? lo : kmin[a];
+                kmax[a] = hi > kmax[a] ? hi : kmax[a];
+            }
         }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { kmin[a] = wave64_key<true>(kmin[a]); kmax[a] = wave64_key<false>(kmax[a]); }
     if (lane == 0)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { s_v[wave][a] = lo[a]; s_i[wave][a] = ilo[a]; s_v[wave][3 + a] = hi[a]; s_i[wave][3 + a] = ihi[a]; }
+        for (int a = 0; a < 3; ++a) { s_k[wave][a] = kmin[a]; s_k[wave][3 + a] = kmax[a]; }
     __syncthreads();
     if (tid == 0) {
         SdfBox o;
         float ext[3];
         for (int a = 0; a < 3; ++a) {
-            float l = s_v[0][a], h = s_v[0][3 + a];
-            int il = s_i[0][a], ih = s_i[0][3 + a];
-            for (int w = 1; w < 8; ++w) { better_min(l, il, s_v[w][a], s_i[w][a]); better_max(h, ih, s_v[w][3 + a], s_i[w][3 + a]); }
+            u64 lo = s_k[0][a], hi = s_k[0][3 + a];
+            for (int w = 1; w < 8; ++w) { lo = s_k[w][a] < lo ? s_k[w][a] : lo; hi = s_k[w][3 + a] > hi ? s_k[w][3 + a] : hi; }
+            const float l = ord_float((unsigned)(lo >> 32)), h = ord_float((unsigned)(hi >> 32));
             o.c[a] = (l + h) / 2.f;                                  // boxes.mean(dim=1)
-            o.imin[a] = il; o.imax[a] = ih;
+            o.imin[a] = (int)(unsigned)lo; o.imax[a] = (int)~(unsigned)hi;
             ext[a] = h - l;
         }
         int am = 0;
@@ -102,7 +136,10 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
         i0[a] = (int)fl;
         fr[a] = pix - fl;
     }
-    // the 8 corners: bit q of corner index = +1 along axis q
+    // the 8 corners: bit q of corner index = +1 along axis q; their voxel-centre coordinates per axis
+    float vc[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { vc[a][0] = sdf_voxel_coord(i0[a], G); vc[a][1] = sdf_voxel_coord(i0[a] + 1, G); }
     unsigned inrange = 0, parity = 0;
 #pragma unroll
     for (int cn = 0; cn < 8; ++cn) {
@@ -123,10 +160,10 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
         }
         __syncthreads();
         if (inrange) {
+#pragma unroll
             for (int cn = 0; cn < 8; ++cn) {
                 if (!((inrange >> cn) & 1)) continue;
-                const float c[3] = {sdf_voxel_coord(i0[0] + (cn & 1), G), sdf_voxel_coord(i0[1] + ((cn >> 1) & 1), G),
-                                    sdf_voxel_coord(i0[2] + (cn >> 2), G)};
+                const float c[3] = {vc[0][cn & 1], vc[1][(cn >> 1) & 1], vc[2][cn >> 2]};
                 int n = 0;
                 for (int t = 0; t < nf; ++t) n += sdf_ray_hit(tri[t], c) ? 1 : 0;
                 if (n & 1) parity ^= 1u << cn;
@@ -157,8 +194,7 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
 #pragma unroll
                 for (int cn = 0; cn < 8; ++cn) {
                     if (!((parity >> cn) & 1)) continue;
-                    const float c[3] = {sdf_voxel_coord(i0[0] + (cn & 1), G), sdf_voxel_coord(i0[1] + ((cn >> 1) & 1), G),
-                                        sdf_voxel_coord(i0[2] + (cn >> 2), G)};
+                    const float c[3] = {vc[0][cn & 1], vc[1][(cn >> 1) & 1], vc[2][cn >> 2]};
                     float md = pv[cn];
                     for (int t = 0; t < nf; ++t) { const float d = sdf_tri_distance(tri[t], c); if (d < md) md = d; }
                     pv[cn] = md;
@@ -183,148 +219,164 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
     if (live) samp[(size_t)b * nv + v] = make_float4(val, gx * hg, gy * hg, gz * hg);
 }
 
-// block-wide sum of a double, same bits in every thread (fixed order: lanes, then waves ascending)
-__device__ __forceinline__ double block_sum(double v, double* sh, int tid) {
-    v = wave64_sum(v);
-    __syncthreads();
-    if ((tid & 63) == 0) sh[tid >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int w = 0; w < SDF_ADJ_NT / 64; ++w) s += sh[w];
-    return s;
-}
-
-// entry list of one problem: [nv] SdfEntry written by the compaction, then [nv] SdfPull written by phase 1
-// (separate arrays: no cache line is read before another wave writes into it)
+// entry list of one problem: the vertices that carry gradient, in ascending vertex order
 struct SdfEntry { int v; float g[3]; };                                  // vertex, dS/dvertex
-struct SdfPull { float vposed[3]; float gvp[3]; float pad[2]; };         // v_posed, Tr^T g
-static_assert(sizeof(SdfEntry) == 16 && sizeof(SdfPull) == 32, "entry layout");
+static_assert(sizeof(SdfEntry) == 16, "entry layout");
+
+constexpr int SDF_NIT = 16;          // 64-vertex rows per wave: nv <= 8 * 16 * 64
 
 __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_adjoint_kernel(DevModel M, const float* __restrict__ verts,
                                                                  const SdfBox* __restrict__ box, const float4* __restrict__ samp,
                                                                  DevPose P, const int* __restrict__ gate,
-                                                                 unsigned char* __restrict__ entries, SdfAdj* __restrict__ out) {
-    __shared__ double sh_d[8];
-    __shared__ int sh_cnt[SDF_ADJ_NT];
-    __shared__ float sh_coef[KROWS];
+                                                                 SdfEntry* __restrict__ entries, SdfAdj* __restrict__ out) {
+    __shared__ double sh_d[8][5];
+    __shared__ int sh_cnt[8];
+    __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
     __shared__ float sh_A[NJ * 12];
     __shared__ __attribute__((aligned(16))) SdfEntry sh_e[SDF_EB];
-    __shared__ __attribute__((aligned(16))) SdfPull sh_p[SDF_EB];
+    __shared__ float sh_T[SDF_EB][12];
+    __shared__ float sh_vp[SDF_EB][3];
+    __shared__ float sh_part[SDF_EB][3][4];
+    __shared__ float sh_gvp[SDF_EB][3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
     const int nv = M.nv;
     const SdfBox bx = box[b];
     const float* vb = verts + (size_t)b * nv * 3;
     const float4* sb = samp + (size_t)b * nv;
-    SdfEntry* eb = reinterpret_cast<SdfEntry*>(entries + (size_t)b * nv * 48);
-    SdfPull* pb = reinterpret_cast<SdfPull*>(entries + (size_t)b * nv * 48 + (size_t)nv * 16);
+    SdfEntry* eb = entries + (size_t)b * nv;
     if (tid < KROWS) sh_coef[tid] = P.coefT[(size_t)(b >> 5) * KROWS * 32 + (size_t)tid * 32 + (b & 31)];
     if (tid >= 224 && tid < 224 + NJ * 12) sh_A[tid - 224] = P.Amat[(size_t)b * NJ * 12 + (tid - 224)];
-    // ---- reductions over the vertices: S, g_c = -sum g/s, g_s = -sum g.loc/s ----
-    const int per = (nv + SDF_ADJ_NT - 1) / SDF_ADJ_NT;
-    const int v0 = tid * per, v1 = min(nv, v0 + per);
-    double S = 0.0, gc[3] = {0.0, 0.0, 0.0}, gs = 0.0;
+    // ---- pass A: every wave owns an ascending chunk of vertices, 64 per row; everything stays in registers ----
+    const int chunk = (nv + 7) / 8, c0 = wave * chunk, c1 = min(nv, c0 + chunk);
+    float4 q[SDF_NIT];
+    double S = 0.0, gc0 = 0.0, gc1 = 0.0, gc2 = 0.0, gs = 0.0;
+    unsigned actmask = 0;
     int cnt = 0;
-    for (int v = v0; v < v1; ++v) {
-        const float4 q = sb[v];
-        S += (double)q.x;
-        const float g[3] = {q.y, q.z, q.w};
-        bool act = false;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float loc = (vb[3 * v + a] - bx.c[a]) / bx.s;
-            gc[a] -= (double)(g[a] / bx.s);
-            gs -= (double)(g[a] * loc / bx.s);
-            act |= g[a] != 0.f;
-            act |= (v == bx.imin[a]) | (v == bx.imax[a]);
+    for (int h = 0; h < SDF_NIT; h += 8) {             // 8 rows (32 loads) in flight at a time
+        float px[8], py[8], pz[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = c0 + (h + i) * 64 + lane;
+            const bool in = v < c1;
+            const int vc = in ? v : c0;
+            q[h + i] = sb[vc];
+            px[i] = vb[3 * vc]; py[i] = vb[3 * vc + 1]; pz[i] = vb[3 * vc + 2];
+            if (!in) q[h + i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        cnt += act ? 1 : 0;
-    }
-    S = block_sum(S, sh_d, tid);
-    gc[0] = block_sum(gc[0], sh_d, tid); gc[1] = block_sum(gc[1], sh_d, tid); gc[2] = block_sum(gc[2], sh_d, tid);
-    gs = block_sum(gs, sh_d, tid);
-    // ---- compaction: exclusive scan of the per-thread counts (threads own ascending vertex ranges) ----
-    sh_cnt[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < SDF_ADJ_NT; off <<= 1) {
-        const int add = tid >= off ? sh_cnt[tid - off] : 0;
-        __syncthreads();
-        sh_cnt[tid] += add;
-        __syncthreads();
-    }
-    const int n = sh_cnt[SDF_ADJ_NT - 1];
-    int pos = sh_cnt[tid] - cnt;
-    const float gcf[3] = {(float)gc[0], (float)gc[1], (float)gc[2]};
-    const float gsf = (float)gs * (float)((1 + 0.2) * 0.5);
-    for (int v = v0; v < v1; ++v) {
-        const float4 q = sb[v];
-        float g[3] = {q.y / bx.s, q.z / bx.s, q.w / bx.s};
-        bool act = (q.y != 0.f) | (q.z != 0.f) | (q.w != 0.f);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (v == bx.imin[a]) { g[a] += gcf[a] / 2.f; act = true; if (a == bx.amax) g[a] -= gsf; }
-            if (v == bx.imax[a]) { g[a] += gcf[a] / 2.f; act = true; if (a == bx.amax) g[a] += gsf; }
-        }
-        if (act) { eb[pos].v = v; eb[pos].g[0] = g[0]; eb[pos].g[1] = g[1]; eb[pos].g[2] = g[2]; ++pos; }
-    }
-    __syncthreads();            // entries of this workgroup are visible to it (workgroup-scope release/acquire)
-    // ---- phase 1: wave per entry - v_posed (lbs.py:179,203), blended transform (lbs.py:209-213), g_vposed = Tr^T g ----
-    for (int e = wave; e < n; e += SDF_ADJ_NT / 64) {
-        const int v = eb[e].v;
-        const float g0 = eb[e].g[0], g1 = eb[e].g[1], g2 = eb[e].g[2];
-        const float* bsv = M.bs_vm + (size_t)v * 3 * KROWS;
-        float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = lane + 64 * q;
-            if (p < KROWS) {
-                const float cf = sh_coef[p];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] += cf * bsv[k * KROWS + p];
+        for (int i = 0; i < 8; ++i) {
+            const int v = c0 + (h + i) * 64 + lane;
+            const bool in = v < c1;
+            const float4 qq = q[h + i];
+            S += (double)qq.x;
+            bool act = (qq.y != 0.f) | (qq.z != 0.f) | (qq.w != 0.f);
+            if (act) {                                  // rare: only vertices next to a non-zero voxel
+                const float l0 = (px[i] - bx.c[0]) / bx.s, l1 = (py[i] - bx.c[1]) / bx.s, l2 = (pz[i] - bx.c[2]) / bx.s;
+                gc0 -= (double)(qq.y / bx.s); gc1 -= (double)(qq.z / bx.s); gc2 -= (double)(qq.w / bx.s);
+                gs -= (double)(qq.y * l0 / bx.s); gs -= (double)(qq.z * l1 / bx.s); gs -= (double)(qq.w * l2 / bx.s);
             }
-        }
-        float vp[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vp[k] = M.vt_planes[(size_t)k * M.nv_pad + v] + wave64_sum(acc[k]);
-        float tl = 0.f;
-        if (lane < 12)
-            for (int j = 0; j < NJ; ++j) tl += M.w_vm[(size_t)v * NJ + j] * sh_A[j * 12 + lane];
-        float T[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = lane_read(tl, i);
-        if (lane == 0) {
-            pb[e].vposed[0] = vp[0]; pb[e].vposed[1] = vp[1]; pb[e].vposed[2] = vp[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pb[e].gvp[k] = T[k] * g0 + T[4 + k] * g1 + T[8 + k] * g2;
+            act |= (v == bx.imin[0]) | (v == bx.imin[1]) | (v == bx.imin[2]) | (v == bx.imax[0]) | (v == bx.imax[1]) | (v == bx.imax[2]);
+            act &= in;
+            if (act) actmask |= 1u << (h + i);
+            cnt += __popcll(__ballot(act));
         }
     }
+    S = wave64_sum(S); gc0 = wave64_sum(gc0); gc1 = wave64_sum(gc1); gc2 = wave64_sum(gc2); gs = wave64_sum(gs);
+    if (lane == 0) { sh_d[wave][0] = S; sh_d[wave][1] = gc0; sh_d[wave][2] = gc1; sh_d[wave][3] = gc2; sh_d[wave][4] = gs; sh_cnt[wave] = cnt; }
     __syncthreads();
-    // ---- phase 2: thread per output, entries in ascending order ----
+    S = 0.0; gc0 = 0.0; gc1 = 0.0; gc2 = 0.0; gs = 0.0;
+    int base = 0, n = 0;
+    for (int w = 0; w < 8; ++w) {
+        S += sh_d[w][0]; gc0 += sh_d[w][1]; gc1 += sh_d[w][2]; gc2 += sh_d[w][3]; gs += sh_d[w][4];
+        if (w < wave) base += sh_cnt[w];
+        n += sh_cnt[w];
+    }
+    // ---- pass B: dS/dvertex of the active vertices -> entry list (ballot compaction, ascending order) ----
+    const float gcf[3] = {(float)gc0, (float)gc1, (float)gc2};
+    const float gsf = (float)gs * (float)((1 + 0.2) * 0.5);
+#pragma unroll
+    for (int i = 0; i < SDF_NIT; ++i) {
+        const int v = c0 + i * 64 + lane;
+        const bool act = (actmask >> i) & 1u;
+        const unsigned long long bal = __ballot(act);
+        if (act) {
+            float g[3] = {q[i].y / bx.s, q[i].z / bx.s, q[i].w / bx.s};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (v == bx.imin[a]) { g[a] += gcf[a] / 2.f; if (a == bx.amax) g[a] -= gsf; }
+                if (v == bx.imax[a]) { g[a] += gcf[a] / 2.f; if (a == bx.amax) g[a] += gsf; }
+            }
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            *reinterpret_cast<float4*>(&eb[pos]) = make_float4(__builtin_bit_cast(float, v), g[0], g[1], g[2]);
+        }
+        base += __popcll(bal);
+    }
+    __syncthreads();            // the entries written by this workgroup are visible to all of its waves
+    // ---- pull-back through skinning and the blendshape basis, SDF_EB entries at a time ----
     float acc = 0.f;
     const int oj = tid >= KROWS ? (tid - KROWS) / 12 : 0, oe = tid >= KROWS ? (tid - KROWS) % 12 : 0;
-    float gt[3] = {0.f, 0.f, 0.f};
+    float gtv = 0.f;
     for (int e0 = 0; e0 < n; e0 += SDF_EB) {
         const int ne = min(SDF_EB, n - e0);
         __syncthreads();
-        for (int i = tid; i < ne * 4; i += SDF_ADJ_NT) reinterpret_cast<float*>(sh_e)[i] = reinterpret_cast<const float*>(eb + e0)[i];
-        for (int i = tid; i < ne * 8; i += SDF_ADJ_NT) reinterpret_cast<float*>(sh_p)[i] = reinterpret_cast<const float*>(pb + e0)[i];
+        if (tid < ne) reinterpret_cast<float4*>(sh_e)[tid] = reinterpret_cast<const float4*>(eb + e0)[tid];
         __syncthreads();
-        for (int e = 0; e < ne; ++e) {
-            const SdfEntry& E = sh_e[e];
-            const SdfPull& Q = sh_p[e];
-            if (tid < KROWS) {
-                const float* bsv = M.bs_vm + (size_t)E.v * 3 * KROWS + tid;
-                acc += bsv[0] * Q.gvp[0] + bsv[KROWS] * Q.gvp[1] + bsv[2 * KROWS] * Q.gvp[2];
-                if (tid < 3) gt[tid] += E.g[tid];
-            } else {
-                const float w = M.w_vm[(size_t)E.v * NJ + oj];
-                acc += w * (oe < 9 ? E.g[oe / 3] * Q.vposed[oe % 3] : E.g[oe - 9]);
+        // v_posed = v_template + coef . basis  (lbs.py:179,203): thread per (entry, coordinate, quarter row),
+        // 14 independent 16-byte loads in flight per thread
+#pragma unroll 1
+        for (int it = tid; it < ne * 12; it += SDF_ADJ_NT) {
+            const int e = it / 12, r6 = it - 12 * e, k = r6 >> 2, h = r6 & 3;
+            const int v = sh_e[e].v;
+            const float4* row = reinterpret_cast<const float4*>(M.bs_vm + ((size_t)v * 3 + k) * KROWS) + h * (KROWS / 16);
+            float4 r[KROWS / 16];
+#pragma unroll
+            for (int p4 = 0; p4 < KROWS / 16; ++p4) r[p4] = row[p4];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int p4 = 0; p4 < KROWS / 16; ++p4) {
+                const float4 cf = reinterpret_cast<const float4*>(sh_coef)[h * (KROWS / 16) + p4];
+                a0 += cf.x * r[p4].x; a1 += cf.y * r[p4].y; a2 += cf.z * r[p4].z; a3 += cf.w * r[p4].w;
+            }
+            sh_part[e][k][h] = (a0 + a1) + (a2 + a3);
+        }
+        // blended transform rows (lbs.py:209-213): thread per (entry, element)
+#pragma unroll 1
+        for (int it = tid; it < ne * 12; it += SDF_ADJ_NT) {
+            const int e = it / 12, l = it - 12 * e;
+            const float* wr = M.w_vm + (size_t)sh_e[e].v * NJ;
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) t += wr[j] * sh_A[j * 12 + l];
+            sh_T[e][l] = t;
+        }
+        __syncthreads();
+        for (int it = tid; it < ne * 3; it += SDF_ADJ_NT) {                  // g_vposed = Tr^T g
+            const int e = it / 3, k = it - 3 * e;
+            sh_vp[e][k] = M.vt_planes[(size_t)k * M.nv_pad + sh_e[e].v] + ((sh_part[e][k][0] + sh_part[e][k][1]) + (sh_part[e][k][2] + sh_part[e][k][3]));
+            sh_gvp[e][k] = sh_T[e][k] * sh_e[e].g[0] + sh_T[e][4 + k] * sh_e[e].g[1] + sh_T[e][8 + k] * sh_e[e].g[2];
+        }
+        __syncthreads();
+        // thread per output, entries in ascending order: g_coef[224] | g_A[24][12]
+        if (tid < KROWS) {
+#pragma unroll 16
+            for (int e = 0; e < ne; ++e) {
+                const float* bsv = M.bs_vm + (size_t)sh_e[e].v * 3 * KROWS + tid;
+                acc += bsv[0] * sh_gvp[e][0] + bsv[KROWS] * sh_gvp[e][1] + bsv[2 * KROWS] * sh_gvp[e][2];
+            }
+            if (tid < 3) for (int e = 0; e < ne; ++e) gtv += sh_e[e].g[tid];
+        } else {
+#pragma unroll 8
+            for (int e = 0; e < ne; ++e) {
+                const float w = M.w_vm[(size_t)sh_e[e].v * NJ + oj];
+                acc += w * (oe < 9 ? sh_e[e].g[oe / 3] * sh_vp[e][oe % 3] : sh_e[e].g[oe - 9]);
             }
         }
     }
     SdfAdj& O = out[b];
     if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
-    if (tid < 3) O.gtau[tid] = gt[tid];
+    if (tid < 3) O.gtau[tid] = gtv;
     if (tid == 0) { O.S = (float)S; }
 }
 
@@ -334,10 +386,10 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
                        (const SdfBox*)box, faces, num_faces, G, gate, samp);
     hipLaunchKernelGGL(sdf_adjoint_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, M, verts, (const SdfBox*)box,
-                       (const float4*)samp, P, gate, reinterpret_cast<unsigned char*>(entries), adj);
+                       (const float4*)samp, P, gate, reinterpret_cast<SdfEntry*>(entries), adj);
     return hipGetLastError();
 }
 
-size_t sdf_entry_bytes() { return 48; }     // per vertex: SdfEntry + SdfPull
+size_t sdf_entry_bytes() { return sizeof(SdfEntry); }
 
 }  // namespace mvfit

@@ -104,12 +104,18 @@ class BodyModel(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------- loss holder
 class SMPLifyLoss:
     """Weights and prior selection of reference ``SMPLifyLoss`` (fitting.py:215-280).  ``forward`` is
-    evaluated inside libmvfit; this object only carries what it is configured with."""
+    evaluated inside libmvfit; this object only carries what it is configured with.
+
+    ``interpenetration`` (reference default True, fitting.py:224): the SDF term of fitting.py:352-393 is active
+    whenever ``coll_loss_weight > 0``.  ``sdf_num_faces`` (an addition): how many leading triangles the SDF op
+    sees - 1 is what the reference's call site produces (faces.reshape(1, -1, 3), :367-368), None = all."""
 
     def __init__(self, rho=100, body_pose_prior=None, shape_prior=None, angle_prior=None,
-                 use_joints_conf=True, interpenetration=False, dtype=torch.float32, data_weight=1.0,
+                 use_joints_conf=True, interpenetration=True, dtype=torch.float32, data_weight=1.0,
                  body_pose_weight=0.0, shape_weight=0.0, bending_prior_weight=0.0,
-                 coll_loss_weight=0.0, reduction='sum', use_3d=False, **kwargs):
+                 coll_loss_weight=0.0, reduction='sum', use_3d=False, sdf_num_faces=1, sdf_grid_size=128,
+                 **kwargs):
+        self.sdf_num_faces, self.sdf_grid_size = sdf_num_faces, int(sdf_grid_size)
         self.use_3d = bool(use_3d)
         self.rho = float(rho)
         self.body_pose_prior = body_pose_prior
@@ -222,6 +228,13 @@ class _HipClosure:
             c3 = torch.as_tensor(joints3d_conf, dtype=torch.float32, device=dev).reshape(1, 17)
             eng.set_joints3d(g3, c3)
             self.flags |= _lib.F_USE_3D
+        if loss.interpenetration:                        # fitting.py:157,181,251-253,367-368
+            faces = model_arrays(body_model).get('faces')
+            if faces is None:
+                raise MvFitError('interpenetration=True needs body_model.faces_tensor')
+            eng.set_sdf(faces, num_faces=loss.sdf_num_faces, grid_size=loss.sdf_grid_size)
+        else:
+            eng.set_sdf(None)
         if isinstance(loss.body_pose_prior, object) and hasattr(loss.body_pose_prior, 'precisions'):
             self.flags |= _lib.F_PRIOR_GMM
         if not self.params['betas'].requires_grad or loss.fix_shape:

@@ -11,7 +11,7 @@ import torch
 
 from mvsmplfitting_amd import fitting as mf
 from mvsmplfitting_amd.engine import YAML_POSE_W, YAML_SHAPE_W
-from tests.helpers import GOLD, body_model, load_case
+from tests.helpers import GOLD, body_model, load_case, oracle_for
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +89,35 @@ def test_stage_loop_like_non_linear_solver():
         # the fitted values are left in the torch Parameters (non_linear_solver.py:284-287)
         chk = float(closure(backward=False))
         assert chk <= final * (1 + 1e-3) + 1e-3
+
+
+def test_closure_seam_with_interpenetration():
+    """create_loss(interpenetration=True) + coll_loss_weight > 0 through the reference's seams: the SDF term
+    of fitting.py:352-393 as wired (first triangle only, grid 128)."""
+    from oracle import sdf_term_np as st
+    cfg, g, model, vpw, gmm, wts, cams = load_case('l2_s3_v6')
+    orc = oracle_for(model, vpw, gmm)
+    bm = mf.BodyModel(model)
+    loss = mf.create_loss(loss_type='smplify', rho=wts['rho'], body_pose_prior=None)     # interpenetration defaults to True
+    assert loss.interpenetration
+    cw = 40.0
+    loss.reset_loss_weights({k: torch.tensor(v) for k, v in dict(wts, coll_loss_weight=cw).items() if k != 'rho'})
+    monitor = mf.FittingMonitor(maxiters=30, ftol=1e-9, gtol=1e-9)
+    x = g['x'][0]
+    bm.reset_params(betas=x[0:10], global_orient=x[10:13], body_pose=x[13:82], transl=x[82:85], scale=x[85:86])
+    params = [p for p in bm.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0)
+    gt_joints, joints_conf, jw = _frame_inputs(g, 0)
+    closure = monitor.create_fitting_closure(opt, bm, camera=_cameras(g), gt_joints=gt_joints, loss=loss,
+                                             joints_conf=joints_conf, joint_weights=jw, use_vposer=False)
+    val = float(closure(backward=True))
+    verts = closure.eng.closure(closure.pack(), loss.weights(closure.flags), want_grad=False, want_verts=True)['verts']
+    pen, g_sdf, aux = st.sdf_term(verts[0].cpu().numpy().astype(np.float64), model['faces'], cw, 1, 128)
+    assert aux['S'] > 0
+    Lr, gr, _ = orc.closure(x, cams, g['gt_xy'][0], g['conf'][0], dict(wts, coll_loss_weight=0.0), g_verts_extra=g_sdf)
+    assert abs(val - (Lr + pen)) <= 1e-5 * abs(Lr + pen)
+    grad = torch.cat([p.grad.reshape(-1) for p in params]).cpu().numpy().astype(np.float64)
+    assert np.abs(grad - gr).max() <= 2e-4 * np.abs(gr).max()
+    # weight 0 -> the term is off (fitting.py:354)
+    loss.reset_loss_weights({'coll_loss_weight': 0.0})
+    assert abs(float(closure(backward=False)) - Lr) <= 1e-5 * abs(Lr)
