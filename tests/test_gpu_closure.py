@@ -172,3 +172,37 @@ def test_ragged_batches_and_errors():
     with pytest.raises(MvFitError):
         eng.closure(x[B - 1:], dict(stage_weights(0), flags=0, coll_loss_weight=10.0))
     eng.close()
+
+
+@pytest.mark.parametrize('V', [1, 16])
+def test_view_count_extremes_and_per_problem_cameras(V):
+    """1 view and MVFIT_MAX_VIEWS views, cameras given per problem ([B,V,...]) - against the oracle; one view
+    more than the maximum is refused."""
+    model = body_model()
+    orc = oracle_for(model, None, None)
+    B = 3
+    rng = np.random.default_rng(40 + V)
+    rigs = [syn.make_camera_ring(V, radius=3.5 + 0.4 * b, height=0.2 * b) for b in range(B)]
+    cams_b = tuple(np.stack([rigs[b][i] for b in range(B)]) for i in range(4))      # [B,V,...]
+    x86 = rng.normal(0, 0.12, (B, 86)); x86[:, 85] = 1.0 + rng.normal(0, 0.05, B)
+    x = np.stack([to118(x86[b], False) for b in range(B)]).astype(np.float32)
+    gt = rng.uniform(300, 1700, (B, V, 17, 2)).astype(np.float32)
+    conf = rng.uniform(0.0, 1.0, (B, V, 17)).astype(np.float32)
+    conf[conf < 0.2] = 0.0                                         # undetected keypoints
+    wts = stage_weights(2)
+    eng = make_engine(model)
+    eng.set_problems(cams_b, gt, conf)
+    for sparse in (False, True):
+        out = eng.closure(x, dict(wts, flags=_lib.F_SPARSE_VERTS if sparse else 0))
+        loss = out['loss'].cpu().numpy().astype(np.float64)
+        grad = out['grad'].cpu().numpy().astype(np.float64)
+        for b in range(B):
+            Lr, gr, _ = orc.closure(x86[b].astype(np.float32).astype(np.float64), rigs[b], gt[b], conf[b], wts)
+            assert abs(loss[b] - Lr) <= LOSS_RTOL * abs(Lr)
+            assert np.abs(grad[b][:86] - gr).max() <= GRAD_RTOL * np.abs(gr).max()
+    if V == 16:
+        from mvsmplfitting_amd.engine import MvFitError
+        cams17 = syn.make_camera_ring(17)
+        with pytest.raises(MvFitError):
+            eng.set_problems(cams17, np.zeros((1, 17, 17, 2), np.float32), np.ones((1, 17, 17), np.float32))
+    eng.close()
