@@ -96,7 +96,7 @@ struct ClosureLds {
     // VPoser activations (decoder fwd/bwd)
     float vp_pre1[512];
     float vp_pre2[512];
-    float vp_h[512];
+    __attribute__((aligned(16))) float vp_h[512];
     float vp_g[512];
     float vp_o[144];
     float vp_go[144];
@@ -174,59 +174,90 @@ __device__ __forceinline__ void rodrigues(const float* r, float* R, float* rod) 
     rod[0] = a; rod[1] = sn; rod[2] = cs;
 }
 
+// Streamed GEMV for the decoder: out[o] = sum_{i < n} W[i * ld + o] * h[i], o < ncols (multiple of 4).
+// Thread = (row slice sl, column quad q): 16-byte loads, U rows requested before the first FMA - the weights
+// arrive from the Infinity Cache / HBM (the L2 does not keep 2.8 MB of decoder weights next to the basis
+// streams), so the stream is bound by bytes in flight per CU.  Partials go to part[sl * ncols + o]; the caller
+// sums the slices in ascending order after a barrier (deterministic, independent of the launch geometry).
+template <int U>
+__device__ __forceinline__ void gemv4_partial(const float* __restrict__ W, int ld, int n, int ncols, int nsl,
+                                              const float* h, float* part, int tid) {
+    const int nq = ncols >> 2;
+    const int sl = tid / nq, q = tid - sl * nq;
+    if (sl >= nsl) return;
+    const int per = (n + nsl - 1) / nsl;
+    const int i0 = sl * per, i1 = min(n, i0 + per);
+    const float4* Wq = reinterpret_cast<const float4*>(W) + q;
+    const int ld4 = ld >> 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = i0;
+    for (; i + U <= i1; i += U) {
+        float4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = Wq[(size_t)(i + u) * ld4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float hv = h[i + u];
+            acc.x = fmaf(w[u].x, hv, acc.x); acc.y = fmaf(w[u].y, hv, acc.y);
+            acc.z = fmaf(w[u].z, hv, acc.z); acc.w = fmaf(w[u].w, hv, acc.w);
+        }
+    }
+    if (i < i1) {                                    // last, partial chunk: clamped row index, zero multiplier
+        float4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = Wq[(size_t)min(i + u, i1 - 1) * ld4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float hv = (i + u < i1) ? h[min(i + u, i1 - 1)] : 0.f;
+            acc.x = fmaf(w[u].x, hv, acc.x); acc.y = fmaf(w[u].y, hv, acc.y);
+            acc.z = fmaf(w[u].z, hv, acc.z); acc.w = fmaf(w[u].w, hv, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(&part[sl * ncols + 4 * q]) = acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // VPoser decoder forward (VPoser.py:218-232,165-174,263-273,29-156) for one latent, block-wide.
 // Weight rows are streamed with the whole block; every GEMV output is k-split over lanes.
 // ---------------------------------------------------------------------------------------------
+constexpr int VP_U = 16;          // rows (16-byte loads) in flight per thread in the decoder streams
+
 __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
     constexpr int nt = STEP_NT;
     // h1 = lrelu(W1 z + b1): one output per thread
     for (int o = tid; o < 512; o += nt) {
         float s = M.vp_b1[o];
-        const float4* w = reinterpret_cast<const float4*>(M.vp_w1 + o * 32);
+        float w[32];                                   // transposed copy: consecutive threads, consecutive addresses
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = w[i];
-            s = fmaf(v.x, L.opt.x[X_EMB + 4 * i], s); s = fmaf(v.y, L.opt.x[X_EMB + 4 * i + 1], s);
-            s = fmaf(v.z, L.opt.x[X_EMB + 4 * i + 2], s); s = fmaf(v.w, L.opt.x[X_EMB + 4 * i + 3], s);
-        }
+        for (int i = 0; i < 32; ++i) w[i] = M.vp_w1T[i * 512 + o];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s = fmaf(w[i], L.opt.x[X_EMB + i], s);
         L.vp_pre1[o] = s;
         L.vp_h[o] = s > 0.f ? s : 0.2f * s;
     }
     __syncthreads();
+    PH_T(26);
     // h2 = lrelu(W2 h1 + b2): w2T[i][o], thread o, consecutive threads read consecutive o
+    gemv4_partial<VP_U>(M.vp_w2T, 512, 512, 512, 4, L.vp_h, L.scratch, tid);
+    __syncthreads();
     for (int o = tid; o < 512; o += nt) {
-        float s0 = M.vp_b2[o], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-        for (int i = 0; i < 512; i += 4) {
-            s0 = fmaf(M.vp_w2T[(i + 0) * 512 + o], L.vp_h[i + 0], s0);
-            s1 = fmaf(M.vp_w2T[(i + 1) * 512 + o], L.vp_h[i + 1], s1);
-            s2 = fmaf(M.vp_w2T[(i + 2) * 512 + o], L.vp_h[i + 2], s2);
-            s3 = fmaf(M.vp_w2T[(i + 3) * 512 + o], L.vp_h[i + 3], s3);
-        }
-        L.vp_pre2[o] = (s0 + s1) + (s2 + s3);
+        const float s = M.vp_b2[o] + (((L.scratch[o] + L.scratch[512 + o]) + L.scratch[1024 + o]) + L.scratch[1536 + o]);
+        L.vp_pre2[o] = s;
+        L.vp_h[o] = s > 0.f ? s : 0.2f * s;
     }
     __syncthreads();
-    for (int o = tid; o < 512; o += nt) { float s = L.vp_pre2[o]; L.vp_h[o] = s > 0.f ? s : 0.2f * s; }
+    PH_T(27);
+    // out = W3 h2 + b3: 36 column quads (144 padded outputs) x 14 row slices
+    gemv4_partial<VP_U>(M.vp_w3T, 144, 512, 144, 14, L.vp_h, L.scratch, tid);
     __syncthreads();
-    // out = W3 h2 + b3: 144 padded outputs x 3 k-slices (432 threads)
-    {
-        const int o = tid % 144, ks = tid / 144;
-        if (ks < 3) {
-            const int i0 = ks * 171, i1 = min(512, i0 + 171);
-            float s0 = 0.f, s1 = 0.f;
-            int i = i0;
-            for (; i + 1 < i1; i += 2) {
-                s0 = fmaf(M.vp_w3T[i * 144 + o], L.vp_h[i], s0);
-                s1 = fmaf(M.vp_w3T[(i + 1) * 144 + o], L.vp_h[i + 1], s1);
-            }
-            if (i < i1) s0 = fmaf(M.vp_w3T[i * 144 + o], L.vp_h[i], s0);
-            L.scratch[ks * 144 + o] = s0 + s1;
-        }
+    for (int o = tid; o < 138; o += nt) {
+        float sacc = M.vp_b3[o];
+#pragma unroll
+        for (int sl = 0; sl < 14; ++sl) sacc += L.scratch[sl * 144 + o];
+        L.vp_o[o] = sacc;
     }
     __syncthreads();
-    for (int o = tid; o < 138; o += nt) L.vp_o[o] = M.vp_b3[o] + ((L.scratch[o] + L.scratch[144 + o]) + L.scratch[288 + o]);
-    __syncthreads();
+    PH_T(28);
     // per joint: Gram-Schmidt -> R^T rows -> quaternion (4-way branch) -> axis-angle
     for (int j = tid; j < 23; j += nt) {
         float* C = L.vp_cache[j];
@@ -344,35 +375,34 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
         for (int c = 0; c < 3; ++c) { go[2 * c] = (gb1[c] - b1[c] * pa) / n1; go[2 * c + 1] = ga2[c]; }
     }
     __syncthreads();
+    PH_T(29);
     // g_h2 = W3^T g_o ; through lrelu.  w3[o][i]: thread i, consecutive threads consecutive addresses
-    for (int i = tid; i < 512; i += nt) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll 3
-        for (int o = 0; o < 138; o += 2) {
-            s0 = fmaf(M.vp_w3[o * 512 + i], L.vp_go[o], s0);
-            s1 = fmaf(M.vp_w3[(o + 1) * 512 + i], L.vp_go[o + 1], s1);
-        }
-        L.vp_g[i] = (s0 + s1) * (L.vp_pre2[i] > 0.f ? 1.0f : 0.2f);
-    }
+    gemv4_partial<VP_U>(M.vp_w3, 512, 138, 512, 4, L.vp_go, L.scratch, tid);
     __syncthreads();
+    for (int i = tid; i < 512; i += nt)
+        L.vp_g[i] = (((L.scratch[i] + L.scratch[512 + i]) + L.scratch[1024 + i]) + L.scratch[1536 + i]) * (L.vp_pre2[i] > 0.f ? 1.0f : 0.2f);
+    __syncthreads();
+    PH_T(30);
     // g_h1 = W2^T g_pre2 : w2[o][i], consecutive threads i -> consecutive addresses
-    for (int i = tid; i < 512; i += nt) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-        for (int o = 0; o < 512; o += 4) {
-            s0 = fmaf(M.vp_w2[(o + 0) * 512 + i], L.vp_g[o + 0], s0);
-            s1 = fmaf(M.vp_w2[(o + 1) * 512 + i], L.vp_g[o + 1], s1);
-            s2 = fmaf(M.vp_w2[(o + 2) * 512 + i], L.vp_g[o + 2], s2);
-            s3 = fmaf(M.vp_w2[(o + 3) * 512 + i], L.vp_g[o + 3], s3);
-        }
-        L.vp_h[i] = ((s0 + s1) + (s2 + s3)) * (L.vp_pre1[i] > 0.f ? 1.0f : 0.2f);
-    }
+    gemv4_partial<VP_U>(M.vp_w2, 512, 512, 512, 4, L.vp_g, L.scratch, tid);
     __syncthreads();
+    for (int i = tid; i < 512; i += nt)
+        L.vp_h[i] = (((L.scratch[i] + L.scratch[512 + i]) + L.scratch[1024 + i]) + L.scratch[1536 + i]) * (L.vp_pre1[i] > 0.f ? 1.0f : 0.2f);
+    __syncthreads();
+    PH_T(31);
     // g_z = W1^T g_pre1: 32 outputs x 16 k-slices, DPP row reduction (lane&15 = slice)
     {
-        const int i = tid >> 4, ks = tid & 15;        // 512 threads = 32 outputs x 16 slices
+        const int i = tid >> 4, ks = tid & 15;        // 512 threads = 32 outputs x 16 slices of 32 consecutive rows
+        const float4* wr = reinterpret_cast<const float4*>(M.vp_w1T + (size_t)i * 512 + ks * 32);
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = wr[u];
         float s = 0.f;
-        for (int o = ks; o < 512; o += 16) s = fmaf(M.vp_w1[o * 32 + i], L.vp_h[o], s);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 hv = *reinterpret_cast<const float4*>(&L.vp_h[ks * 32 + 4 * u]);
+            s = fmaf(w[u].x, hv.x, s); s = fmaf(w[u].y, hv.y, s); s = fmaf(w[u].z, hv.z, s); s = fmaf(w[u].w, hv.w, s);
+        }
         s = row16_sum(s);
         if (ks == 0) L.grad[X_EMB + i] += s;
     }

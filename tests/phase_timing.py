@@ -2,7 +2,7 @@
 import sys, os, ctypes as C, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
+subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
 import numpy as np, torch
 from mvsmplfitting_amd import _lib, synthetic as syn
 from mvsmplfitting_amd.engine import MvFit, stage_weights
@@ -27,6 +27,7 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     print('   ', ' | '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(13)), '| total=%.0f cycles/round' % (sum(buf[i] for i in range(13))/n))
     print('    step-kernel prologue=%.0f epilogue (state store + pose/chain of next x + publish)=%.0f' % (buf[24]/n, buf[25]/n))
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
+    print('    vposer: L1=%.0f L2=%.0f out=%.0f | (GS+quat in pose_prep rest) | bwd: joints=%.0f W3T=%.0f W2T=%.0f (W1T in E9 rest)' % tuple(buf[i]/n for i in (26,27,28,29,30,31)))
     if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
     print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
 
