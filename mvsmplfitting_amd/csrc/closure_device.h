@@ -55,7 +55,14 @@ struct OptBlock {                   // optimiser state that survives between clo
     LbState lbS;
     float lbV[LB_NVEC][LB_D];
 };
-static_assert(sizeof(ObsBlock) % 16 == 0 && sizeof(PoseBlock) % 16 == 0 && sizeof(OptBlock) % 16 == 0, "16-byte blocks");
+struct VpBlock {                    // VPoser decoder state of the current trial point (image of ClosureLds::vp_pre1..vp_cpad)
+    float pre1[512];
+    float pre2[512];
+    float cache[23][25];
+    float pad;
+};
+static_assert(sizeof(ObsBlock) % 16 == 0 && sizeof(PoseBlock) % 16 == 0 && sizeof(OptBlock) % 16 == 0 && sizeof(VpBlock) % 16 == 0,
+              "16-byte blocks");
 
 struct ClosureLds {
     ModelLds M;                     // model constants
@@ -94,13 +101,15 @@ struct ClosureLds {
     // scratch for k-split partial sums: max(8 * nc_pad, 8 * KROWS)
     __attribute__((aligned(16))) float scratch[8 * NC_MAX];
     // VPoser activations (decoder fwd/bwd)
-    float vp_pre1[512];
+    // what the decoder adjoint needs from the forward: handed from launch to launch as one block (VpBlock)
+    __attribute__((aligned(16))) float vp_pre1[512];
     float vp_pre2[512];
+    float vp_cache[23][25];
+    float vp_cpad;
     __attribute__((aligned(16))) float vp_h[512];
     float vp_g[512];
     float vp_o[144];
     float vp_go[144];
-    float vp_cache[23][25];
     // GMM
     float gmm_d[72];
     float gmm_t[8][72];
@@ -116,7 +125,8 @@ struct ClosureLds {
 // the first wait.  Null pointers skip a block; x_g (flat parameters, DV floats) fills L.opt.x.
 __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const ObsBlock* obs_g, const PoseBlock* pose_g,
                                          const OptBlock* opt_g, const float* vposed_g, const float* xs_g,
-                                         const float* x_g, int tid, const SdfAdj* sdf_adj = nullptr) {
+                                         const float* x_g, int tid, const SdfAdj* sdf_adj = nullptr,
+                                         const VpBlock* vp_g = nullptr) {
     constexpr int n16 = sizeof(ModelLds) / 16;
     constexpr int nobs = sizeof(ObsBlock) / 16, npose = sizeof(PoseBlock) / 16, nopt = sizeof(OptBlock) / 16;
     static_assert(n16 <= 3 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
@@ -134,6 +144,9 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     const float4 vvps = (vposed_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(vposed_g)[tid] : z;
     const float4 vxss = (xs_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(xs_g)[tid] : z;
     const float xv = (x_g && tid < DV) ? x_g[tid] : 0.f;
+    constexpr int nvp = sizeof(VpBlock) / 16;
+    static_assert(nvp <= STEP_NT, "one word per thread");
+    const float4 vvp = (vp_g && tid < nvp) ? reinterpret_cast<const float4*>(vp_g)[tid] : z;
     int4* dst = reinterpret_cast<int4*>(&L.M);
     if (tid < n16) dst[tid] = m0;
     if (tid + STEP_NT < n16) dst[tid + STEP_NT] = m1;
@@ -144,6 +157,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     if (opt_g && tid < nopt) reinterpret_cast<float4*>(&L.opt)[tid] = vopt;
     if (vposed_g && tid < NC_MAX / 4) { reinterpret_cast<float4*>(L.vposed)[tid] = vvps; reinterpret_cast<float4*>(L.xs)[tid] = vxss; }
     if (x_g && tid < DPAD) L.opt.x[tid] = xv;
+    if (vp_g && tid < nvp) reinterpret_cast<float4*>(L.vp_pre1)[tid] = vvp;
     if (tid >= 384 && tid < 384 + 8 * 12) (&L.gG[NJ][0])[tid - 384] = 0.f;               // "no child" rows
     if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; }
 }

@@ -43,6 +43,7 @@ struct FitBuffers {
     float* gcol;         // [B][LB_GSIZE]
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
     int* n_done;         // [1]
+    VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
     const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
     int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
 };
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
         pose_and_chain(M, L, flags, tid);
         publish_pose(L, P, b, tid);
         store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
+        if (flags & MVFIT_F_VPOSER) store_block16(F.vp + b, L.vp_pre1, sizeof(VpBlock), tid);
     }
 }
 
@@ -199,9 +201,8 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     const LbOpts& O = L.opts;
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     PH_T0();
-    // have_pose: the previous launch left the pose block of this x (not the VPoser activations, which
-    // the adjoint needs: with VPoser the decoder is re-run)
-    have_pose = have_pose && !use_vp;
+    // have_pose: the previous launch left the pose block of this x (and, with VPoser, the decoder state the
+    // adjoint needs - the VpBlock)
     if (!have_pose) pose_prep(M, L, W.flags, tid);
     PH_T(0);
     sparse_forward(M, L, from_pass, tid, !have_pose);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     const int b = blockIdx.x, tid = threadIdx.x;
     PH_T0();
     prologue(L, M, obs + b, F.pose + b, F.opt + b, P.vposed_sel + (size_t)b * NC_MAX, P.xs_sel + (size_t)b * NC_MAX, nullptr, tid,
-             F.sdf_adj ? F.sdf_adj + b : nullptr);
+             F.sdf_adj ? F.sdf_adj + b : nullptr, (SW.w[0].flags & MVFIT_F_VPOSER) ? F.vp + b : nullptr);
     opts_in(L, SW, O, tid);
     __syncthreads();
     if (L.opt.lbS.status != 0) return;                    // uniform per block
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
     store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
+    if (SW.w[0].flags & MVFIT_F_VPOSER) store_block16(F.vp + b, L.vp_pre1, sizeof(VpBlock), tid);
     PH_T(25);
 }
 
@@ -800,7 +802,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
-                  c->d_sdf_adj, c->F.sdf_gate};
+                  c->d_sdf_adj, c->F.sdf_gate, c->F.vp};
     for (void* p : ps) if (p) hipFree(p);
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
     c->d_obs = nullptr;
@@ -861,6 +863,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
         HIP_OK(c, hipMalloc(&c->F.n_done, 4));
         HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
+        HIP_OK(c, hipMalloc(&c->F.vp, (size_t)B * sizeof(VpBlock)));
         c->B = B; c->V = V; c->Bpad = Bpad;
     }
     const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
