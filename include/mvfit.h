@@ -188,6 +188,10 @@ int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 int mvfit_profile(mvfit_ctx* ctx, int enable);
 int mvfit_profile_read(mvfit_ctx* ctx, double* vertex_pass_ms_avg, int* launches,
                        double* step_kernel_ms_avg, int* step_launches);
+/* `launches` back-to-back launches of the vertex pass (pose operands as the last closure / fit left them)
+ * inside ONE hipEvent pair on the ctx stream; *avg_ms = elapsed / launches.  A pair around a single launch
+ * (mvfit_profile_read) contains the markers' own few microseconds; this amortises them. */
+int mvfit_profile_vertex_pass(mvfit_ctx* ctx, int launches, double* avg_ms);
 
 /* Known-answer test entry for the device L-BFGS state machine (same template as production,
  * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.

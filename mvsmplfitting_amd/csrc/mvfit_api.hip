@@ -11,6 +11,7 @@
 //   lbfgs_kat_kernel   float64 instantiation of the state machine on analytic objectives
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1209,6 +1210,28 @@ extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, cons
 extern "C" int mvfit_profile(mvfit_ctx* c, int enable) {
     if (!c) return MVFIT_E_ARG;
     c->profile = enable != 0;
+    return MVFIT_OK;
+}
+
+// n back-to-back launches of the vertex pass on the pose operands the last closure / fit left behind,
+// bracketed by ONE hipEvent pair on the ctx stream: elapsed / n is the per-launch duration with the event
+// markers' own ~2-4 us amortised away (a pair around a single launch over-reports by about that much).
+extern "C" int mvfit_profile_vertex_pass(mvfit_ctx* c, int launches, double* avg_ms) {
+    if (!c || !avg_ms || launches <= 0) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    HIP_OK(c, hipSetDevice(c->device));
+    hipEvent_t a, b;
+    HIP_OK(c, hipEventCreate(&a)); HIP_OK(c, hipEventCreate(&b));
+    hipError_t e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, c->stream);      // warm
+    HIP_OK(c, hipEventRecord(a, c->stream));
+    for (int i = 0; i < launches && e == hipSuccess; ++i) e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, c->stream);
+    HIP_OK(c, hipEventRecord(b, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    hipError_t e2 = hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass timing failed");
+    *avg_ms = (double)ms / launches;
     return MVFIT_OK;
 }
 

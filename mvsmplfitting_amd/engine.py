@@ -238,6 +238,12 @@ class MvFit:
     def profile(self, enable=True):
         self._check(self._lib.mvfit_profile(self._ctx, 1 if enable else 0))
 
+    def profile_vertex_pass_ms(self, launches=64):
+        """Average duration (ms) of `launches` back-to-back vertex-pass launches inside one hipEvent pair."""
+        a = C.c_double()
+        self._check(self._lib.mvfit_profile_vertex_pass(self._ctx, int(launches), C.byref(a)))
+        return a.value
+
     def profile_read(self):
         a, b = C.c_double(), C.c_double()
         n1, n2 = C.c_int(), C.c_int()
