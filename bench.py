@@ -38,12 +38,15 @@ PER_PROBLEM_BYTES = 2032 + 82680                      # (betas, pose_feature, A,
 # HBM-side bytes per vertex-pass launch at 32 problems from rocprofv3 PMC passes (profiles/r1c_kernel_stats_pmc.md, profiles/r1_pmc.md):
 # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE.  Not measurable from inside
 # this process; quoted only when the workload matches the profiled one.
-PMC_TRAFFIC_B32 = 22.98e6
+PMC_TRAFFIC_B32 = 22.98e6          # dense skinning rows
+PMC_TRAFFIC_B32_TOP4 = 22.55e6     # 4-sparse skinning rows (profiles/r1d_kernel_stats_pmc.md)
 
 
-def bytes_fwd(B):
-    """Algorithmic bytes of one LBS vertex pass over B problems."""
-    return CONST_BYTES + PER_PROBLEM_BYTES * B
+def bytes_fwd(B, skin_topk=0):
+    """Algorithmic bytes of one LBS vertex pass over B problems; with
+    k-sparse skinning weights the weight matrix is k (weight, joint) pairs per vertex instead of 24 floats."""
+    const = CONST_BYTES if not skin_topk else CONST_BYTES - 661440 + 6890 * skin_topk * 8
+    return const + PER_PROBLEM_BYTES * B
 
 
 def build_inputs(eng, frames, views, seed0):
@@ -100,6 +103,8 @@ def main():
     ap.add_argument('--prior', default='l2', choices=['l2', 'vposer', 'gmm'])
     ap.add_argument('--sparse', action='store_true',
                     help='objective-vertices-only closure (no full vertex pass inside the loop)')
+    ap.add_argument('--skin-topk', type=int, default=4,
+                    help='non-zero skinning weights per vertex of the synthetic body (SMPL: <= 4); 0 = dense rows')
     ap.add_argument('--sdf', action='store_true',
                     help='configs[2]: SDF interpenetration term on (as wired: first triangle, grid 128; yaml coll_loss_weights)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -117,7 +122,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    model = syn.make_body_model(0)
+    model = syn.make_body_model(0, skin_topk=args.skin_topk or None)
     vpw = syn.make_vposer_decoder() if args.prior == 'vposer' else None
     gmm = syn.make_gmm() if args.prior == 'gmm' else None
     eng = MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank)
@@ -194,12 +199,12 @@ def main():
         raw_vp_ms = pr['vertex_pass_ms']
         pr['vertex_pass_ms'] = eng.profile_vertex_pass_ms(64)
         if pr['vertex_pass_launches'] > 0:
-            ach = bytes_fwd(B) / (pr['vertex_pass_ms'] * 1e-3) / 1e9
+            ach = bytes_fwd(B, args.skin_topk) / (pr['vertex_pass_ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', kernel='lbs_vertex_pass_kernel', achieved=round(ach, 1),
                         peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=PMC_TRAFFIC_B32 if (B == 32 and args.views == 8) else None,
-                        traffic_source='profiles/r1c_kernel_stats_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
-                        algorithmic_bytes=bytes_fwd(B), avg_launch_us=round(pr['vertex_pass_ms'] * 1e3, 2),
+                        traffic=(PMC_TRAFFIC_B32 if args.skin_topk == 0 else PMC_TRAFFIC_B32_TOP4) if (B == 32 and args.views == 8 and args.skin_topk in (0, 4)) else None,
+                        traffic_source='profiles/r1d_kernel_stats_pmc.md / r1c_kernel_stats_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+                        algorithmic_bytes=bytes_fwd(B, args.skin_topk), avg_launch_us=round(pr['vertex_pass_ms'] * 1e3, 2),
                         avg_launch_us_single_bracketed=round(raw_vp_ms * 1e3, 2), timed_region='64 back-to-back launches, one hipEvent pair',
                         launches=pr['vertex_pass_launches'],
                         step_kernel_avg_us=round(pr['step_ms'] * 1e3, 2))
@@ -217,7 +222,7 @@ def main():
             'value': round(tot_closure / tmax, 1), 'unit': 'closures/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * tmax / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic (seeded SMPL-shaped body, camera ring, noisy projected keypoints)',
+            'data': 'synthetic (seeded SMPL-shaped body%s, camera ring, noisy projected keypoints)' % ((', %d skinning weights per vertex like SMPL' % args.skin_topk) if args.skin_topk else ', dense skinning rows'),
             'config': {'workload': '%s: 1 person x %d views x %d synthetic frames per GPU, '
                                    'GMoF + pose prior (%s) + shape + angle priors, %s, 4 yaml stages'
                                    % ('configs[2]' if args.sdf else 'configs[1]', args.views, B, args.prior,

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -557,6 +558,32 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
             for (int j = 0; j < NJ; ++j)
                 wt[((size_t)(v / 32) * NJ + j) * 32 + (v % 32)] = m->lbs_weights[(size_t)v * NJ + j];
         M.wt_tiles = dev_upload(c, wt);
+        // sparse skinning table when the model allows it (SMPL-family weights have <= 4 non-zeros per vertex);
+        // MVFIT_DENSE_SKINNING=1 keeps the dense blend (tests compare the two bit for bit)
+        {
+            bool sparse_ok = true;
+            for (int v = 0; v < nv && sparse_ok; ++v) {
+                int nz = 0;
+                for (int j = 0; j < NJ; ++j) nz += m->lbs_weights[(size_t)v * NJ + j] != 0.f;
+                sparse_ok = nz <= 4;
+            }
+            const char* env = getenv("MVFIT_DENSE_SKINNING");
+            if (env && env[0] == '1') sparse_ok = false;
+            M.wsp_w = nullptr; M.wsp_j = nullptr;
+            if (sparse_ok) {
+                std::vector<float> sw((size_t)M.nv_pad * 4, 0.f);
+                std::vector<int> sj((size_t)M.nv_pad * 4, 0);
+                for (int v = 0; v < nv; ++v) {
+                    int t = 0;
+                    for (int j = 0; j < NJ; ++j) {
+                        const float w = m->lbs_weights[(size_t)v * NJ + j];
+                        if (w != 0.f) { sw[(size_t)v * 4 + t] = w; sj[(size_t)v * 4 + t] = j; ++t; }
+                    }
+                }
+                M.wsp_w = reinterpret_cast<const float4*>(dev_upload(c, sw));
+                M.wsp_j = reinterpret_cast<const int4*>(dev_upload(c, sj));
+            }
+        }
         // vertex-major copies (SDF term pull-back): coefficient row order (posedirs 0..206, shapedirs 207..216)
         std::vector<float> bsv((size_t)nv * 3 * KROWS, 0.f);
         for (int v = 0; v < nv; ++v)

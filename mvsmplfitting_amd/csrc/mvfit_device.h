@@ -70,6 +70,10 @@ struct DevModel {
     const float* bs4;        // [ntiles][3][KGROUPS][64][4]   MFMA-B-operand order (see vertex pass)
     const float* vt_planes;  // [3][nv_pad]
     const float* wt_tiles;   // [ntiles][24][32]
+    // sparse skinning (null unless every vertex has <= 4 non-zero weights): per padded vertex 4 weights and
+    // their joint indices in ascending order, zero-weight padding
+    const float4* wsp_w;     // [nv_pad]
+    const int4* wsp_j;       // [nv_pad]
     // vertex-major copies for the per-vertex pull-back of the SDF term (sdf_term.hip)
     const float* bs_vm;      // [nv][3][KROWS]   same row order as the coefficient vector
     const float* w_vm;       // [nv][24]

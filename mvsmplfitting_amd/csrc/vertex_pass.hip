@@ -37,6 +37,10 @@ constexpr int VP_GPS = KGROUPS / VP_KSPLIT;      // 7 groups of 4 k-steps per sl
 
 // one workgroup per CU (LDS-limited): 2 waves per SIMD, so let the allocator use 256 VGPRs instead of
 // spilling to keep a third wave possible
+// SPARSE_W: every vertex has at most 4 non-zero skinning weights (true of the SMPL family): the blend reads
+// 4 (weight, joint) pairs per vertex (M.wsp_w / M.wsp_j, ascending joint index) instead of the dense 24-column
+// row - the same non-zero products in the same order, i.e. bit-identical transforms for 1/6 of the FMAs.
+template <bool SPARSE_W>
 __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
                                                                 float* __restrict__ verts) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -90,6 +94,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // copy (wave & 3) of the tile's weights: waves w and w + 4 write the identical words to the same copy,
     // so each may read right after its own writes without waiting for the other
     float* Wt_w = Wt_l + (wave & 3) * NJ * 32;
+    float4 spw[2];
+    int4 spj[2];
     {
         // A of this wave's 4 problems: 4 x 72 float4 = 288 -> 5 per lane (last partial); W: 192 float4 -> 3 per lane
         const float4* asrc4 = reinterpret_cast<const float4*>(P.Amat + (size_t)(b0 + 4 * wave) * 288);   // Bpad rows exist
@@ -97,7 +103,15 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // (named registers, not arrays: with the sched_barriers the allocator otherwise parks them in scratch)
         const float4 a40 = asrc4[lane], a41 = asrc4[lane + 64], a42 = asrc4[lane + 128], a43 = asrc4[lane + 192],
                      a44 = asrc4[min(lane + 256, 287)];
-        const float4 w40 = wsrc[lane], w41 = wsrc[lane + 64], w42 = wsrc[lane + 128];
+        float4 w40, w41, w42;
+        float4 sw0, sw1;                                  // sparse: weights of vertices 2 vp2, 2 vp2 + 1
+        int4 sj0, sj1;                                    //         and their joint indices
+        if (SPARSE_W) {
+            sw0 = M.wsp_w[(size_t)tile * TILE_V + 2 * vp2]; sw1 = M.wsp_w[(size_t)tile * TILE_V + 2 * vp2 + 1];
+            sj0 = M.wsp_j[(size_t)tile * TILE_V + 2 * vp2]; sj1 = M.wsp_j[(size_t)tile * TILE_V + 2 * vp2 + 1];
+        } else {
+            w40 = wsrc[lane]; w41 = wsrc[lane + 64]; w42 = wsrc[lane + 128];
+        }
         if (wave == 7 && lane < 32) reinterpret_cast<float4*>(tau_l)[lane] = reinterpret_cast<const float4*>(P.tau + (size_t)b0 * 4)[lane];
         __builtin_amdgcn_sched_barrier(0);
         if (mfma_role) {      // counted waits: the coefficient slice has landed while 21 + 8 younger loads are in flight
@@ -108,9 +122,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             if (i < 288) { const int b = i / 72, q = i - b * 72; *reinterpret_cast<float4*>(A_l + (4 * wave + b) * A_STRIDE + 4 * q) = v; }
         };
         put_a(lane, a40); put_a(lane + 64, a41); put_a(lane + 128, a42); put_a(lane + 192, a43); put_a(lane + 256, a44);
-        reinterpret_cast<float4*>(Wt_w)[lane] = w40;
-        reinterpret_cast<float4*>(Wt_w)[lane + 64] = w41;
-        reinterpret_cast<float4*>(Wt_w)[lane + 128] = w42;
+        if (!SPARSE_W) {
+            reinterpret_cast<float4*>(Wt_w)[lane] = w40;
+            reinterpret_cast<float4*>(Wt_w)[lane + 64] = w41;
+            reinterpret_cast<float4*>(Wt_w)[lane + 128] = w42;
+        }
+        spw[0] = sw0; spw[1] = sw1; spj[0] = sj0; spj[1] = sj1;
     }
     wave_lds_fence();
     VP_T(1, t_start);
@@ -122,7 +139,24 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
-    {
+    if (SPARSE_W) {
+        const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float wq[4] = {spw[i].x, spw[i].y, spw[i].z, spw[i].w};
+            const int jq[4] = {spj[i].x, spj[i].y, spj[i].z, spj[i].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
+                    tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
+                    tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
+                    tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
+                    tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
+                }
+        }
+    } else {
         const float* arow = A_l + bb * A_STRIDE;
 #pragma unroll 4
         for (int j = 0; j < NJ; ++j) {
@@ -248,12 +282,16 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
                               hipStream_t stream) {
     (void)ksplit;
     dim3 grid(M.ntiles, (B + 31) / 32);
-    hipLaunchKernelGGL(lbs_vertex_pass_kernel, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
+    if (M.wsp_w) hipLaunchKernelGGL(lbs_vertex_pass_kernel<true>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
+    else hipLaunchKernelGGL(lbs_vertex_pass_kernel<false>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
     return hipGetLastError();
 }
 
 hipError_t vertex_pass_configure() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
 }
 

@@ -206,3 +206,26 @@ def test_view_count_extremes_and_per_problem_cameras(V):
         with pytest.raises(MvFitError):
             eng.set_problems(cams17, np.zeros((1, 17, 17, 2), np.float32), np.ones((1, 17, 17), np.float32))
     eng.close()
+
+
+def test_sparse_skinning_path_is_bit_identical_to_dense(monkeypatch):
+    """A model with <= 4 weights per vertex (like SMPL) takes the 4-pair blend in the vertex pass; forcing the
+    dense 24-column blend on the same model must give the same bits (same non-zero products, same order)."""
+    model = body_model(0, 4)
+    cams = syn.make_camera_ring(8)
+    B = 33
+    rng = np.random.default_rng(8)
+    x = np.zeros((B, 118), np.float32)
+    x[:, :86] = rng.normal(0, 0.2, (B, 86)); x[:, 85] = 1.0 + rng.normal(0, 0.05, B)
+    gt = rng.uniform(300, 1700, (B, 8, 17, 2)).astype(np.float32)
+    conf = np.ones((B, 8, 17), np.float32)
+    outs = []
+    for dense in ('0', '1'):
+        monkeypatch.setenv('MVFIT_DENSE_SKINNING', dense)
+        eng = make_engine(model)
+        eng.set_problems(cams, gt, conf)
+        o = eng.closure(x, dict(stage_weights(1), flags=0), want_verts=True)
+        outs.append((o['verts'].cpu().numpy(), o['loss'].cpu().numpy(), o['grad'].cpu().numpy()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
