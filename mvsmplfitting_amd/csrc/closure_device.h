@@ -530,6 +530,51 @@ __device__ void chain_forward_wave(ClosureLds& L, int lane) {
     }
 }
 
+// The same chain by the whole workgroup in pointer-jumping form: P_j <- P_anc(j) . P_j with the ancestor
+// distance doubling every step, so the longest path (9 joints in SMPL) is complete after 4 steps of one
+// 3x4 product each instead of 9 dependent passes of one wave.  Thread = (joint, element) for tid < 288;
+// the steps ping-pong between L.pose.G and L.gM (the adjoint's buffer, dead during the forward).  The
+// products are associated differently from the sequential chain (last-bit differences in G); every consumer
+// (vertex pass, objective, adjoint) reads the same G / A.  Ends with __syncthreads.
+__device__ void chain_forward_block(ClosureLds& L, int tid) {
+    const bool act = tid < NJ * 12;
+    const int j = act ? tid / 12 : 0, e = tid - 12 * j, a = e >> 2, c = e & 3;
+    const int ns = L.M.n_jump;
+    int anc[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) anc[s] = L.M.anc_tab[s][j];
+    const float* src = &L.pose.Mj[0][0];
+    float* dst = &L.pose.G[0][0];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        if (s < ns) {                                             // uniform
+            if (act) {
+                float v;
+                if (anc[s] >= 0) {
+                    const float4 x = *reinterpret_cast<const float4*>(src + anc[s] * 12 + 4 * a);
+                    v = x.x * src[j * 12 + c] + x.y * src[j * 12 + 4 + c] + x.z * src[j * 12 + 8 + c];
+                    if (c == 3) v += x.w;
+                } else {
+                    v = src[j * 12 + e];
+                }
+                dst[j * 12 + e] = v;
+            }
+            __syncthreads();
+            src = dst;
+            dst = (dst == &L.pose.G[0][0]) ? &L.gM[0][0] : &L.pose.G[0][0];
+        }
+    }
+    // src holds G; A_j = [Gr_j | Gt_j - Gr_j J_j]  (lbs.py:365-368); G itself lands in L.pose.G
+    if (tid < NJ * 3) {
+        const int jj = tid / 3, aa = tid - 3 * jj;
+        const float4 g = *reinterpret_cast<const float4*>(src + jj * 12 + 4 * aa);
+        const float t = g.w - (g.x * L.pose.J[jj][0] + g.y * L.pose.J[jj][1] + g.z * L.pose.J[jj][2]);
+        *reinterpret_cast<float4*>(&L.pose.A[jj][4 * aa]) = make_float4(g.x, g.y, g.z, t);
+        if (src != &L.pose.G[0][0]) *reinterpret_cast<float4*>(&L.pose.G[jj][4 * aa]) = g;
+    }
+    __syncthreads();
+}
+
 // k-split partial sums of v_posed = v_template + coef . pd_sub  (lbs.py:179,192-203 on the selected
 // vertices): 8 slices of 28 basis rows x nc_pad/4 float4 column groups = items; threads [0, nthreads)
 // take items round-robin (one each for the SMPL keypoint set).  All 28 loads of an item are issued

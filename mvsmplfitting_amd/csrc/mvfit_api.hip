@@ -60,8 +60,7 @@ __device__ __forceinline__ int dact(bool use_vp) { return use_vp ? 49 : 86; }
 // pose operands of the vertex pass only: E1 + chain
 __device__ __forceinline__ void pose_and_chain(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     pose_prep(M, L, flags, tid);
-    if (tid < 64) chain_forward_wave(L, tid);
-    __syncthreads();
+    chain_forward_block(L, tid);
 }
 
 __device__ __forceinline__ void store_block16(void* dst_g, const void* src_l, int nbytes, int tid) {
@@ -740,6 +739,19 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 }
             }
         G.n_fwd = np;
+        // pointer-jumping tables (chain_forward_block)
+        {
+            for (int j = 0; j < NJ; ++j) G.anc_tab[0][j] = m->parents[j];
+            for (int st = 1; st < 5; ++st)
+                for (int j = 0; j < NJ; ++j) {
+                    const int a = G.anc_tab[st - 1][j];
+                    G.anc_tab[st][j] = a < 0 ? -1 : G.anc_tab[st - 1][a];
+                }
+            int nj = 0;
+            while ((1 << nj) < maxd + 1) ++nj;
+            if (nj > 5) return fail(c, MVFIT_E_UNSUPPORTED, "kinematic tree deeper than 32 joints");
+            G.n_jump = nj;
+        }
         // backward schedule: parents with children, deepest level first; <= 3 children per entry
         // (a parent with more children appears in consecutive passes), <= 5 entries per pass.
         // Two entries of the same parent never share a pass (they would race on its row).

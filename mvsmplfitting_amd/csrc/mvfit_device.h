@@ -61,6 +61,10 @@ struct ModelLds {
     int n_fwd, n_bwd;
     int fwd_tab[NJ][5];
     int bwd_tab[NJ][5];
+    // pointer-jumping form of the forward chain: anc_tab[s][j] = the 2^s-th ancestor of joint j (-1: above the root);
+    // n_jump = steps until every path product is complete (2^n_jump >= joints on the longest path)
+    int anc_tab[5][NJ];
+    int n_jump, jpad0, jpad1, jpad2;
     int ns, nc, nc_pad, pad0;
 };
 static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds is bulk-copied as 16-byte words");
