@@ -1152,7 +1152,17 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
 // write the operands of the vertex pass for problem b
 __device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid) {
     float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
-    for (int p = tid; p < KROWS; p += STEP_NT) ct[p * 32] = L.coef[p];
+    _Float16* ch = reinterpret_cast<_Float16*>(P.coefH) + (size_t)(b >> 5) * (KROWS / 16) * 2 * 64 * 8;
+    for (int p = tid; p < KROWS; p += STEP_NT) {
+        const float cv = L.coef[p];
+        ct[p * 32] = cv;
+        // split-fp16 A operand of the vertex pass: block p / 16, lane = 32 * ((p % 16) / 8) + problem, element p % 8
+        const _Float16 hi = (_Float16)cv;
+        const _Float16 lo = (_Float16)(cv - (float)hi);
+        const size_t at = ((size_t)(p >> 4) * 2 * 64 + (size_t)(((p >> 3) & 1) * 32 + (b & 31))) * 8 + (p & 7);
+        ch[at] = hi;
+        ch[at + 64 * 8] = lo;
+    }
     for (int i = tid; i < NJ * 12; i += STEP_NT) P.Amat[(size_t)b * 288 + i] = (&L.pose.A[0][0])[i];
     if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.opt.x[X_TR + tid];
 }

@@ -548,6 +548,40 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                             bs[((((size_t)T * 3 + k) * KGROUPS + g) * 64 + l) * 4 + q] = val;
                         }
         M.bs4 = dev_upload(c, bs);
+        // the same basis as split-fp16 MFMA B operands (vertex_pass.hip: lbs_vertex_pass_split_kernel):
+        // x * scale = hi + lo, scale = the power of two that brings max |x| into [2^13, 2^14)
+        M.bs_h2 = nullptr; M.bs_scale = 1.f;
+        const char* exact = getenv("MVFIT_EXACT_FP32");
+        if (!(exact && exact[0] == '1')) {
+            float mx = 0.f;
+            for (float v : bs) mx = std::max(mx, std::fabs(v));
+            int ex = 0;
+            if (mx > 0.f) std::frexp(mx, &ex);                 // mx = f * 2^ex, f in [0.5, 1)
+            const float scale = std::ldexp(1.f, 14 - ex);       // max |x| * scale in [2^13, 2^14)
+            constexpr int NB = KROWS / 16;
+            std::vector<_Float16> h2((size_t)M.ntiles * 3 * NB * 2 * 64 * 8);
+            for (int T = 0; T < M.ntiles; ++T)
+                for (int k = 0; k < 3; ++k)
+                    for (int G16 = 0; G16 < NB; ++G16)
+                        for (int l = 0; l < 64; ++l)
+                            for (int t = 0; t < 8; ++t) {
+                                const int pr = 16 * G16 + 8 * (l >> 5) + t;
+                                const int v = TILE_V * T + (l & 31);
+                                float val = 0.f;
+                                if (v < nv) {
+                                    if (pr < 207) val = m->posedirs[(size_t)pr * nv * 3 + 3 * v + k];
+                                    else if (pr < 217) val = m->shapedirs[((size_t)v * 3 + k) * 10 + (pr - 207)];
+                                }
+                                val *= scale;
+                                const _Float16 hi = (_Float16)val;
+                                const _Float16 lo = (_Float16)(val - (float)hi);
+                                const size_t at = ((((size_t)(T * 3 + k) * NB + G16) * 2) * 64 + l) * 8 + t;
+                                h2[at] = hi;
+                                h2[at + 64 * 8] = lo;
+                            }
+            M.bs_h2 = reinterpret_cast<const float4*>(dev_upload(c, h2));
+            M.bs_scale = scale;
+        }
         std::vector<float> vtp((size_t)3 * M.nv_pad, 0.f);
         for (int v = 0; v < nv; ++v)
             for (int k = 0; k < 3; ++k) vtp[(size_t)k * M.nv_pad + v] = m->v_template[3 * v + k];
@@ -839,7 +873,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
 
 static void free_problem_buffers(mvfit_ctx* c) {
     drop_graph(c);
-    void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefT, c->P.Amat, c->P.tau,
+    void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
                   c->d_sdf_adj, c->F.sdf_gate, c->F.vp};
@@ -890,6 +924,8 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->P.vposed_sel, (size_t)Bpad * NC_MAX * 4));
         HIP_OK(c, hipMalloc(&c->P.xs_sel, (size_t)Bpad * NC_MAX * 4));
         HIP_OK(c, hipMemset(c->P.coefT, 0, (size_t)Bpad * KROWS * 4));
+        HIP_OK(c, hipMalloc(&c->P.coefH, (size_t)Bpad * KROWS * 4));
+        HIP_OK(c, hipMemset(c->P.coefH, 0, (size_t)Bpad * KROWS * 4));
         HIP_OK(c, hipMalloc(&c->d_verts, (size_t)B * c->nv * 3 * 4));
         HIP_OK(c, hipMalloc(&c->d_obs, (size_t)B * sizeof(ObsBlock)));
         HIP_OK(c, hipMalloc(&c->F.opt, (size_t)B * sizeof(OptBlock)));

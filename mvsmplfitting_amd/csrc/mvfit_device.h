@@ -72,6 +72,11 @@ static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds is bulk-copied as 16-byte wo
 struct DevModel {
     int nv, nv_pad, ntiles;
     const float* bs4;        // [ntiles][3][KGROUPS][64][4]   MFMA-B-operand order (see vertex pass)
+    // the same basis split into fp16 pairs for the fp16 matrix pipe (null: exact-fp32 contraction):
+    // [ntiles][3][14 blocks][hi, lo][64 lanes] 16-byte words = 8 fp16 of rows 16 G + 8 (lane >> 5) + t, vertex
+    // 32 T + (lane & 31), values scaled by bs_scale (a power of two)
+    const float4* bs_h2;
+    float bs_scale;
     const float* vt_planes;  // [3][nv_pad]
     const float* wt_tiles;   // [ntiles][24][32]
     // sparse skinning (null unless every vertex has <= 4 non-zero weights): per padded vertex 4 weights and
@@ -129,12 +134,15 @@ struct DevWeights {          // one stage
 
 // per-problem pose workspace handed from the step kernel to the vertex pass
 //   coefT [B/32][KROWS][32]   (pose_feature | betas | 0), transposed per 32-problem chunk
+//   coefH the same coefficients, split into fp16 (hi, lo) pairs in MFMA A-operand order
 //   Amat  [B][24][12]
 //   tau   [B][4]
 // and back (vertex pass -> step kernel), for the selected vertices only:
 //   vposed_sel [B][NC_MAX]   blendshaped rest positions  (lbs.py:203), c = 3 s + a
 //   xs_sel     [B][NC_MAX]   skinned positions before "+ transl"
 struct DevPose {
+    float4* coefH;           // [B/32][14 blocks][hi, lo][64 lanes] 16-byte words: the coefficients of a chunk as
+                             // split-fp16 MFMA A operands (problem = lane & 31, rows 16 G + 8 (lane >> 5) + t)
     float* coefT;
     float* Amat;
     float* tau;

@@ -273,6 +273,224 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Same pass with the blendshape contraction on the fp16 matrix pipe in error-compensated form.
+//
+// fp32 MFMA issues at the fp32 vector rate; v_mfma_f32_32x32x16_f16 is 16x faster per multiply-add.  Every
+// fp32 operand is split into two fp16 terms, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits),
+// and the product is taken as lo.hi + hi.lo + hi.hi with fp32 accumulation inside the MFMA - each partial
+// product (11 x 11 bits) is exact in fp32, the dropped lo.lo term is 2^-22 relative.  The basis is pre-split on
+// the host (same 4 bytes per element: hi and lo packed as two fp16), scaled by a power of two (M.bs_scale) so that
+// the lo terms of all but negligible elements stay in fp16's normal range; the coefficients are split by the
+// step kernel when it publishes them (P.coefH).  3 MFMAs of 32 cycles replace 8 of 64 per 16 k-steps.
+//
+// Mapping: six contraction waves, wave = coordinate plane c (w % 3) x K-half h (w / 3): 7 blocks of 16 rows,
+// one accumulator; A and B operands arrive as ready-made 16-byte lane words (no LDS staging, no conversion).
+// All eight waves run the skinning blend as in the exact-fp32 kernel; partials meet in LDS in a fixed order.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int VP_NBLK = KROWS / 16;             // 14 blocks of 16 k-steps
+constexpr int VP_BPW = VP_NBLK / 2;             // 7 per contraction wave
+
+template <bool SPARSE_W>
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_split_kernel(DevModel M, DevPose P, int B,
+                                                                float* __restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A_l = smem;                              // [32][A_STRIDE]
+    float* Wt_l = A_l + 32 * A_STRIDE;              // [4 copies][24][32]
+    float* tau_l = Wt_l + 4 * NJ * 32;              // [32][4]
+    float* part = tau_l + 32 * 4;                   // [2 K-halves][3][32][33]
+    float* out_l = part + 2 * 3 * 32 * 33;          // [32 b][96]  skinned positions before "+ transl"
+    float* vps_l = out_l + 32 * 96;                 // [32 b][96]  v_posed (only read for the side outputs)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int chunk = blockIdx.y;
+    const int b0 = chunk * 32;
+    const bool mfma_role = wave < 6;
+    const int kc_w = wave % 3, kh_w = wave / 3;
+#ifdef MVFIT_TIMING
+    const long long t_start = clock64();
+#else
+    const long long t_start = 0;
+#endif
+    const int vp2 = tid & 15, bb = tid >> 4;              // wave w blends problems [4 w, 4 w + 4)
+    float vt_init = 0.f;
+    float4 ah[VP_BPW], al[VP_BPW], bh[VP_BPW], bl[VP_BPW];
+    if (mfma_role) {
+        vt_init = (kh_w == 0) ? M.vt_planes[kc_w * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale : 0.f;
+        const float4* ca = P.coefH + ((size_t)(chunk * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+        const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + kc_w) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < VP_BPW; ++g) { ah[g] = ca[(2 * g) * 64]; al[g] = ca[(2 * g + 1) * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < VP_BPW; ++g) { bh[g] = cb[(2 * g) * 64]; bl[g] = cb[(2 * g + 1) * 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* Wt_w = Wt_l + (wave & 3) * NJ * 32;
+    float4 spw[2];
+    int4 spj[2];
+    {
+        const float4* asrc4 = reinterpret_cast<const float4*>(P.Amat + (size_t)(b0 + 4 * wave) * 288);   // Bpad rows exist
+        const float4* wsrc = reinterpret_cast<const float4*>(M.wt_tiles + (size_t)tile * NJ * 32);
+        const float4 a40 = asrc4[lane], a41 = asrc4[lane + 64], a42 = asrc4[lane + 128], a43 = asrc4[lane + 192],
+                     a44 = asrc4[min(lane + 256, 287)];
+        float4 w40, w41, w42;
+        float4 sw0, sw1;
+        int4 sj0, sj1;
+        if (SPARSE_W) {
+            sw0 = M.wsp_w[(size_t)tile * TILE_V + 2 * vp2]; sw1 = M.wsp_w[(size_t)tile * TILE_V + 2 * vp2 + 1];
+            sj0 = M.wsp_j[(size_t)tile * TILE_V + 2 * vp2]; sj1 = M.wsp_j[(size_t)tile * TILE_V + 2 * vp2 + 1];
+        } else {
+            w40 = wsrc[lane]; w41 = wsrc[lane + 64]; w42 = wsrc[lane + 128];
+        }
+        if (wave == 7 && lane < 32) reinterpret_cast<float4*>(tau_l)[lane] = reinterpret_cast<const float4*>(P.tau + (size_t)b0 * 4)[lane];
+        __builtin_amdgcn_sched_barrier(0);
+        auto put_a = [&](int i, const float4& v) {
+            if (i < 288) { const int b = i / 72, q = i - b * 72; *reinterpret_cast<float4*>(A_l + (4 * wave + b) * A_STRIDE + 4 * q) = v; }
+        };
+        put_a(lane, a40); put_a(lane + 64, a41); put_a(lane + 128, a42); put_a(lane + 192, a43); put_a(lane + 256, a44);
+        if (!SPARSE_W) {
+            reinterpret_cast<float4*>(Wt_w)[lane] = w40;
+            reinterpret_cast<float4*>(Wt_w)[lane + 64] = w41;
+            reinterpret_cast<float4*>(Wt_w)[lane + 128] = w42;
+        }
+        spw[0] = sw0; spw[1] = sw1; spj[0] = sj0; spj[1] = sj1;
+    }
+    wave_lds_fence();
+    VP_T(1, t_start);
+    // ---- skinning blend (lbs.py:209-213), all waves ----
+    float tr[3][2][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+    if (SPARSE_W) {
+        const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float wq[4] = {spw[i].x, spw[i].y, spw[i].z, spw[i].w};
+            const int jq[4] = {spj[i].x, spj[i].y, spj[i].z, spj[i].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
+                    tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
+                    tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
+                    tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
+                    tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
+                }
+        }
+    } else {
+        const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll 4
+        for (int j = 0; j < NJ; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
+            const float wv[2] = {w.x, w.y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
+                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
+                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
+                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
+                }
+            }
+        }
+    }
+    VP_T(2, t_start);
+    if (mfma_role) {
+        // ---- blendshape contraction: plane kc_w, K-half kh_w; small products first ----
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = vt_init;
+#pragma unroll
+        for (int g = 0; g < VP_BPW; ++g) {
+            const half8 Ah = __builtin_bit_cast(half8, ah[g]), Al = __builtin_bit_cast(half8, al[g]);
+            const half8 Bh = __builtin_bit_cast(half8, bh[g]), Bl = __builtin_bit_cast(half8, bl[g]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+        }
+        // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        float* pdst = part + ((kh_w * 3 + kc_w) * 32) * 33 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            pdst[b * 33] = acc[r];
+        }
+    }
+    VP_T(3, t_start);
+    __syncthreads();
+
+    // ---- all waves: combine the two K-halves (fixed order), undo the basis scale, apply T ----
+    const float inv_scale = 1.0f / M.bs_scale;        // power of two: exact
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = 2 * vp2 + i;
+        float vp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            vp[k] = (part[((0 * 3 + k) * 32 + bb) * 33 + v] + part[((1 * 3 + k) * 32 + bb) * 33 + v]) * inv_scale;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+            vps_l[bb * 96 + v * 3 + k] = vp[k];
+        }
+    }
+    VP_T(4, t_start);
+    __syncthreads();
+    VP_T(5, t_start);
+
+    // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
+    {
+        const int vbase = tile * TILE_V;
+        const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
+            const int b = i / 48, q = i - b * 48;
+            if (b0 + b < B) {
+                float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
+                const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
+                float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+                o.x += tau_l[b * 4 + k0];
+                o.y += tau_l[b * 4 + k1];
+                if (2 * q + 1 < nvalid) *reinterpret_cast<float2*>(dst) = o;
+                else if (2 * q < nvalid) dst[0] = o.x;
+            }
+        }
+    }
+    // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
+    {
+        const int s0 = M.tile_sel_start[tile], nsel = M.tile_sel_start[tile + 1] - s0;
+        for (int i = tid; i < nsel * 96; i += VP_NT) {
+            const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
+            if (b0 + b >= B) continue;
+            const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
+            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
+            P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
+        }
+    }
+    VP_T(6, t_start);
+#ifdef MVFIT_TIMING
+    if (blockIdx.x == 5 && threadIdx.x == 0) g_vp[7] += 1;
+#endif
+}
+
+size_t vertex_pass_split_lds_bytes() {
+    return sizeof(float) * (size_t)(32 * A_STRIDE + 4 * NJ * 32 + 32 * 4 + 2 * 3 * 32 * 33 + 2 * 32 * 96);
+}
+
 size_t vertex_pass_lds_bytes() {
     return sizeof(float) * (size_t)(KROWS * 32 + 32 * A_STRIDE + 4 * NJ * 32 + 32 * 4 +
                                     VP_KSPLIT * 3 * 32 * 33 + 2 * 32 * 96);
@@ -282,6 +500,11 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
                               hipStream_t stream) {
     (void)ksplit;
     dim3 grid(M.ntiles, (B + 31) / 32);
+    if (M.bs_h2) {        // split-fp16 contraction (default); MVFIT_EXACT_FP32=1 at mvfit_create keeps the fp32 MFMA chain
+        if (M.wsp_w) hipLaunchKernelGGL(lbs_vertex_pass_split_kernel<true>, grid, dim3(VP_NT), vertex_pass_split_lds_bytes(), stream, M, P, B, verts);
+        else hipLaunchKernelGGL(lbs_vertex_pass_split_kernel<false>, grid, dim3(VP_NT), vertex_pass_split_lds_bytes(), stream, M, P, B, verts);
+        return hipGetLastError();
+    }
     if (M.wsp_w) hipLaunchKernelGGL(lbs_vertex_pass_kernel<true>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
     else hipLaunchKernelGGL(lbs_vertex_pass_kernel<false>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
     return hipGetLastError();
@@ -291,8 +514,14 @@ hipError_t vertex_pass_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_lds_bytes());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
 }
 
 }  // namespace mvfit

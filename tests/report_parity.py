@@ -13,6 +13,8 @@ for name in sorted(CASES):
     eng = make_engine(model, vpw, gmm)
     B = g['x'].shape[0]
     eng.set_problems(cams, g['gt_xy'], g['conf'])
+    if 'joints3d' in g:
+        eng.set_joints3d(g['joints3d'][:, :, :3], g['joints3d'][:, :, 3])
     x = np.stack([to118(g['x'][b], cfg['use_vposer']) for b in range(B)]).astype(np.float32)
     for sparse in (False, True):
         w = dict(wts); w['flags'] = flags_for(cfg) | (_lib.F_SPARSE_VERTS if sparse else 0)

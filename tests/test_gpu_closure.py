@@ -229,3 +229,34 @@ def test_sparse_skinning_path_is_bit_identical_to_dense(monkeypatch):
         eng.close()
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+def test_split_fp16_contraction_against_exact_fp32(monkeypatch):
+    """The default vertex pass takes the blendshape contraction as error-compensated split-fp16 products on the
+    fp16 matrix pipe; MVFIT_EXACT_FP32=1 keeps the exact fp32 MFMA chain.  The two agree to fp32 rounding level
+    on the vertices (both are ~5e-7 from the float64 oracle), far inside the 1e-4 tolerance."""
+    model = body_model()
+    cams = syn.make_camera_ring(8)
+    orc = oracle_for(model, None, None)
+    B = 32
+    rng = np.random.default_rng(21)
+    x86 = rng.normal(0, 0.3, (B, 86)); x86[:, :10] = rng.normal(0, 1.5, (B, 10)); x86[:, 85] = 1.0 + rng.normal(0, 0.05, B)
+    x = np.stack([to118(x86[b], False) for b in range(B)]).astype(np.float32)
+    gt = rng.uniform(300, 1700, (B, 8, 17, 2)).astype(np.float32)
+    conf = np.ones((B, 8, 17), np.float32)
+    outs = {}
+    for exact in ('0', '1'):
+        monkeypatch.setenv('MVFIT_EXACT_FP32', exact)
+        eng = make_engine(model)
+        eng.set_problems(cams, gt, conf)
+        o = eng.closure(x, dict(stage_weights(2), flags=0), want_verts=True)
+        outs[exact] = (o['verts'].cpu().numpy().astype(np.float64), o['loss'].cpu().numpy().astype(np.float64))
+        eng.close()
+    assert np.abs(outs['0'][0] - outs['1'][0]).max() < 2e-6
+    assert np.all(np.abs(outs['0'][1] - outs['1'][1]) <= 2e-6 * np.abs(outs['1'][1]))
+    errs = {}
+    for b in (0, 7, 31):
+        ref = orc.body(dict(cn.unpack(x[b, :86].astype(np.float64), False), use_vposer=False), want_cache=False)['vertices']
+        for k in outs:
+            errs.setdefault(k, []).append(np.abs(outs[k][0][b] - ref).max())
+    assert max(errs['0']) < 3e-6 and max(errs['0']) <= 4 * max(errs['1']) + 1e-6, errs
