@@ -39,7 +39,7 @@ PER_PROBLEM_BYTES = 2032 + 82680                      # (betas, pose_feature, A,
 # 2 x FETCH_SIZE (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE.  Not measurable from inside
 # this process; quoted only when the workload matches the profiled one.
 PMC_TRAFFIC_B32 = 22.98e6          # dense skinning rows
-PMC_TRAFFIC_B32_TOP4 = 22.55e6     # 4-sparse skinning rows (profiles/r1d_kernel_stats_pmc.md)
+PMC_TRAFFIC_B32_TOP4 = 22.53e6     # 4-sparse skinning rows (profiles/r1e_kernel_stats_pmc.md)
 
 
 def bytes_fwd(B, skin_topk=0):
@@ -207,7 +207,7 @@ def main():
             roof = dict(bound='hbm', kernel='lbs_vertex_pass_kernel', achieved=round(ach, 1),
                         peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                         traffic=(PMC_TRAFFIC_B32 if args.skin_topk == 0 else PMC_TRAFFIC_B32_TOP4) if (B == 32 and args.views == 8 and args.skin_topk in (0, 4)) else None,
-                        traffic_source='profiles/r1d_kernel_stats_pmc.md / r1c_kernel_stats_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
+                        traffic_source='profiles/r1e_kernel_stats_pmc.md / r1c_kernel_stats_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)',
                         algorithmic_bytes=bytes_fwd(B, args.skin_topk), avg_launch_us=round(pr['vertex_pass_ms'] * 1e3, 2),
                         avg_launch_us_single_bracketed=round(raw_vp_ms * 1e3, 2), timed_region='64 back-to-back launches, one hipEvent pair',
                         launches=pr['vertex_pass_launches'],
@@ -226,6 +226,9 @@ def main():
             'value': round(tot_closure / tmax, 1), 'unit': 'closures/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * tmax / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'dtype_note': 'all arithmetic fp32 (line-search scalars fp64 like the reference); the blendshape contraction of the '
+                          'vertex pass takes its fp32 products as error-compensated split-fp16 pairs on the matrix pipe with '
+                          'fp32 accumulation (vertices 5e-7 from the float64 oracle, as with the exact fp32 chain)',
             'data': 'synthetic (seeded SMPL-shaped body%s, camera ring, noisy projected keypoints)' % ((', %d skinning weights per vertex like SMPL' % args.skin_topk) if args.skin_topk else ', dense skinning rows'),
             'config': {'workload': '%s: 1 person x %d views x %d synthetic frames per GPU, '
                                    'GMoF + pose prior (%s) + shape + angle priors, %s, 4 yaml stages'
