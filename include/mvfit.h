@@ -118,6 +118,9 @@ typedef struct mvfit_lbfgs_opts {
 
 /* SMPL.__init__ + .to(device) (body_models_scale.py:98-305, code/init.py:143-151): copies and
  * re-tiles the constants into HBM.  hip_stream may be NULL (default stream). */
+/* Environment switches read here (testing / comparison): MVFIT_EXACT_FP32=1 keeps the vertex pass's blendshape
+ * contraction as an exact fp32 MFMA chain (default: error-compensated split-fp16 products, fp32 accumulate);
+ * MVFIT_DENSE_SKINNING=1 keeps the dense 24-column skinning blend even when every vertex has <= 4 weights. */
 int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* model);
 void mvfit_destroy(mvfit_ctx* ctx);
 const char* mvfit_last_error(const mvfit_ctx* ctx);
