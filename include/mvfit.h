@@ -185,6 +185,14 @@ int mvfit_set_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, int grid_
  *   sums[B] dev out = S = sum_v phi_v (may be NULL). */
 int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 
+/* Per-frame initial guess, stage 1 (code/utils/init_guess.py:80-83 -> code/utils/recompute3D.py:22-62): weighted linear
+ * triangulation of the 17 keypoints from V calibrated views, batched over B frames.
+ *   keypoints[B,V,17,3] float32 dev (u, v, confidence) ; intris[V,3,3], extris[V,4,4] float64 dev (the reference
+ *   keeps the camera file in float64, code/utils/utils.py:352-394) ; joints3d[B,17,3] float64 dev out.
+ * Same arithmetic as the reference: float64 accumulation, AtA rounded to float32 before the float64 solve (:54). */
+int mvfit_triangulate(mvfit_ctx* ctx, int B, int V, const float* keypoints, const double* intris, const double* extris,
+                      double* joints3d);
+
 /* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
  * the last call, measured with hipEvents on the ctx stream; *launches = number measured.
  * Enable with mvfit_profile(ctx, 1) (adds two event records per launch). */

@@ -30,6 +30,8 @@ hipError_t vertex_pass_configure();
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
 size_t sdf_entry_bytes();
+hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
+                              hipStream_t stream);
 hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
                                float* phi, hipStream_t stream);
 
@@ -1279,6 +1281,17 @@ extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, cons
     HIP_OK(c, hipSetDevice(c->device));
     hipError_t e = launch_sdf_voxelize(faces, num_faces, vertices, B, num_vertices, G, phi, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_triangulate(mvfit_ctx* c, int B, int V, const float* keypoints, const double* intris, const double* extris,
+                                 double* joints3d) {
+    if (!c) return MVFIT_E_ARG;
+    if (B <= 0 || V <= 0 || !keypoints || !intris || !extris || !joints3d)
+        return fail(c, MVFIT_E_ARG, "mvfit_triangulate: bad argument (B=%d V=%d)", B, V);
+    HIP_OK(c, hipSetDevice(c->device));
+    hipError_t e = launch_triangulate(keypoints, intris, extris, B, V, NKP, joints3d, c->stream);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "triangulate launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
 

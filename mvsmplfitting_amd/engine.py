@@ -227,6 +227,23 @@ class MvFit:
             raise MvFitError(f'num_faces={n} outside [1, {f.shape[0]}]')
         self._check(self._lib.mvfit_set_sdf(self._ctx, f.ctypes.data, n, int(grid_size)))
 
+    def triangulate(self, keypoints, intris, extris):
+        """joints3d [B,17,3] float64 from keypoints [B,V,17,3] (u, v, confidence) and the float64 camera matrices
+        intris [V,3,3], extris [V,4,4] (include/mvfit.h:mvfit_triangulate; reference recompute3D)."""
+        kp = self._dev(keypoints)
+        if kp.dim() != 4 or kp.shape[2] != 17 or kp.shape[3] != 3:
+            raise MvFitError('keypoints must be [B, V, 17, 3]')
+        B, V = int(kp.shape[0]), int(kp.shape[1])
+        K = torch.as_tensor(np.asarray(intris, np.float64) if not isinstance(intris, torch.Tensor) else intris,
+                            dtype=torch.float64, device=self.device).contiguous()
+        E = torch.as_tensor(np.asarray(extris, np.float64) if not isinstance(extris, torch.Tensor) else extris,
+                            dtype=torch.float64, device=self.device).contiguous()
+        if tuple(K.shape) != (V, 3, 3) or tuple(E.shape) != (V, 4, 4):
+            raise MvFitError('intris must be [V,3,3] and extris [V,4,4] with V = %d' % V)
+        out = torch.empty(B, 17, 3, dtype=torch.float64, device=self.device)
+        self._check(self._lib.mvfit_triangulate(self._ctx, B, V, kp.data_ptr(), K.data_ptr(), E.data_ptr(), out.data_ptr()))
+        return out
+
     def sdf_term_read(self):
         """(samples [B,Nv,4] = phi_v and its local-coordinate gradient, S [B]) of the last evaluated term."""
         smp = torch.empty(self.B, self.nv, 4, device=self.device)

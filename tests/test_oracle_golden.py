@@ -41,3 +41,13 @@ def test_param_layout_matches_reference_order():
     assert D == 86 and lay['betas'] == (0, 10) and lay['body_pose'] == (13, 82) and lay['scale'] == (85, 86)
     lay, D = cn.param_layout(True)
     assert D == 49 and lay['pose_embedding'] == (17, 49)
+
+
+def test_triangulation_golden_file_matches_oracle():
+    import os
+    from oracle import triangulate_np as tn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'triangulate.npz'))
+    for name in ('v8', 'v2', 'v16'):
+        for b in range(g[name + '_kps'].shape[0]):
+            d = np.abs(tn.recompute3d(g[name + '_extris'], g[name + '_intris'], g[name + '_kps'][b]) - g[name + '_joints3d'][b]).max()
+            assert d <= 1e-12

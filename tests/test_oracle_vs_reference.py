@@ -57,3 +57,16 @@ def test_live_reference_3d_joint_term():
     assert np.abs(g - gr).max() <= 1e-11 * np.abs(gr).max()
     L0, _, _ = orc.closure(x, cams, gt[0], cf[0], wts)
     assert L > L0          # the term is really there
+
+
+def test_triangulation_oracle_equals_reference_recompute3D():
+    """oracle/triangulate_np.py against the reference's own function on the seeded rigs of the golden file."""
+    from oracle import make_golden_triangulate as mg, triangulate_np as tn
+    ri.load()
+    from utils.recompute3D import recompute3D
+    for V, B, seed in [(8, 2, 11), (3, 2, 12)]:
+        extris, intris, kps = mg.make_case(V, B, seed)
+        for b in range(B):
+            ref = recompute3D(list(extris), list(intris), [kps[b, v][None].copy() for v in range(V)])
+            assert np.abs(tn.recompute3d(extris, intris, kps[b]) - ref).max() <= 1e-12
+
