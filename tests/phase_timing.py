@@ -2,12 +2,12 @@
 import sys, os, ctypes as C, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
+subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip init_guess.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
 import numpy as np, torch
 from mvsmplfitting_amd import _lib, synthetic as syn
 from mvsmplfitting_amd.engine import MvFit, stage_weights
 B, V = 32, 8
-model = syn.make_body_model(0); cams = syn.make_camera_ring(V)
+model = syn.make_body_model(0, skin_topk=4); cams = syn.make_camera_ring(V)
 eng = MvFit(model, vposer=syn.make_vposer_decoder())
 lib = eng._lib
 fr = syn.make_frames(B); xgt = np.zeros((B,118), np.float32)
