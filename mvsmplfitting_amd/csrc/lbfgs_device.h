@@ -31,6 +31,7 @@
 // workgroup; the two triangular recurrences run column-oriented on wave 0 (lane k owns the
 // running value of index k; per step one v_readlane + one FMA, G rows prefetched 8 deep).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "wave_ops.h"
@@ -170,11 +171,41 @@ __device__ void lb_row_dots(const LbHist<T>& Hh, LbWork<T>& W, int which, int ti
     }
 }
 
+// Window of Gram rows staged in LDS by the step kernel (direct global -> LDS loads, issued long before the recurrence
+// runs): physical rows [row0, row0 + LB_GW_ROWS) of ONE matrix; a row of the matrix is its own cache line and cold after
+// a launch boundary, which costs the recurrence ~100 cycles per step from global and ~55 from LDS
+// (tests/microbench/recur.hip).
+constexpr int LB_GW_ROWS = LB_HIST + 3 + 4 * LB_PD;
+constexpr int LB_GW_BYTES = ((LB_GW_ROWS * LB_GS * 4 + 1023) / 1024) * 1024;
+struct LbGramLds {
+    float* buf;          // LDS, LB_GW_BYTES; null: recurrences read the matrices from global memory
+    int row0;            // physical row of buf row 0
+    int nrows;           // rows staged
+};
+
+// all threads: request the window of matrix M that starts at physical row row0 (16-byte words, 1 KiB per wave load)
+template <int NT>
+__device__ __forceinline__ void lb_gram_dma(const float* M, int row0, float* lds, int nrows, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const float4* src = reinterpret_cast<const float4*>(M + (size_t)row0 * LB_GS);
+    const int last = (LB_GROWS - row0) * (LB_GS / 4) - 1;          // stay inside the matrix
+    const int n4 = nrows * (LB_GS / 4);
+    for (int c = wave; c * 64 < n4; c += NT / 64) {
+        const int i = min(c * 64 + lane, last);
+        __builtin_amdgcn_global_load_lds(src + i, reinterpret_cast<float4*>(lds) + c * 64, 16, 0, 0);
+    }
+}
+
 // Gram maintenance after the row dots of an inserted pair t: rows t and column t of both matrices
 // (see LbHist).  Thread a < 100 owns history slot a.
 template <typename T, int NT>
-__device__ void lb_gram_insert(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+__device__ void lb_gram_insert(const LbHist<T>& Hh, LbWork<T>& W, int tid, const LbGramLds& GL) {
     const int n = W.n, head = W.head, t = W.ins_slot;
+    // the staged window of gcol (first recurrence) gets the same row / column of the new pair
+    auto lds_put = [&](int r, int col, T val) {          // r: row index relative to the first non-pad row
+        const int lr = LB_GPAD + r - GL.row0;
+        if (sizeof(T) == 4 && GL.buf && lr >= 0 && lr < LB_GW_ROWS) reinterpret_cast<T*>(GL.buf)[lr * LB_GS + col] = val;
+    };
     for (int a = tid; a < LB_HIST; a += NT) {
         int age = a - head;
         age = age < 0 ? age + LB_HIST : age;                     // age of slot a (valid if < n)
@@ -185,6 +216,7 @@ __device__ void lb_gram_insert(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
         T* gc = Hh.gcol + LB_GPAD * LB_GS;
         T* gr = Hh.grow + LB_GPAD * LB_GS;
         gc[t * LB_GS + a] = c;              gc[(t + LB_HIST) * LB_GS + a] = c;
+        lds_put(t, a, c); lds_put(t + LB_HIST, a, c); lds_put(a, t, (T)0); lds_put(a + LB_HIST, t, (T)0);
         gr[t * LB_GS + a] = (T)0;           gr[(t + LB_HIST) * LB_GS + a] = (T)0;
         gc[a * LB_GS + t] = (T)0;           gc[(a + LB_HIST) * LB_GS + t] = (T)0;
         gr[a * LB_GS + t] = r;              gr[(a + LB_HIST) * LB_GS + t] = r;
@@ -223,8 +255,10 @@ __device__ void lb_matvec(const T* rows, const T* coef, T sign, T scale, const T
 // oldest over gcol; else oldest -> newest over grow).  Lane k owns ages k and k + 64; when the
 // loop is done lane k holds the solution component of age k (al_k, resp. c_k = al_k - be_k).
 // Per step: one prefetched row element per owned age, one v_readlane, one FMA.
-template <typename T, bool DESC, bool TWO>
-__device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int lane, T& x0, T& x1) {
+template <typename T, bool DESC, bool TWO, bool LDSM = false>
+__device__ __forceinline__ void lb_recur_loop(const T* Mg, int n, int head, int lane, T& x0, T& x1) {
+    typedef typename std::conditional<LDSM, __attribute__((address_space(3))) const T*, const T*>::type MP;
+    MP M = (MP)Mg;
     int s0 = head + lane, s1 = head + lane + 64;
     s0 = s0 >= LB_HIST ? s0 - LB_HIST : s0;
     s1 = s1 >= LB_HIST ? s1 - LB_HIST : s1;
@@ -233,8 +267,8 @@ __device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int l
     if (lane >= n) s0 = LB_HIST;
     if (lane + 64 >= n) s1 = LB_HIST;
     // row of age i is physical row LB_GPAD + head + i (doubled layout: no wrap for i < 100)
-    const T* p0 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s0;
-    const T* p1 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s1;
+    MP p0 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s0;
+    MP p1 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s1;
     constexpr int RS = DESC ? -LB_GS : LB_GS;
     T g0[LB_PD], g1[LB_PD];
 #pragma unroll
@@ -258,7 +292,7 @@ __device__ __forceinline__ void lb_recur_loop(const T* M, int n, int head, int l
 }
 
 template <typename T, bool FIRST>
-__device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane) {
+__device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane, const LbGramLds& GL) {
     const int n = __builtin_amdgcn_readfirstlane(W.n), head = __builtin_amdgcn_readfirstlane(W.head);
     const int k0 = lane, k1 = lane + 64;
     int s0 = head + k0, s1 = head + k1;
@@ -273,8 +307,15 @@ __device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane) {
         if (k0 < n) x0 = W.alpha[k0] - Hh.ro[s0] * W.bvec[k0];
         if (k1 < n) x1 = W.alpha[k1] - Hh.ro[s1] * W.bvec[k1];
     }
-    if (n > 64) lb_recur_loop<T, FIRST, true>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
-    else lb_recur_loop<T, FIRST, false>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
+    if (sizeof(T) == 4 && GL.buf) {
+        // virtual base so that "physical row r" of the loop lands on window row r - row0
+        const T* Mv = reinterpret_cast<const T*>(GL.buf) - (ptrdiff_t)GL.row0 * LB_GS;
+        if (n > 64) lb_recur_loop<T, FIRST, true, true>(Mv, n, head, lane, x0, x1);
+        else lb_recur_loop<T, FIRST, false, true>(Mv, n, head, lane, x0, x1);
+    } else {
+        if (n > 64) lb_recur_loop<T, FIRST, true>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
+        else lb_recur_loop<T, FIRST, false>(FIRST ? Hh.gcol : Hh.grow, n, head, lane, x0, x1);
+    }
     T* out = FIRST ? W.alpha : W.cvec;
     if (k0 < n) out[k0] = x0;
     if (k1 < n) out[k1] = x1;
@@ -283,21 +324,38 @@ __device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane) {
 // d = -H g (lbfgs_ls.py:336-358) by the whole workgroup (NT threads, wave 0 = the optimiser wave).
 // In: W.qv = -g, W.n/head/ins_slot/Hdiag, history rows incl. the freshly inserted pair.  Out: W.dv.
 template <typename T, int NT>
-__device__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+__device__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid, LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
+    // the window was requested before the optimiser advanced: it is usable if the ring head is where it was (or one
+    // further: the oldest pair was evicted) and the rows the walks touch are inside it; a stage change resets the
+    // ring and a head wrap moves the walk far away - then the recurrences read global memory as before
+    const bool staged = GL.buf != nullptr;
+    if (staged) {
+        const int hd = W.head - GL.row0;
+        if (hd < 0 || hd > 1 || hd + W.n + 2 + 4 * LB_PD > GL.nrows) GL.buf = nullptr;          // block-uniform
+    }
     lb_row_dots<T, NT>(Hh, W, 0, tid);
+    if (staged) __builtin_amdgcn_s_waitcnt(0);            // this wave's share of the gcol window has landed
     __syncthreads();
-    if (W.ins_slot >= 0) { lb_gram_insert<T, NT>(Hh, W, tid); __syncthreads(); }
+    if (W.ins_slot >= 0) { lb_gram_insert<T, NT>(Hh, W, tid, GL); __syncthreads(); }
     PH_T(16);
-    if (tid < 64) lb_recurrence<T, true>(Hh, W, tid);
+    if (tid < 64) lb_recurrence<T, true>(Hh, W, tid, GL);
     __syncthreads();
     PH_T(17);
+    if (sizeof(T) == 4 && GL.buf) {
+        // the window now takes grow (second recurrence): its rows around the current head, requested here and
+        // consumed after the mat-vec and the second row dots
+        GL.row0 = W.head;
+        GL.nrows = min(W.n, LB_HIST) + 2 + 4 * LB_PD;
+        lb_gram_dma<NT>(reinterpret_cast<const float*>(Hh.grow), GL.row0, GL.buf, GL.nrows, tid);
+    }
     // r_0 = H (-g - sum_j al_j y_j)
     lb_matvec<T, NT>(Hh.dirs, W.alpha, (T)-1, W.Hdiag, W.qv, W.qv, W, tid);
     PH_T(18);
     lb_row_dots<T, NT>(Hh, W, 1, tid);
+    if (GL.buf) __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     PH_T(19);
-    if (tid < 64) lb_recurrence<T, false>(Hh, W, tid);
+    if (tid < 64) lb_recurrence<T, false>(Hh, W, tid, GL);
     __syncthreads();
     PH_T(20);
     // d = r_0 + sum_j c_j s_j

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // shared by the two fit kernels: evaluate the closure at L.opt.x, advance the optimiser, leave the
 // next trial point in L.opt.x.  Returns true when the problem is finished.
 __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
-                          bool from_pass, bool have_pose, double* stage_final, int tid) {
+                          bool from_pass, bool have_pose, double* stage_final, int tid,
+                          LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
@@ -241,7 +242,7 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     __syncthreads();
     PH_T(10);
     if (L.lbW.need_dir) {                                  // block-uniform
-        lb_direction_block<float, STEP_NT>(H, L.lbW, tid);
+        lb_direction_block<float, STEP_NT>(H, L.lbW, tid, GL);
         PH_T(11); PH_ADD(15, 1);
         if (tid < 64) {
             float gnew[LB_EPL], xt[LB_EPL];
@@ -265,6 +266,8 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     return L.sh_status != 0;
 }
 
+__device__ __forceinline__ size_t step_lds_dev() { return (sizeof(ClosureLds) + 15) & ~(size_t)15; }
+
 // one closure round per launch (full mode): the objective reads the vertex pass's output for its
 // vertices; afterwards the pose operands of the NEXT trial point are published for the next pass.
 __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
@@ -282,8 +285,13 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     LbHist<float> H{F.dirs + (size_t)b * LB_HIST * LB_D, F.stps + (size_t)b * LB_HIST * LB_D, L.opt.lb_ro,
                     F.grow + (size_t)b * LB_GSIZE, F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
+    // Gram rows of the first recurrence -> LDS while the closure runs (the window covers the current head / length and
+    // the one after an insertion); lb_direction_block waits for it
+    LbGramLds GL{reinterpret_cast<float*>(smem_raw + step_lds_dev()), L.opt.lbS.hist_head,
+                 min(L.opt.lbS.hist_len + 1, LB_HIST) + 3 + 4 * LB_PD};
+    lb_gram_dma<STEP_NT>(H.gcol, GL.row0, GL.buf, GL.nrows, tid);
     PH_T(24);
-    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid);
+    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid, GL);
     PH_T0();
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
@@ -503,6 +511,7 @@ static T* dev_upload(mvfit_ctx* c, const std::vector<T>& h) {
 }
 
 static size_t step_lds() { return (sizeof(ClosureLds) + 15) & ~(size_t)15; }
+static size_t step_gram_lds() { return step_lds() + LB_GW_BYTES; }       // fit_step_kernel: + the staged Gram window
 static size_t persistent_lds() { return step_lds() + (size_t)2 * LB_HIST * LB_D * sizeof(float); }
 
 static void drop_graph(mvfit_ctx* c) {
@@ -866,7 +875,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
     HIP_OK(c, hipHostMalloc(&c->h_done, 4));
     HIP_OK(c, hipDeviceSynchronize());
@@ -1161,7 +1170,7 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
             if (e == hipSuccess && c->F.sdf_adj)
                 e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
                                     c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs);
-            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_gram_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                c->P, c->F);
         }
         hipError_t e2 = hipStreamEndCapture(cs, &g);
@@ -1235,7 +1244,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                 if (!rc && any_sdf) rc = run_sdf_term(c, c->d_verts, c->F.sdf_gate, c->stream);
                 if (rc) return rc;
                 prof_begin(c, c->ev_step);
-                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_gram_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                    c->P, c->F);
                 prof_end(c, c->ev_step);
             }
