@@ -5,7 +5,11 @@
 // "+ transl" of SMPL.forward (code/smplx/body_models_scale.py:401-403); the joint regression
 // J(beta) and the kinematic chain (lbs.py:183,205) are done per problem by the step kernel.
 //
-// MI355X mapping (details and the measured timeline: DESIGN.md 4.1)
+// Two kernels: lbs_vertex_pass_split_kernel (default; the contraction as error-compensated split-fp16 products on
+// the fp16 matrix pipe, described at its definition below) and lbs_vertex_pass_kernel (exact fp32 MFMA chain,
+// MVFIT_EXACT_FP32=1), each with a dense and a 4-pair skinning blend.
+//
+// MI355X mapping of the exact-fp32 kernel (details and the measured timeline: DESIGN.md 4.1)
 //   * one workgroup = one tile of 32 vertices x one chunk of 32 problems, 8 waves, 154 KB LDS.
 //   * waves 0-3 own the blendshape contraction [32 problems x 224] . [224 x 32 verts x 3] on the matrix
 //     cores in exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain): wave w = k-slice w (56 of the 224
