@@ -75,6 +75,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // While the basis stream is in flight ALL eight waves run the skinning blend T = W . A on the VALU
     // (the contraction waves would otherwise just wait for HBM); then waves 0-3 run the MFMA chain.
     // Blend item of a thread: vertices {2 vp, 2 vp + 1} x problem bb, all three rows of T (24 accumulators).
+    // (requested now: the side-output loop at the end would otherwise start with a cold dependent load)
+    const int sel_s0 = M.tile_sel_start[tile], sel_s1 = M.tile_sel_start[tile + 1];
     const int vp2 = tid & 15, bb = tid >> 4;              // wave w blends problems [4 w, 4 w + 4)
     float vt_init[3] = {0.f, 0.f, 0.f};
     float4 bv[3][VP_GPS];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
     {
-        const int s0 = M.tile_sel_start[tile], nsel = M.tile_sel_start[tile + 1] - s0;
+        const int s0 = sel_s0, nsel = sel_s1 - s0;
         for (int i = tid; i < nsel * 96; i += VP_NT) {
             const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
             if (b0 + b >= B) continue;
@@ -321,6 +323,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #else
     const long long t_start = 0;
 #endif
+    // (requested now: the side-output loop at the end would otherwise start with a cold dependent load)
+    const int sel_s0 = M.tile_sel_start[tile], sel_s1 = M.tile_sel_start[tile + 1];
     const int vp2 = tid & 15, bb = tid >> 4;              // wave w blends problems [4 w, 4 w + 4)
     float vt_init = 0.f;
     float4 ah[VP_BPW], al[VP_BPW], bh[VP_BPW], bl[VP_BPW];
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
     // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
     {
-        const int s0 = M.tile_sel_start[tile], nsel = M.tile_sel_start[tile + 1] - s0;
+        const int s0 = sel_s0, nsel = sel_s1 - s0;
         for (int i = tid; i < nsel * 96; i += VP_NT) {
             const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
             if (b0 + b >= B) continue;
