@@ -64,3 +64,28 @@ def test_device_fit_against_reference_fit(name, use_vp, sparse):
     chk = eng.closure(xf, w, want_grad=False)['loss'].cpu().numpy()
     assert np.all(chk <= final * (1 + 1e-3) + 1e-3)
     eng.close()
+
+
+def test_fit_is_independent_of_the_batch(monkeypatch):
+    """A problem fitted alone and inside a ragged batch of 33 (two vertex-pass chunks) follows the same trajectory
+    bit for bit: same parameters, loss and closure count (problems never interact; the pass is deterministic)."""
+    g = dict(np.load(os.path.join(GOLD, 'fit_l2.npz')))
+    model = body_model(0, 4)
+    cams = (g['cam_R'], g['cam_t'], g['cam_f'], g['cam_c'])
+    B = 33
+    rng = np.random.default_rng(12)
+    gt = np.repeat(g['gt_xy'][:1], B, 0) + rng.normal(0, 3.0, (B,) + g['gt_xy'].shape[1:]).astype(np.float32)
+    conf = np.repeat(g['conf'][:1], B, 0)
+    x0 = np.zeros((B, 118), np.float32); x0[:, 85] = 1.0
+    x0[:, :86] += rng.normal(0, 0.02, (B, 86)).astype(np.float32)
+    stages = eng_stage_weights(1536.0, flags=0)
+    eng = make_engine(model)
+    eng.set_problems(cams, gt, conf)
+    xa, sa = eng.fit(x0, stages)
+    xa = xa.cpu().numpy(); fa = sa['final_loss'].cpu().numpy(); na = sa['n_closure'].cpu().numpy()
+    for b in (0, 31, 32):
+        eng.set_problems(cams, gt[b:b + 1], conf[b:b + 1])
+        xb, sb = eng.fit(x0[b:b + 1], stages)
+        assert np.array_equal(xb.cpu().numpy()[0], xa[b])
+        assert sb['final_loss'].cpu().numpy()[0] == fa[b] and sb['n_closure'].cpu().numpy()[0] == na[b]
+    eng.close()
