@@ -287,6 +287,21 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     __syncthreads();
     // Gram rows of the first recurrence -> LDS while the closure runs (the window covers the current head / length and
     // the one after an insertion); lb_direction_block waits for it
+    // Touch every 128-byte line of the live history rows (s and y) once, now: after a launch boundary they are
+    // ~2.5 k cycles away, and the direction's row dots and mat-vecs - 18 k cycles from here - would each start with
+    // that round trip; afterwards they hit L2.  One load per thread, value never used (kept alive to the end so that
+    // the register is not recycled under the load).
+    float warm = 0.f;
+    {
+        const int n0 = L.opt.lbS.hist_len, head0 = L.opt.lbS.hist_head;
+        constexpr int LPR = LB_D * 4 / 128;                      // 3 lines per row
+        if (tid < 2 * LPR * n0) {
+            const int which = tid / (LPR * n0), r = tid - which * LPR * n0, age = r / LPR, ln = r - age * LPR;
+            int slot = head0 + age;
+            slot = slot >= LB_HIST ? slot - LB_HIST : slot;
+            warm = (which ? H.stps : H.dirs)[slot * LB_D + ln * 32];
+        }
+    }
     LbGramLds GL{reinterpret_cast<float*>(smem_raw + step_lds_dev()), L.opt.lbS.hist_head,
                  min(L.opt.lbS.hist_len + 1, LB_HIST) + 3 + 4 * LB_PD};
     lb_gram_dma<STEP_NT>(H.gcol, GL.row0, GL.buf, GL.nrows, tid);
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
     publish_pose(L, P, b, tid);
     store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
     if (SW.w[0].flags & MVFIT_F_VPOSER) store_block16(F.vp + b, L.vp_pre1, sizeof(VpBlock), tid);
+    if (__builtin_expect(warm == 1.7014118e38f, 0)) atomicAdd(F.n_done, 0);       // sink of the warm-up loads
     PH_T(25);
 }
 
