@@ -89,3 +89,28 @@ def test_fit_is_independent_of_the_batch(monkeypatch):
         assert np.array_equal(xb.cpu().numpy()[0], xa[b])
         assert sb['final_loss'].cpu().numpy()[0] == fa[b] and sb['n_closure'].cpu().numpy()[0] == na[b]
     eng.close()
+
+
+def test_fit_with_3d_targets_and_frozen_parameters():
+    """use_3d targets + fix_shape + fix_scale through the staged device fit: frozen parameters stay untouched, the
+    loss at the returned parameters is the returned loss, and it is far below the loss at the start."""
+    cfg_g = dict(np.load(os.path.join(GOLD, 'closure_l2_3d_v8.npz')))
+    model = body_model()
+    cams = (cfg_g['cam_R'], cfg_g['cam_t'], cfg_g['cam_f'], cfg_g['cam_c'])
+    B = cfg_g['x'].shape[0]
+    eng = make_engine(model)
+    eng.set_problems(cams, cfg_g['gt_xy'], cfg_g['conf'])
+    eng.set_joints3d(cfg_g['joints3d'][:, :, :3], cfg_g['joints3d'][:, :, 3])
+    flags = _lib.F_USE_3D | _lib.F_FIX_SHAPE | _lib.F_FIX_SCALE
+    stages = eng_stage_weights(1536.0, flags=flags)
+    x0 = np.zeros((B, 118), np.float32); x0[:, 85] = 1.1; x0[:, :10] = 0.3
+    l0 = eng.closure(x0, dict(stages[0]), want_grad=False)['loss'].cpu().numpy()
+    xf, st = eng.fit(x0, stages)
+    xf_h = xf.cpu().numpy()
+    assert np.array_equal(xf_h[:, :10], x0[:, :10]) and np.array_equal(xf_h[:, 85], x0[:, 85])
+    final = st['final_loss'].cpu().numpy()
+    chk = eng.closure(xf, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
+    assert np.all(np.isfinite(final)) and np.all(chk <= final * (1 + 1e-3) + 1e-3)
+    l0_last = eng.closure(x0, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
+    assert np.all(chk < 0.5 * l0_last), (chk, l0_last, l0)
+    eng.close()
