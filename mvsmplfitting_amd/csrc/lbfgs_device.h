@@ -94,6 +94,18 @@ struct LbHist {
     T* ro;         // [LB_HIST]
     T* grow;       // [LB_GROWS][LB_GS]
     T* gcol;       // [LB_GROWS][LB_GS]
+    // compact form (lb_direction_compact): by history slot, float64
+    //   rinv[i][j] = (R^-1)_ij, R_ij = s_i . y_j for i not newer than j ; rinvT = its transpose ; yyg[i][j] = y_i . y_j
+    double* rinv = nullptr;
+    double* rinvT = nullptr;
+    double* yyg = nullptr;
+};
+
+// scratch of lb_direction_compact (LDS): inputs of the small algebra by age index
+template <typename T>
+struct LbCompactWs {
+    T p[LB_HIST + 4], q[LB_HIST + 4], u[LB_HIST + 4], yy[LB_HIST + 4];
+    double w[LB_HIST + 4], z[LB_HIST + 4], a[LB_HIST + 4], c[LB_HIST + 4];
 };
 
 // LDS scratch of the block-wide direction computation
@@ -319,6 +331,154 @@ __device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane, const
     T* out = FIRST ? W.alpha : W.cvec;
     if (k0 < n) out[k0] = x0;
     if (k1 < n) out[k1] = x1;
+}
+
+// d = H (-g) in the compact (Byrd-Nocedal-Schnabel 1994, eq. 3.1) form of the same L-BFGS matrix the two-loop
+// recursion applies (lbfgs_ls.py:336-358), H_0 = gamma I:
+//     H q = gamma q + S a - gamma Y w,   w = R^-1 S^T q,   a = R^-T ((D + gamma Y^T Y) w - gamma Y^T q)
+// with R_ij = s_i . y_j (i not newer than j), D = diag(s_i . y_i).  R^-1 is maintained explicitly, one bordered
+// column per accepted pair ([R u; 0 rho]^-1 = [R^-1, -R^-1 u / rho; 0, 1/rho]); evicting the oldest pair drops the
+// first row and column, which leaves the inverse of the remaining block untouched.  The two triangular recurrences of
+// the two-loop form - 2 m dependent steps on one wave - become three m x m mat-vecs for the whole workgroup, and the
+// history is read twice instead of four times.  The m x m algebra runs in float64 (m <= 100: it is the conditioning
+// of R, not the flop count, that matters); the inputs are the same float dot products the two-loop form takes.
+// Same direction as the two-loop recursion up to rounding (tests: float64 instantiation follows the reference
+// optimiser's trajectories to 1e-7).
+template <typename T, int NT>
+__device__ void lb_direction_compact(const LbHist<T>& Hh, LbWork<T>& W, LbCompactWs<T>& C, int tid) {
+    const int n = W.n, head = W.head, t = W.ins_slot;
+    const bool ins = t >= 0;
+    const int nE = ins ? n - 1 : n;                      // pairs already represented in the matrices
+    const int l16 = tid & 15;
+    auto slot_of = [&](int age) { int sl = head + age; return sl >= LB_HIST ? sl - LB_HIST : sl; };
+    constexpr int HS = LB_HIST;                          // row stride of the matrices
+    // ---- pass 1 over the history: p = S^T q, q = Y^T q (+ u = S^T y_new, yy = Y^T y_new) ----
+    {
+        T qv[6], yn[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { qv[e] = W.qv[6 * l16 + e]; yn[e] = ins ? Hh.dirs[t * LB_D + 6 * l16 + e] : (T)0; }
+        for (int a = tid >> 4; a < n; a += NT / 16) {
+            const int sl = slot_of(a);
+            const T* sr = Hh.stps + sl * LB_D + 6 * l16;
+            const T* yr = Hh.dirs + sl * LB_D + 6 * l16;
+            T d0 = (T)0, d1 = (T)0, d2 = (T)0, d3 = (T)0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const T sv = sr[e], yv = yr[e];
+                d0 = fma(sv, qv[e], d0); d1 = fma(yv, qv[e], d1); d2 = fma(sv, yn[e], d2); d3 = fma(yv, yn[e], d3);
+            }
+            d0 = row16_sum(d0); d1 = row16_sum(d1);
+            if (ins) { d2 = row16_sum(d2); d3 = row16_sum(d3); }
+            if (l16 == 0) { C.p[a] = d0; C.q[a] = d1; C.u[a] = d2; C.yy[a] = d3; }
+        }
+    }
+    __syncthreads();
+    PH_T(16);
+    const double gam = (double)W.Hdiag;
+    const double rho = ins ? 1.0 / (double)Hh.ro[t] : 1.0;
+    // The three m x m mat-vecs: 8 lanes per matrix row, every lane's (up to 13) elements requested before the first
+    // FMA - a phase is one L2 round trip, not one per stripe of the row.
+    constexpr int RL = 8, NK = (LB_HIST + RL - 1) / RL;      // lanes per row, elements per lane
+    const int l8 = tid & (RL - 1);
+    auto row8_sum = [](double v) {                            // 8-lane butterfly (lanes of a group are DPP neighbours)
+        v += dpp_mov<DPP_XOR1>(v);
+        v += dpp_mov<DPP_XOR2>(v);
+        v += dpp_mov<DPP_HALF_MIRROR>(v);
+        return v;
+    };
+    // ---- rows of R^-1: c = -R^-1 u / rho (new column) and w = R^-1 p ----
+    for (int i = tid / RL; i < nE; i += NT / RL) {
+        const int si = slot_of(i);
+        const double* row = Hh.rinv + (size_t)si * HS;
+        double rv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const int j = min(i + l8 + RL * k, LB_HIST - 1); rv[k] = row[slot_of(min(j, n - 1))]; }
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int j = i + l8 + RL * k;
+            if (j < nE) { d1 = fma(rv[k], (double)C.u[j], d1); d2 = fma(rv[k], (double)C.p[j], d2); }
+        }
+        d1 = row8_sum(d1); d2 = row8_sum(d2);
+        if (l8 == 0) {
+            double wi = d2;
+            if (ins) {
+                const double ci = -d1 / rho;
+                C.c[i] = ci;
+                wi = fma(ci, (double)C.p[n - 1], wi);
+                Hh.rinv[(size_t)si * HS + t] = ci;
+                Hh.rinvT[(size_t)t * HS + si] = ci;
+                const double yi = (double)C.yy[i];
+                Hh.yyg[(size_t)si * HS + t] = yi;
+                Hh.yyg[(size_t)t * HS + si] = yi;
+            }
+            C.w[i] = wi;
+        }
+    }
+    if (ins && tid == NT - 1) {
+        C.w[n - 1] = (double)C.p[n - 1] / rho;
+        C.c[n - 1] = 1.0 / rho;
+        Hh.rinv[(size_t)t * HS + t] = 1.0 / rho;
+        Hh.rinvT[(size_t)t * HS + t] = 1.0 / rho;
+        Hh.yyg[(size_t)t * HS + t] = (double)C.yy[n - 1];
+    }
+    __syncthreads();
+    PH_T(17);
+    // ---- z = (D + gamma Y^T Y) w - gamma q ----
+    for (int i = tid / RL; i < n; i += NT / RL) {
+        const int si = slot_of(i);
+        const double* row = Hh.yyg + (size_t)si * HS;
+        double rv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) rv[k] = row[slot_of(min(l8 + RL * k, n - 1))];
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const int j = l8 + RL * k; if (j < n) d = fma(rv[k], C.w[j], d); }
+        d = row8_sum(d);
+        if (l8 == 0) C.z[i] = C.w[i] / (double)Hh.ro[si] + gam * (d - (double)C.q[i]);
+    }
+    __syncthreads();
+    PH_T(18);
+    // ---- a = R^-T z: rows of the transposed copy; the newest pair's column is still in C.c ----
+    for (int j = tid / RL; j < n; j += NT / RL) {
+        const bool fresh = ins && j == n - 1;
+        const double* row = Hh.rinvT + (size_t)slot_of(j) * HS;
+        double rv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const int i = min(l8 + RL * k, n - 1); rv[k] = fresh ? C.c[i] : row[slot_of(i)]; }
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { const int i = l8 + RL * k; if (i <= j) d = fma(rv[k], C.z[i], d); }
+        d = row8_sum(d);
+        if (l8 == 0) C.a[j] = d;
+    }
+    __syncthreads();
+    PH_T(19);
+    // ---- pass 2 over the history: d = gamma q + S a - gamma Y w ----
+    {
+        constexpr int NW = NT / 64;
+        const int wave = tid >> 6, lane = tid & 63;
+        if (LB_EPL * lane < LB_D) {
+            T a0 = (T)0, a1 = (T)0;
+            for (int j = wave; j < n; j += NW) {
+                const int sl = slot_of(j);
+                const T ca = (T)C.a[j], cw = (T)(-gam * C.w[j]);
+                a0 = fma(ca, Hh.stps[sl * LB_D + 2 * lane], a0);     a1 = fma(ca, Hh.stps[sl * LB_D + 2 * lane + 1], a1);
+                a0 = fma(cw, Hh.dirs[sl * LB_D + 2 * lane], a0);     a1 = fma(cw, Hh.dirs[sl * LB_D + 2 * lane + 1], a1);
+            }
+            W.part[wave][2 * lane] = a0;
+            W.part[wave][2 * lane + 1] = a1;
+        }
+        __syncthreads();
+        for (int e = tid; e < LB_D; e += NT) {
+            T sacc = (T)0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sacc += W.part[w][e];
+            W.dv[e] = fma((T)gam, W.qv[e], sacc);
+        }
+        __syncthreads();
+    }
+    PH_T(20);
 }
 
 // d = -H g (lbfgs_ls.py:336-358) by the whole workgroup (NT threads, wave 0 = the optimiser wave).

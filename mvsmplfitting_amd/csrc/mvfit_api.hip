@@ -412,16 +412,20 @@ __device__ double kat_eval(int kind, int D, const double* x, double* g) {
 __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O, double* x_io, double* trace,
                                                        int max_trace, int* n_closure, double* final_loss,
                                                        double* dirs, double* stps, double* ro, double* grow,
-                                                       double* gcol) {
+                                                       double* gcol, double* cmat) {
     __shared__ double xs[LB_D], gs[LB_D];
     __shared__ double fsh;
     __shared__ LbWork<double> W;
+    __shared__ LbCompactWs<double> CW;
+    const bool compact = (kind & 0x100) != 0;              // direction in compact form (lb_direction_compact)
+    kind &= 0xff;
     const int lane = threadIdx.x;
     LbState S;
     memset(&S, 0, sizeof(S));
     S.phase = PH_STEP_START; S.H = 1.0;
     LbVecs<double> V;
     LbHist<double> H{dirs, stps, ro, grow, gcol};
+    H.rinv = cmat; H.rinvT = cmat + LB_HIST * LB_HIST; H.yyg = cmat + 2 * LB_HIST * LB_HIST;
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) {
         const int i = LB_EPL * lane + e;
@@ -450,7 +454,8 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
         __syncthreads();
         if (lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss)) {     // wave-uniform
             __syncthreads();
-            lb_direction_block<double, 64>(H, W, lane);
+            if (compact) lb_direction_compact<double, 64>(H, W, CW, lane);
+            else lb_direction_block<double, 64>(H, W, lane);
             lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss);
         }
         if (S.status) break;
@@ -1383,12 +1388,12 @@ extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs,
     O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
     O.num_stages = 1; O.nseg = nseg;
     for (int i = 0; i < nseg; ++i) { O.seg_lo[i] = segs[i]; O.seg_hi[i] = segs[i + 1]; }
-    double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro, *dgrow, *dgcol;
+    double *dx, *dtrace, *dfl, *ddirs, *dstps, *dro, *dgrow, *dgcol, *dcmat;
     int* dn;
     const size_t tb = (size_t)std::max(max_trace, 1) * (D + 1) * 8;
     if (hipMalloc(&dx, LB_D * 8) || hipMalloc(&dtrace, tb) || hipMalloc(&dfl, 8) || hipMalloc(&dn, 4) ||
         hipMalloc(&ddirs, LB_HIST * LB_D * 8) || hipMalloc(&dstps, LB_HIST * LB_D * 8) || hipMalloc(&dro, LB_HIST * 8) ||
-        hipMalloc(&dgrow, LB_GSIZE * 8) || hipMalloc(&dgcol, LB_GSIZE * 8))
+        hipMalloc(&dgrow, LB_GSIZE * 8) || hipMalloc(&dgcol, LB_GSIZE * 8) || hipMalloc(&dcmat, 3 * LB_HIST * LB_HIST * 8))
         return MVFIT_E_HIP;
     hipMemcpy(dx, x_inout, D * 8, hipMemcpyHostToDevice);
     hipMemset(dtrace, 0, tb);
@@ -1396,13 +1401,14 @@ extern "C" int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs,
     hipMemset(dgcol, 0, LB_GSIZE * 8);
     hipMemset(ddirs, 0, LB_HIST * LB_D * 8);
     hipMemset(dstps, 0, LB_HIST * LB_D * 8);
+    hipMemset(dcmat, 0, 3 * LB_HIST * LB_HIST * 8);
     hipLaunchKernelGGL(lbfgs_kat_kernel, dim3(1), dim3(64), 0, 0, kind, D, O, dx, dtrace, max_trace, dn, dfl, ddirs, dstps, dro,
-                       dgrow, dgcol);
+                       dgrow, dgcol, dcmat);
     hipError_t e = hipDeviceSynchronize();
     hipMemcpy(x_inout, dx, D * 8, hipMemcpyDeviceToHost);
     if (trace && max_trace > 0) hipMemcpy(trace, dtrace, tb, hipMemcpyDeviceToHost);
     if (n_closure) hipMemcpy(n_closure, dn, 4, hipMemcpyDeviceToHost);
     if (final_loss) hipMemcpy(final_loss, dfl, 8, hipMemcpyDeviceToHost);
-    hipFree(dx); hipFree(dtrace); hipFree(dfl); hipFree(dn); hipFree(ddirs); hipFree(dstps); hipFree(dro); hipFree(dgrow); hipFree(dgcol);
+    hipFree(dx); hipFree(dtrace); hipFree(dfl); hipFree(dn); hipFree(ddirs); hipFree(dstps); hipFree(dro); hipFree(dgrow); hipFree(dgcol); hipFree(dcmat);
     return e == hipSuccess ? MVFIT_OK : MVFIT_E_HIP;
 }

@@ -17,12 +17,15 @@ KAT = dict(np.load(os.path.join(GOLD, 'lbfgs_kat.npz')))
 KIND = dict(quad=0, rosen=1, gmof=2)
 
 
+@pytest.mark.parametrize('form', ['two_loop', 'compact'])
 @pytest.mark.parametrize('kind', ['quad', 'rosen', 'gmof'])
 @pytest.mark.parametrize('D', [49, 86])
-def test_device_lbfgs_follows_reference(kind, D):
+def test_device_lbfgs_follows_reference(kind, D, form):
+    """form: the direction as the Gram-form two-loop recursion (single-launch kernel) or in compact form (full-mode
+    step kernel) - the same L-BFGS matrix, different association of the sums."""
     key = '%s_%d' % (kind, D)
     _, x0 = ln.kat_objective(kind, D)
-    xf, trace, ncl, final = lbfgs_kat(KIND[kind], D, [0, 10, 13, D], x0, max_trace=80)
+    xf, trace, ncl, final = lbfgs_kat(KIND[kind] | (0x100 if form == 'compact' else 0), D, [0, 10, 13, D], x0, max_trace=80)
     ref = KAT[key + '_trace']
     n = min(len(ref), len(trace), 40)
     for i in range(n):
