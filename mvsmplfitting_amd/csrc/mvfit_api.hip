@@ -486,7 +486,8 @@ struct mvfit_ctx {
     DevPose P{};
     float* d_verts = nullptr;          // [B][nv][3] internal vertex buffer
     FitBuffers F{};
-    int* h_done = nullptr;             // pinned
+    int* h_done = nullptr;             // pinned, 2 slots
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
     int ksplit = 4;
     bool has_vposer = false;
     bool has_joints3d = false;
@@ -898,7 +899,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
-    HIP_OK(c, hipHostMalloc(&c->h_done, 4));
+    HIP_OK(c, hipHostMalloc(&c->h_done, 8));
     HIP_OK(c, hipDeviceSynchronize());
     return MVFIT_OK;
 }
@@ -926,6 +927,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     if (c->d_sdf_faces) hipFree(c->d_sdf_faces);
     for (void* p : c->allocs) if (p) hipFree(p);
     if (c->h_done) hipHostFree(c->h_done);
+    for (hipEvent_t e : c->ev_done) if (e) hipEventDestroy(e);
     for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_step) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -1278,13 +1280,36 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     } else {
         rc = ensure_round_graph(c, SW, O);
         if (rc) return rc;
-        while (rounds < cap) {
-            HIP_OK(c, hipGraphLaunch(c->round_graph, c->stream));
-            rounds += c->graph_rounds;
-            HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_OK(c, hipStreamSynchronize(c->stream));
-            if (*h_done >= B) break;
+        // While at most half of the problems have finished, the next replay is queued before the host looks at the
+        // done counter of the current one (the GPU does not idle through the ~30 us host turnaround); later the
+        // replays go one at a time, so that no replay runs after the last problem finished.
+        if (!c->ev_done[0]) {
+            HIP_OK(c, hipEventCreateWithFlags(&c->ev_done[0], hipEventDisableTiming));
+            HIP_OK(c, hipEventCreateWithFlags(&c->ev_done[1], hipEventDisableTiming));
         }
+        auto enqueue = [&](int slot) -> hipError_t {
+            hipError_t e = hipGraphLaunch(c->round_graph, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_done[slot], c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_done[slot], c->stream);
+            return e;
+        };
+        int launched = 0, waited = 0, seen = 0;
+        h_done[0] = h_done[1] = 0;
+        const bool ahead_ok = B >= 8;
+        while (true) {
+            while (launched - waited < ((ahead_ok && seen <= B / 2) ? 2 : 1) && rounds < cap) {
+                HIP_OK(c, enqueue(launched & 1));
+                rounds += c->graph_rounds;
+                ++launched;
+            }
+            if (launched == waited) break;                     // round cap reached
+            HIP_OK(c, hipEventSynchronize(c->ev_done[waited & 1]));
+            seen = h_done[waited & 1];
+            ++waited;
+            if (seen >= B) break;
+        }
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        h_done[0] = seen;
     }
     const bool finished = *h_done >= B;
     hipLaunchKernelGGL(fit_finish_kernel, dim3(B), dim3(128), 0, c->stream, c->F, params, final_loss, n_closure, n_iter, B,
