@@ -119,6 +119,13 @@ class MvFit:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _dev(self, a, shape=None):
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(_f32(a))
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
