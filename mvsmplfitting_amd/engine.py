@@ -58,6 +58,7 @@ class MvFit:
                              'there is no CPU fallback')
         self._lib = _lib.load()
         self.device = torch.device('cuda', device)
+        self.dtype = torch.float32
         self.nv = int(model['v_template'].shape[0])
         keep = []
 

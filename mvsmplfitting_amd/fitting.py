@@ -102,9 +102,11 @@ class BodyModel(torch.nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------- loss holder
-class SMPLifyLoss:
-    """Weights and prior selection of reference ``SMPLifyLoss`` (fitting.py:215-280).  ``forward`` is
-    evaluated inside libmvfit; this object only carries what it is configured with.
+class SMPLifyLoss(torch.nn.Module):
+    """Weights and prior selection of reference ``SMPLifyLoss`` (fitting.py:215-280), an ``nn.Module`` like the
+    reference's so that the caller's ``loss = loss.to(device=device)`` (non_linear_solver.py:143) works.  The
+    arithmetic of ``forward`` is evaluated inside libmvfit by the closure; this object only carries what it is
+    configured with, and calling it raises.
 
     ``interpenetration`` (reference default True, fitting.py:224): the SDF term of fitting.py:352-393 is active
     whenever ``coll_loss_weight > 0``.  ``sdf_num_faces`` (an addition): how many leading triangles the SDF op
@@ -115,6 +117,7 @@ class SMPLifyLoss:
                  body_pose_weight=0.0, shape_weight=0.0, bending_prior_weight=0.0,
                  coll_loss_weight=0.0, reduction='sum', use_3d=False, sdf_num_faces=1, sdf_grid_size=128,
                  **kwargs):
+        super().__init__()
         self.sdf_num_faces, self.sdf_grid_size = sdf_num_faces, int(sdf_grid_size)
         self.use_3d = bool(use_3d)
         self.rho = float(rho)
@@ -135,6 +138,10 @@ class SMPLifyLoss:
             if hasattr(self, key):
                 v = loss_weight_dict[key]
                 setattr(self, key, float(v.item() if isinstance(v, torch.Tensor) else v))
+
+    def forward(self, *args, **kwargs):
+        raise MvFitError('SMPLifyLoss.forward runs inside libmvfit: evaluate it through the closure made by '
+                         'FittingMonitor.create_fitting_closure (there is no host implementation)')
 
     def weights(self, flags: int) -> dict:
         coll = self.coll_loss_weight if self.interpenetration else 0.0
@@ -174,19 +181,40 @@ class LBFGSHip:
                          '(or use the reference LBFGSLs with the HIP closure)')
 
 
+_reference_create_optimizer = None        # the reference's own factory, captured by patch_reference()
+
+
 def create_optimizer(parameters, optim_type='lbfgs', lr=1e-3, maxiters=20, gtol=1e-6, ftol=1e-9, **kwargs):
-    """reference optimizers/optim_factory.py:27-65 + the new ``'lbfgs_hip'`` type."""
+    """reference optimizers/optim_factory.py:27-65 + the new ``'lbfgs_hip'`` type.
+
+    ``'lbfgs_hip'``: the device-resident strong-Wolfe L-BFGS (whole stage inside libmvfit).  Every other type is
+    the REFERENCE's optimiser driving the HIP closure from the host: after :func:`patch_reference` the call is
+    handed to the reference's own factory unchanged (so ``'lbfgsls'`` - the yaml default, cfg_files/fit_smpl.yaml:63 -
+    is the reference's ``LBFGSLs``, and ``'rmsprop'`` fails exactly as it does there); stand-alone, the torch
+    optimisers are constructed with the reference's arguments and ``'lbfgsls'`` - whose class lives in the
+    reference tree - raises the reference's ValueError."""
     if optim_type == 'lbfgs_hip':
         return LBFGSHip(parameters, lr=lr, max_iter=maxiters), False
+    if _reference_create_optimizer is not None:
+        return _reference_create_optimizer(parameters, optim_type=optim_type, lr=lr, maxiters=maxiters,
+                                           gtol=gtol, ftol=ftol, **kwargs)
     if optim_type == 'lbfgs':
         return torch.optim.LBFGS(parameters, lr=lr, max_iter=maxiters), False
     if optim_type == 'adam':
         return torch.optim.Adam(parameters, lr=lr, betas=(kwargs.get('beta1', 0.9), kwargs.get('beta2', 0.999)),
                                 weight_decay=kwargs.get('weight_decay', 0.0)), False
+    if optim_type == 'rmsprop':           # optim_factory.py:53-58 passes `epsilon=`, which torch rejects (TypeError)
+        return torch.optim.RMSprop(parameters, lr=lr, epsilon=kwargs.get('epsilon', 1e-8),
+                                   alpha=kwargs.get('rmsprop_alpha', 0.99),
+                                   weight_decay=kwargs.get('weight_decay', 0.0),
+                                   momentum=kwargs.get('momentum', 0.9), centered=kwargs.get('centered', False)), False
     if optim_type == 'sgd':
         return torch.optim.SGD(parameters, lr=lr, momentum=kwargs.get('momentum', 0.9),
                                weight_decay=kwargs.get('weight_decay', 0.0),
                                nesterov=kwargs.get('use_nesterov', True)), False
+    if optim_type == 'lbfgsls':
+        raise ValueError("Optimizer lbfgsls not supported! (the reference's LBFGSLs class lives in its "
+                         "optimizers package: call patch_reference() first, or use optim_type='lbfgs_hip')")
     raise ValueError('Optimizer {} not supported!'.format(optim_type))
 
 
@@ -217,7 +245,7 @@ class _HipClosure:
         conf = torch.stack([torch.as_tensor(jc, dtype=torch.float32, device=dev).reshape(-1)[:17] for jc in joints_conf])
         jw = torch.as_tensor(joint_weights, dtype=torch.float32, device=dev).reshape(-1)[:17]
         eng.set_problems((R, t, f, c2), gt, (conf * jw[None])[None])
-        self.x = torch.zeros(1, D, device=dev)
+        self.x = torch.zeros(1, D, device=dev, dtype=eng.dtype)        # float32: what the kernels compute in
         self.x[0, 85] = 1.0
         self.params = dict(body_model.named_parameters())
         if use_vposer:
@@ -254,7 +282,7 @@ class _HipClosure:
             for name, p in self.params.items():
                 if name in SL:
                     a, b = SL[name]
-                    p.copy_(x[0, a:b].reshape(p.shape))
+                    p.copy_(x[0, a:b].reshape(p.shape))           # copy_ converts to the Parameter's dtype / device
 
     def __call__(self, backward=True):
         if backward and self.optimizer is not None:
@@ -265,7 +293,7 @@ class _HipClosure:
             for name, p in self.params.items():
                 if name in SL and p.requires_grad:
                     a, b = SL[name]
-                    p.grad = g[0, a:b].reshape(p.shape).clone()
+                    p.grad = g[0, a:b].reshape(p.shape).to(device=p.device, dtype=p.dtype, copy=True)
         return out['loss'][0]
 
 
@@ -319,8 +347,23 @@ class FittingMonitor:
 
 
 def patch_reference(fitting_module, optim_factory_module):
-    """Monkey-patch the reference modules (the three names ``non_linear_solver`` resolves at call time)
-    so that ``optim_type: 'lbfgs_hip'`` in the yaml runs the stage loop on libmvfit."""
+    """Monkey-patch the reference modules (the three names ``non_linear_solver`` resolves at call time:
+    non_linear_solver.py:127,145,172) so that its unmodified stage loop evaluates the closure on libmvfit.
+    ``optim_type: 'lbfgs_hip'`` in the yaml runs the whole stage device-resident; every other ``optim_type``
+    (the yaml default ``'lbfgsls'`` included) is built by the reference's ORIGINAL factory, captured here, and
+    drives the HIP closure from the host.  Idempotent; returns a function that undoes the patch."""
+    global _reference_create_optimizer
+    orig = (fitting_module.create_loss, fitting_module.FittingMonitor, optim_factory_module.create_optimizer)
+    if orig[2] is not create_optimizer:
+        _reference_create_optimizer = orig[2]
     fitting_module.create_loss = create_loss
     fitting_module.FittingMonitor = FittingMonitor
     optim_factory_module.create_optimizer = create_optimizer
+
+    def undo():
+        global _reference_create_optimizer
+        fitting_module.create_loss, fitting_module.FittingMonitor = orig[0], orig[1]
+        if orig[2] is not create_optimizer:
+            optim_factory_module.create_optimizer = orig[2]
+            _reference_create_optimizer = None
+    return undo

@@ -63,7 +63,8 @@ def problem_tensors(extris, intris, keypoints_per_view):
 
 def result_dict(x118, loss=None, body_pose_decoded=None):
     """x118: one row of the engine's flat parameter layout (include/mvfit.h); body_pose_decoded [69]: the VPoser
-    decode of the fitted embedding when VPoser was used (then the reference zeroes feet and hands)."""
+    decode of the fitted embedding when VPoser was used.  Like save_results (utils/utils.py:744-766) the saved body_pose /
+    pose have the feet and hand joints zeroed, with or without VPoser."""
     x = np.asarray(x118, np.float32).reshape(-1)
     res = dict(betas=x[0:10][None].copy(), global_orient=x[10:13][None].copy(), transl=x[82:85][None].copy(),
                scale=x[85:86][None].copy())
@@ -71,12 +72,12 @@ def result_dict(x118, loss=None, body_pose_decoded=None):
         res['loss'] = float(loss)
     if body_pose_decoded is not None:
         bp = np.asarray(body_pose_decoded, np.float32).reshape(1, 69).copy()
-        bp[:, 18:24] = 0.
-        bp[:, 27:33] = 0.
-        bp[:, 57:] = 0.
         res['pose_embedding'] = x[86:118][None].copy()
     else:
         bp = x[13:82][None].copy()
+    bp[:, 18:24] = 0.          # feet and hands are zeroed in both branches (utils/utils.py:750-753 and :761-764)
+    bp[:, 27:33] = 0.
+    bp[:, 57:] = 0.
     res['body_pose'] = bp
     res['pose'] = np.hstack((res['global_orient'], bp))
     return res

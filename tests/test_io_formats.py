@@ -46,7 +46,10 @@ def test_camera_and_keypoint_files(tmp_path):
 def test_result_files(tmp_path):
     x = np.arange(118, dtype=np.float32) * 0.01
     r = iof.result_dict(x, loss=12.5)
-    assert r['pose'].shape == (1, 72) and np.array_equal(r['pose'][0, 3:], x[13:82]) and r['loss'] == 12.5
+    want = x[13:82].copy()                       # non-VPoser branch zeroes feet / hands too (utils/utils.py:761-766)
+    want[18:24] = 0; want[27:33] = 0; want[57:] = 0
+    assert r['pose'].shape == (1, 72) and np.array_equal(r['pose'][0, 3:], want) and r['loss'] == 12.5
+    assert np.array_equal(r['body_pose'][0], want) and np.array_equal(r['pose'][0, :3], x[10:13])
     bp = np.ones(69, np.float32)
     rv = iof.result_dict(x, body_pose_decoded=bp)
     z = rv['body_pose'][0]
