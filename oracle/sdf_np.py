@@ -9,8 +9,12 @@ point-triangle distance if the segment towards (-1,-1,-1) crosses an odd number 
 unbounded above), else 0.  ``num_faces = faces.shape[0]`` exactly like the launcher (:314): the
 reference's caller passes faces as [1, F, 3] (code/utils/fitting.py:367-368), i.e. ONE triangle.
 
-PARITY UNPINNED: the reference op is CUDA-only and uses removed ATen APIs, it cannot run in
-this container or on the MI355X box; this restatement is checked only against its own source reading.
+PARITY PINNED against the reference's own kernel: oracle/Makefile compiles sdf_cuda_kernel.cu - unmodified, from
+where it lies under /root/reference - for the host (oracle/_ref/libsdf_ref.so; the CUDA qualifiers are defined away by
+oracle/ref_shims/, the launcher's thread geometry is replayed by oracle/sdf_ref_driver.cpp), oracle/make_golden_sdf.py
+wrote tests/golden/sdf_ref_*.npz with it, and tests/test_sdf_ref.py requires this restatement to reproduce those
+fields BIT-EXACTLY (it does: same float32 expression tree, no FMA contraction on either side).  Only the torch / pybind
+wrapper of the op (sdf_cuda.cpp, removed ATen APIs) remains unbuildable.
 Never imported by the shipped package.
 """
 from __future__ import annotations

@@ -11,9 +11,10 @@ As wired the SDF op receives faces of shape [1, F, 3], so it voxelises the FIRST
 Gradient paths: through the sampling coordinates ((v - c) / s of every vertex, c and s through the arg-min /
 arg-max vertices of the bounding box); phi itself is a constant.
 
-PARITY UNPINNED against the reference (its SDF op is CUDA-only and unbuildable here); the
-sampling + bounding-box part is pinned against torch.nn.functional.grid_sample + autograd in
-tests/test_oracle_sdf_term.py.  Never imported by the shipped package.
+Parity pins: the voxel values come from oracle/sdf_np.py, which is bit-exact against the reference's own kernel source
+compiled for the host (oracle/_ref, tests/test_sdf_ref.py); the sampling + bounding-box part is pinned against
+torch.nn.functional.grid_sample + autograd in tests/test_oracle_sdf_term.py.
+Never imported by the shipped package.
 """
 from __future__ import annotations
 

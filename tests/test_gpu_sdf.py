@@ -71,3 +71,24 @@ def test_sdf_full_size_properties():
     inside = float((phi > 0).float().mean())
     assert 0.01 < inside < 0.5 and float(phi.max()) < 1.0
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['wired_g128', 'f64_g32', 'all_g16', 'sphere1_g128', 'sphere_g32', 'sphere_g12'])
+def test_sdf_matches_reference_kernel_goldens(name):
+    """mvfit_sdf against fields written by the REFERENCE's own kernel source compiled for the host (oracle/_ref,
+    tests/golden/sdf_ref_*.npz, tests/test_sdf_ref.py).  Both sides evaluate the same float32 expression tree without
+    FMA contraction, with IEEE division and square root: the comparison is bit-exact, every voxel (the goldens'
+    `*_all` field; the reference's launch drops a partial last block, a documented deviation)."""
+    import os
+    from oracle import make_golden_sdf as mg
+    from tests.helpers import GOLD
+    g = np.load(os.path.join(GOLD, 'sdf_ref_%s.npz' % name))
+    G = int(g['G'])
+    ref = mg.dense(g['idx_all'], g['val_all'], (g['verts'].shape[0], G, G, G))
+    eng = make_engine(body_model())
+    phi = SDF(eng)(torch.tensor(g['faces'], device='cuda'), torch.tensor(g['verts'], device='cuda'), grid_size=G).cpu().numpy()
+    eng.close()
+    assert phi.shape == ref.shape
+    flips = int(((phi > 0) != (ref > 0)).sum())
+    assert flips == 0, flips
+    assert np.array_equal(phi, ref), (np.abs(phi - ref).max(), int((phi != ref).sum()))
