@@ -121,6 +121,9 @@ typedef struct mvfit_lbfgs_opts {
 /* Environment switches read here (testing / comparison): MVFIT_EXACT_FP32=1 keeps the vertex pass's blendshape
  * contraction as an exact fp32 MFMA chain (default: error-compensated split-fp16 products, fp32 accumulate);
  * MVFIT_DENSE_SKINNING=1 keeps the dense 24-column skinning blend even when every vertex has <= 4 weights. */
+/* Error contract: MVFIT_E_ARG for a null / incomplete model leaves *out = NULL.  Any later failure (unsupported
+ * model, device allocation) still stores a ctx in *out: it carries the message (mvfit_last_error) and owns whatever
+ * was allocated so far - release it with mvfit_destroy, it is not usable for anything else. */
 int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* model);
 void mvfit_destroy(mvfit_ctx* ctx);
 const char* mvfit_last_error(const mvfit_ctx* ctx);
@@ -159,6 +162,13 @@ int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint
  *   n_closure[B], n_iter[B] dev int32 (closure evaluations / L-BFGS iterations spent), may be NULL. */
 int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
+
+/* Optional closure trace of the NEXT mvfit_fit calls (test / debugging hook; the reference equivalent is printing
+ * inside fitting_func): for every problem the first max_closures closure evaluations are recorded as
+ *   trace[b][k][0:MVFIT_D] = the trial point the closure was evaluated at, trace[b][k][MVFIT_D] = its loss.
+ * trace[B, max_closures, MVFIT_D + 1] dev, caller-owned, must stay valid until tracing is switched off with
+ * mvfit_fit_trace(ctx, NULL, 0) (or the ctx is destroyed).  Rows beyond a problem's closure count are not written. */
+int mvfit_fit_trace(mvfit_ctx* ctx, float* trace, int max_closures);
 
 /* The SDF voxelisation op (reference sdf/sdf/sdf.py:21-26 -> sdf_cuda.cpp:14-28 -> sdf_cuda_kernel.cu:242-335):
  *   faces[num_faces,3] int32 dev ; vertices[B,num_vertices,3] dev, coordinates in [-1,1] ; phi[B,G,G,G] dev out

@@ -808,4 +808,25 @@ L_emit_trial:                                                         // _direct
     return 0;
 }
 
+// One optimiser round, shared by every kernel that drives the state machine (fit_step_kernel, fit_persistent_kernel,
+// lbfgs_kat_kernel): consume (f_new, gnew) of the closure just evaluated; when the machine asks for a search
+// direction, run `direction()` with the whole workgroup and resume WITH THE SAME (f_new, gnew) - the resumed call may
+// leave through `gtd > -tolerance_change` (lbfgs_ls.py:379-380) into run_fitting's gtol test (fitting.py:115-116),
+// which reads the .grad the last closure call left, i.e. this round's gnew.  Called by all NT threads (wave 0 = the
+// optimiser wave; S, V, gnew, xt are meaningful in wave 0 only).  On return xt = the next trial point.
+template <typename T, int NT, typename DirFn>
+__device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
+                                            double f_new, const T* gnew, T* xt, int tid, double* stage_final,
+                                            DirFn&& direction) {
+    if (tid < 64) {
+        const int need = lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+        if (tid == 0) W.need_dir = need;
+    }
+    __syncthreads();
+    if (W.need_dir) {                                      // block-uniform
+        direction();
+        if (tid < 64) lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+    }
+}
+
 }  // namespace mvfit

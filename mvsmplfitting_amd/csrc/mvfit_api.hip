@@ -50,6 +50,8 @@ struct FitBuffers {
     VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
     const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
     int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
+    float* trace;            // [B][trace_cap][DV + 1] (x_trial, loss) of the first closures of a fit (mvfit_fit_trace); may be null
+    int trace_cap;
 };
 
 // compact optimiser index (reference final_params order, non_linear_solver.py:164-170) -> flat x slot
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // next trial point in L.opt.x.  Returns true when the problem is finished.
 __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
-                          LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
+                          LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
@@ -213,50 +215,41 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     PH_T(2);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     PH_T(3);
+    if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
+        const int k = L.opt.lbS.n_closure;                 // closures consumed so far = index of this one
+        if (k < trace_cap) {
+            if (tid < DV) trace[(size_t)k * (DV + 1) + tid] = L.opt.x[tid];
+            if (tid == 0) trace[(size_t)k * (DV + 1) + DV] = (float)total;
+        }
+    }
     closure_backward(M, L, nviews, W, tid);
     PH_T(8);
     LbState S;
     LbVecs<float> V;
+    float gnew[LB_EPL], xt[LB_EPL];
     const int D = dact(use_vp);
     if (tid < 64) {
         S = L.opt.lbS;
         lb_load(V, &L.opt.lbV[0][0], tid);
         PH_T(9);
-        float gnew[LB_EPL], xt[LB_EPL];
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) {
             const int i = LB_EPL * tid + e;
             gnew[e] = i < D ? L.grad[cmap(i, use_vp)] : 0.f;
         }
-        // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
-        const int need = lbfgs_advance<float>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final);
-        if (tid == 0) L.lbW.need_dir = need;
-        if (!need) {
-#pragma unroll
-            for (int e = 0; e < LB_EPL; ++e) {
-                const int i = LB_EPL * tid + e;
-                if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
-            }
-        }
     }
-    __syncthreads();
-    PH_T(10);
-    if (L.lbW.need_dir) {                                  // block-uniform
+    // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
+    lbfgs_round<float, STEP_NT>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
+        PH_T(10);
         lb_direction_block<float, STEP_NT>(H, L.lbW, tid, GL);
         PH_T(11); PH_ADD(15, 1);
-        if (tid < 64) {
-            float gnew[LB_EPL], xt[LB_EPL];
-#pragma unroll
-            for (int e = 0; e < LB_EPL; ++e) gnew[e] = 0.f;
-            lbfgs_advance<float>(S, V, H, L.lbW, O, 0.0, gnew, xt, tid, stage_final);
-#pragma unroll
-            for (int e = 0; e < LB_EPL; ++e) {
-                const int i = LB_EPL * tid + e;
-                if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
-            }
-        }
-    }
+    });
     if (tid < 64) {
+#pragma unroll
+        for (int e = 0; e < LB_EPL; ++e) {
+            const int i = LB_EPL * tid + e;
+            if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
+        }
         lb_store(V, &L.opt.lbV[0][0], tid);
         if (tid == 0) { L.opt.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
         PH_ADD(13, 1); PH_ADD(14, S.hist_len);
@@ -306,7 +299,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
                  min(L.opt.lbS.hist_len + 1, LB_HIST) + 3 + 4 * LB_PD};
     lb_gram_dma<STEP_NT>(H.gcol, GL.row0, GL.buf, GL.nrows, tid);
     PH_T(24);
-    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid, GL);
+    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid, GL,
+                                F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap);
     PH_T0();
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     if (tid == 0 && done) atomicAdd(F.n_done, 1);
@@ -348,7 +342,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t);
+        done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
+                         F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap);
         if (done) break;                                  // block-uniform
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
@@ -452,12 +447,10 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
-        if (lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss)) {     // wave-uniform
-            __syncthreads();
+        lbfgs_round<double, 64>(S, V, H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
             if (compact) lb_direction_compact<double, 64>(H, W, CW, lane);
             else lb_direction_block<double, 64>(H, W, lane);
-            lbfgs_advance<double>(S, V, H, W, O, f, gnew, xt, lane, final_loss);
-        }
+        });
         if (S.status) break;
     }
 #pragma unroll
@@ -476,6 +469,7 @@ struct mvfit_ctx {
     std::string err;
     DevModel M{};
     std::vector<void*> allocs;
+    bool upload_failed = false;
     int nv = 0;
     // problems
     DevProblems Q{};
@@ -491,6 +485,9 @@ struct mvfit_ctx {
     int ksplit = 4;
     bool has_vposer = false;
     bool has_joints3d = false;
+    float *d_gt3d = nullptr, *d_c3d = nullptr;   // staging of mvfit_set_joints3d ([B][17][3], [B][17])
+    float* trace = nullptr;            // caller's device buffer (mvfit_fit_trace), not owned
+    int trace_cap = 0;
     int gmm_M = 0;
     // full-mode round loop captured as a graph: key = everything baked into the kernel nodes
     hipGraphExec_t round_graph = nullptr;
@@ -526,9 +523,9 @@ static int fail(mvfit_ctx* c, int code, const char* fmt, ...) {
 template <typename T>
 static T* dev_upload(mvfit_ctx* c, const std::vector<T>& h) {
     T* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
-    c->allocs.push_back(d);
-    if (!h.empty()) hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) d = nullptr;
+    c->allocs.push_back(d);                 // a null entry makes mvfit_create fail (checked after all uploads)
+    if (d && !h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) c->upload_failed = true;
     return d;
 }
 
@@ -545,8 +542,12 @@ extern "C" const char* mvfit_last_error(const mvfit_ctx* ctx) { return ctx ? ctx
 
 extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* m) {
     if (!out || !m || !m->v_template || !m->shapedirs || !m->posedirs || !m->J_regressor || !m->parents ||
-        !m->lbs_weights || !m->kp_regressor || !m->face_vertex_ids || !m->joint_map || m->num_verts <= 0)
+        !m->lbs_weights || !m->kp_regressor || !m->face_vertex_ids || !m->joint_map || m->num_verts <= 0) {
+        if (out) *out = nullptr;
         return MVFIT_E_ARG;
+    }
+    // From here on *out is a ctx even when an error is returned: it holds the message for mvfit_last_error and owns
+    // whatever was allocated so far - the caller releases both with mvfit_destroy (include/mvfit.h).
     mvfit_ctx* c = new mvfit_ctx();
     *out = c;
     c->device = device;
@@ -893,6 +894,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         c->gmm_M = m->gmm_M;
     }
     for (void* p : c->allocs) if (!p) return fail(c, MVFIT_E_HIP, "device allocation failed");
+    if (c->upload_failed) return fail(c, MVFIT_E_HIP, "copying the model constants to the device failed");
     HIP_OK(c, vertex_pass_configure());
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
@@ -909,8 +911,10 @@ static void free_problem_buffers(mvfit_ctx* c) {
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
-                  c->d_sdf_adj, c->F.sdf_gate, c->F.vp};
+                  c->d_sdf_adj, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
+    c->B = c->V = c->Bpad = 0;          // nothing is allocated: a failed re-allocation cannot leave a stale shape behind
+    c->d_gt3d = c->d_c3d = nullptr;
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
     c->d_obs = nullptr;
     c->P = DevPose{};
@@ -974,7 +978,9 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->F.n_done, 4));
         HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
         HIP_OK(c, hipMalloc(&c->F.vp, (size_t)B * sizeof(VpBlock)));
-        c->B = B; c->V = V; c->Bpad = Bpad;
+        HIP_OK(c, hipMalloc(&c->d_gt3d, (size_t)B * NKP * 3 * 4));
+        HIP_OK(c, hipMalloc(&c->d_c3d, (size_t)B * NKP * 4));
+        c->B = B; c->V = V; c->Bpad = Bpad;      // only now: every buffer of this shape exists
     }
     const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
     HIP_OK(c, hipMemcpyAsync(c->d_camR, cam_R, nc * 9 * 4, hipMemcpyDefault, c->stream));
@@ -995,15 +1001,10 @@ extern "C" int mvfit_set_joints3d(mvfit_ctx* c, const float* gt3d, const float* 
     if (!c || !gt3d || !conf3d) return MVFIT_E_ARG;
     if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
     HIP_OK(c, hipSetDevice(c->device));
-    float *d3 = nullptr, *c3 = nullptr;
-    HIP_OK(c, hipMalloc(&d3, (size_t)c->B * NKP * 3 * 4));
-    HIP_OK(c, hipMalloc(&c3, (size_t)c->B * NKP * 4));
-    HIP_OK(c, hipMemcpyAsync(d3, gt3d, (size_t)c->B * NKP * 3 * 4, hipMemcpyDefault, c->stream));
-    HIP_OK(c, hipMemcpyAsync(c3, conf3d, (size_t)c->B * NKP * 4, hipMemcpyDefault, c->stream));
-    hipLaunchKernelGGL(pack_joints3d_kernel, dim3(c->B), dim3(64), 0, c->stream, (const float*)d3, (const float*)c3, c->d_obs);
+    HIP_OK(c, hipMemcpyAsync(c->d_gt3d, gt3d, (size_t)c->B * NKP * 3 * 4, hipMemcpyDefault, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_c3d, conf3d, (size_t)c->B * NKP * 4, hipMemcpyDefault, c->stream));
+    hipLaunchKernelGGL(pack_joints3d_kernel, dim3(c->B), dim3(64), 0, c->stream, (const float*)c->d_gt3d, (const float*)c->d_c3d, c->d_obs);
     HIP_OK(c, hipGetLastError());
-    HIP_OK(c, hipStreamSynchronize(c->stream));
-    hipFree(d3); hipFree(c3);
     c->has_joints3d = true;
     return MVFIT_OK;
 }
@@ -1231,6 +1232,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
         if (rc) return rc;
     }
     c->F.sdf_adj = any_sdf ? c->d_sdf_adj : nullptr;
+    c->F.trace = c->trace; c->F.trace_cap = c->trace ? c->trace_cap : 0;
     LbOpts O;
     int rc = make_opts(c, o, sw[0].flags, O);
     if (rc) return rc;
@@ -1316,6 +1318,13 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                        o->num_stages);
     HIP_OK(c, hipGetLastError());
     if (!finished) return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished", cap);
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_fit_trace(mvfit_ctx* c, float* trace, int max_closures) {
+    if (!c || max_closures < 0 || (trace && max_closures == 0)) return MVFIT_E_ARG;
+    c->trace = trace;
+    c->trace_cap = trace ? max_closures : 0;
     return MVFIT_OK;
 }
 

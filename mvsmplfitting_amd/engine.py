@@ -150,6 +150,8 @@ class MvFit:
         gt = self._dev(gt_xy)
         B, V = int(gt.shape[0]), int(gt.shape[1])
         wc = self._dev(w_conf, (B, V, 17))
+        if B != self.B and getattr(self, '_trace', None) is not None:
+            self.fit_trace(0)                    # the trace buffer was sized for the old batch
         batched = 1 if np.ndim(cam_R) == 4 else 0
         R, t, f, c = self._dev(cam_R), self._dev(cam_t), self._dev(cam_f), self._dev(cam_c)
         self._check(self._lib.mvfit_set_problems(
@@ -207,6 +209,18 @@ class MvFit:
                                  ncl.data_ptr(), nit.data_ptr())
         self._check(rc)
         return x, dict(final_loss=final, n_closure=ncl, n_iter=nit)
+
+    def fit_trace(self, max_closures=0):
+        """Record (x_trial[118], loss) of the first ``max_closures`` closure calls of every problem during the next
+        fits (include/mvfit.h:mvfit_fit_trace); returns the [B, max_closures, 119] tensor (NaN where nothing was
+        written).  ``max_closures=0`` switches tracing off."""
+        if max_closures <= 0:
+            self._check(self._lib.mvfit_fit_trace(self._ctx, None, 0))
+            self._trace = None
+            return None
+        self._trace = torch.full((self.B, int(max_closures), D + 1), float('nan'), device=self.device)
+        self._check(self._lib.mvfit_fit_trace(self._ctx, self._trace.data_ptr(), int(max_closures)))
+        return self._trace
 
     def sdf(self, faces, vertices, grid_size=32):
         """phi[B,G,G,G] of the SDF voxelisation op (include/mvfit.h:mvfit_sdf).  faces: int tensor whose

@@ -53,6 +53,7 @@ class LbfgsOracle:
         self.dirs, self.stps, self.ro = [], [], []
         self.last_grad = None          # .grad left by the last closure call (gtol test reads it)
         self.trace = []                # (x_trial, loss) of every closure call
+        self.exits = []                # why each step() ended: 'grad0', 'gtd' (:379-380, with n_iter), 'ls' (:419-434)
 
     def _eval(self, x):
         f, g = self.evalfn(x)
@@ -139,6 +140,7 @@ class LbfgsOracle:
         loss = orig_loss
         cur_evals = 1
         if np.abs(g).max() <= self.tol_grad:
+            self.exits.append(('grad0', self.n_iter))
             return orig_loss
         d, t, H = self.d, self.t, self.H
         n = 0
@@ -177,6 +179,7 @@ class LbfgsOracle:
                 t = self.lr
             gtd = float(g @ d)
             if gtd > -self.tol_change:
+                self.exits.append(('gtd', self.n_iter))
                 break
             loss, g, t, ls_evals = self._strong_wolfe(t, d, loss, g, gtd)
             self.x = self.x + t * d

@@ -143,12 +143,18 @@ def gen_closure_goldens(lsp, only=None):
         print('%-18s loss64 %s  fp32-vs-fp64 rel %.1e' % (name, res['float64'][0], e_l.max()))
 
 
-def run_ref_lbfgs(fn, x0, segments, dtype_name='float64', maxiters=30):
+def run_ref_lbfgs(fn, x0, segments, dtype_name='float64', maxiters=30, tolerances=None):
+    """tolerances = (tolerance_grad, tolerance_change): construct the reference's LBFGS class directly (the factory
+    does not forward them, optim_factory.py:50-52)."""
     import torch
     ref = ri.load()
     dt = torch.float64 if dtype_name == 'float64' else torch.float32
     ps = [torch.nn.Parameter(torch.tensor(x0[a:b], dtype=dt)) for a, b in segments]
-    opt, _ = ref.optim_factory.create_optimizer(ps, optim_type='lbfgsls', lr=1.0, maxiters=30)
+    if tolerances is None:
+        opt, _ = ref.optim_factory.create_optimizer(ps, optim_type='lbfgsls', lr=1.0, maxiters=30)
+    else:
+        opt = ref.lbfgs_ls.LBFGS(ps, lr=1.0, max_iter=30, tolerance_grad=tolerances[0], tolerance_change=tolerances[1],
+                                 line_search_fn='strong_Wolfe')
     trace = []
 
     def closure(backward=True):
@@ -165,6 +171,9 @@ def run_ref_lbfgs(fn, x0, segments, dtype_name='float64', maxiters=30):
     return final, np.asarray(trace), xf
 
 
+GTD_CASES = [('quad', 49, 1e-3), ('quad', 86, 1e-4), ('gmof', 49, 1e-2), ('gmof', 86, 1e-3)]
+
+
 def gen_lbfgs_kat():
     out = {}
     for kind in ('quad', 'rosen', 'gmof'):
@@ -178,12 +187,54 @@ def gen_lbfgs_kat():
             out[key + '_final'] = np.array(final)
             out[key + '_xf'] = xf
             print('kat', key, 'closures', len(trace), 'final', final)
+    # forced `gtd > -tolerance_change` exits right after a direction computation (lbfgs_ls.py:379-380): tiny
+    # tolerance_grad, large tolerance_change; run_fitting then keeps stepping on the gradient the last closure left
+    for kind, D, tc in GTD_CASES:
+        fn, x0 = ln.kat_objective(kind, D)
+        seg = [(0, 10), (10, 13), (13, D)]
+        final, trace, xf = run_ref_lbfgs(fn, x0, seg, tolerances=(1e-12, tc))
+        key = '%s_%d_gtd' % (kind, D)
+        out[key + '_trace'] = trace[:80]
+        out[key + '_n'] = np.array(len(trace))
+        out[key + '_final'] = np.array(final)
+        out[key + '_xf'] = xf
+        out[key + '_tc'] = np.array(tc)
+        print('kat', key, 'tolerance_change', tc, 'closures', len(trace), 'final', final)
     np.savez_compressed(os.path.join(GOLD, 'lbfgs_kat.npz'), **out)
 
 
+def run_reference_fit(rp, x0, stages):
+    """The stage loop of non_linear_solver.py:156-211 around the reference's own optimiser / closure / run_fitting;
+    returns final loss, flat params, closures per stage and the (x_flat, loss) trace of every closure call."""
+    rp.set_flat(x0)
+    ncl, trace, final = [], [], None
+    for wts in stages:
+        rp.set_weights(wts)
+        opt = rp.make_optimizer()
+        inner = rp.make_closure(opt)
+        cnt = [0]
+
+        def closure(backward=True, inner=inner, cnt=cnt):
+            x = rp.get_flat().astype(np.float64)
+            val = inner(backward)
+            cnt[0] += 1
+            trace.append(np.concatenate([x, [float(val)]]))
+            return val
+        with contextlib.redirect_stdout(io.StringIO()):
+            final = rp.monitor.run_fitting(opt, closure, rp.final_params(), rp.smpl, use_vposer=rp.use_vposer,
+                                           pose_embedding=rp.pose_embedding, vposer=rp.vposer)
+        ncl.append(cnt[0])
+    return final, rp.get_flat().astype(np.float64), ncl, np.asarray(trace)
+
+
+TRACE_LEN = 120
+
+
 def gen_fit_goldens(lsp):
-    """Full 4-stage fits by the reference (non_linear_solver.py:156-211 restated as a driver
-    around the reference's own create_optimizer / create_fitting_closure / run_fitting)."""
+    """Full 4-stage fits by the reference (non_linear_solver.py:156-211 restated as a driver around the reference's
+    own create_optimizer / create_fitting_closure / run_fitting), float64 and float32, with the (x, loss) of the first
+    TRACE_LEN closure calls."""
+    stages = [stage_weights(st) for st in range(4)]
     for name, use_vp in (('l2', False), ('vposer', True)):
         model = syn.make_body_model(0, kp_regressor=lsp)
         cams = syn.make_camera_ring(8)
@@ -191,7 +242,7 @@ def gen_fit_goldens(lsp):
         orc = cn.ClosureOracle(model, np.float64, vposer=vpw)
         frames = syn.make_frames(2, seed0=1000)
         lay, D = cn.param_layout(use_vp)
-        res = dict(x0=[], xf=[], final=[], ncl=[], gt_xy=[], conf=[])
+        res = dict(x0=[], xf=[], final=[], ncl=[], gt_xy=[], conf=[], trace64=[], xf32=[], final32=[], ncl32=[], trace32=[])
         for b in range(2):
             p = {k: frames[k][b] for k in frames}
             p['use_vposer'] = False
@@ -200,28 +251,13 @@ def gen_fit_goldens(lsp):
             gt, cf = gt[0], cf[0]
             x0 = np.zeros(D)
             x0[lay['scale'][0]] = 1.0
-            rp = ri.RefProblem(model, cams, gt, cf, 'float64', use_vposer=use_vp,
-                               vposer_weights=vpw)
-            rp.set_flat(x0)
-            ncl = []
-            final = None
-            for st in range(4):
-                rp.set_weights(stage_weights(st))
-                opt = rp.make_optimizer()
-                inner = rp.make_closure(opt)
-                cnt = [0]
-
-                def closure(backward=True, inner=inner, cnt=cnt):
-                    cnt[0] += 1
-                    return inner(backward)
-                with contextlib.redirect_stdout(io.StringIO()):
-                    final = rp.monitor.run_fitting(opt, closure, rp.final_params(), rp.smpl,
-                                                   use_vposer=use_vp, pose_embedding=rp.pose_embedding,
-                                                   vposer=rp.vposer)
-                ncl.append(cnt[0])
-            res['x0'].append(x0); res['xf'].append(rp.get_flat()); res['final'].append(final)
-            res['ncl'].append(ncl); res['gt_xy'].append(gt); res['conf'].append(cf)
-            print('fit', name, b, 'closures/stage', ncl, 'final', final)
+            for dtn, sfx in (('float64', ''), ('float32', '32')):
+                rp = ri.RefProblem(model, cams, gt, cf, dtn, use_vposer=use_vp, vposer_weights=vpw)
+                final, xf, ncl, trace = run_reference_fit(rp, x0, stages)
+                res['xf' + sfx].append(xf); res['final' + sfx].append(final); res['ncl' + sfx].append(ncl)
+                res['trace64' if not sfx else 'trace32'].append(trace[:TRACE_LEN])
+                print('fit', name, b, dtn, 'closures/stage', ncl, 'final', final)
+            res['x0'].append(x0); res['gt_xy'].append(gt); res['conf'].append(cf)
         np.savez_compressed(os.path.join(GOLD, 'fit_%s.npz' % name),
                             **{k: np.asarray(v) for k, v in res.items()},
                             cam_R=cams[0], cam_t=cams[1], cam_f=cams[2], cam_c=cams[3])

@@ -16,16 +16,14 @@ rotation-vector conversion because cv2 is absent here), closure values and the 4
 Writes tests/golden/demo_fit_smpl.npz."""
 from __future__ import annotations
 
-import contextlib
 import glob
-import io
 import os
 
 import numpy as np
 
 from mvsmplfitting_amd import synthetic as syn
 from oracle import ref_import as ri
-from oracle.make_golden import GOLD, STAGE_POSE_W, STAGE_SHAPE_W
+from oracle.make_golden import GOLD, STAGE_POSE_W, STAGE_SHAPE_W, run_reference_fit
 
 REF = ri.REF_ROOT
 H_IMG = 1536.0          # data/images/0000/Camera0*/00001.jpg are 2048 x 1536
@@ -79,30 +77,6 @@ def reference_init_guess(rp, extris, intris, kps):
     return dict(joints_rest=joints, joints3d=joints3d, rot=rot, global_orient=rvec, transl=trans, scale=float(scale))
 
 
-def run_reference_fit(rp, x0, stages, dtype_name):
-    """The stage loop of non_linear_solver.py:156-211 around the reference's own optimiser / closure / run_fitting;
-    returns final loss, flat params, closures per stage and the (x_flat, loss) trace of every closure call."""
-    rp.set_flat(x0)
-    ncl, trace, final = [], [], None
-    for wts in stages:
-        rp.set_weights(wts)
-        opt = rp.make_optimizer()
-        inner = rp.make_closure(opt)
-        cnt = [0]
-
-        def closure(backward=True, inner=inner, cnt=cnt):
-            x = rp.get_flat().astype(np.float64)
-            val = inner(backward)
-            cnt[0] += 1
-            trace.append(np.concatenate([x, [float(val)]]))
-            return val
-        with contextlib.redirect_stdout(io.StringIO()):
-            final = rp.monitor.run_fitting(opt, closure, rp.final_params(), rp.smpl, use_vposer=rp.use_vposer,
-                                           pose_embedding=rp.pose_embedding, vposer=rp.vposer)
-        ncl.append(cnt[0])
-    return final, rp.get_flat().astype(np.float64), ncl, np.asarray(trace)
-
-
 def main():
     from oracle import closure_np as cn
     vpw = export_vposer_decoder()
@@ -153,7 +127,7 @@ def main():
         if dtn == 'float64':
             out['cverts64_as32'] = np.asarray(Vt)[:3].astype(np.float32)
         rp = ri.RefProblem(model, cams, gt, conf, dtn, use_vposer=True, vposer_weights=vpw)
-        final, xf, ncl, trace = run_reference_fit(rp, out['x0'], stages, dtn)
+        final, xf, ncl, trace = run_reference_fit(rp, out['x0'], stages)
         out['fit_final' + sfx] = np.array(final)
         out['fit_xf' + sfx] = xf
         out['fit_ncl' + sfx] = np.array(ncl)

@@ -40,6 +40,25 @@ def test_device_lbfgs_follows_reference(kind, D, form):
         assert np.abs(xf - KAT[key + '_xf']).max() < 1e-3
 
 
+@pytest.mark.parametrize('form', ['two_loop', 'compact'])
+@pytest.mark.parametrize('kind,D', [('quad', 49), ('quad', 86), ('gmof', 49), ('gmof', 86)])
+def test_device_gtd_exit_after_direction(kind, D, form):
+    """The resumed call after the direction leaves through `gtd > -tolerance_change` (lbfgs_ls.py:379-380) and
+    run_fitting's gtol test must see the gradient of the last closure (fitting.py:115-116) - with a zeroed gradient
+    the stage would end there, 2-3 closures and one or two outer steps early.  The kernel runs the production round
+    (lbfgs_round, shared with the fit kernels); goldens from the reference's LBFGS class with forced tolerances."""
+    key = '%s_%d_gtd' % (kind, D)
+    _, x0 = ln.kat_objective(kind, D)
+    xf, trace, ncl, final = lbfgs_kat(KIND[kind] | (0x100 if form == 'compact' else 0), D, [0, 10, 13, D], x0, max_trace=80,
+                                      tolerance_grad=1e-12, tolerance_change=float(KAT[key + '_tc']))
+    ref = KAT[key + '_trace']
+    assert ncl == int(KAT[key + '_n']), (ncl, int(KAT[key + '_n']))
+    for i in range(len(ref)):
+        assert np.abs(trace[i][:D] - ref[i][:D]).max() < 1e-7, (key, i)
+    assert abs(final - float(KAT[key + '_final'])) <= 1e-9 * max(1.0, abs(final))
+    assert np.abs(xf - KAT[key + '_xf']).max() < 1e-8
+
+
 @pytest.mark.parametrize('name,use_vp', [('l2', False), ('vposer', True)])
 @pytest.mark.parametrize('sparse', [False, True])
 def test_device_fit_against_reference_fit(name, use_vp, sparse):
