@@ -133,6 +133,18 @@ def main():
         out['fit_ncl' + sfx] = np.array(ncl)
         out['fit_trace' + sfx] = trace[:120]
         print(dtn, 'closure losses', np.asarray(L), 'fit closures/stage', ncl, 'final', final)
+    # how much the reference's own float32 fit moves when x0 is perturbed by 1e-6 (relative): the yard-stick for
+    # "same quality" on this ill-conditioned problem (the optimum reached is chaotic in the last bits)
+    rng = np.random.default_rng(0)
+    spread, spread_n = [], []
+    for i in range(6):
+        x0p = out['x0'] * (1 + rng.normal(0, 1e-6, out['x0'].shape))
+        rp = ri.RefProblem(model, cams, gt, conf, 'float32', use_vposer=True, vposer_weights=vpw)
+        final, xf, ncl, trace = run_reference_fit(rp, x0p, stages)
+        spread.append(final); spread_n.append(ncl)
+        print('perturbed x0', i, 'final', final, 'closures/stage', ncl)
+    out['fit_spread32'] = np.asarray(spread)
+    out['fit_spread_ncl32'] = np.asarray(spread_n)
     np.savez_compressed(os.path.join(GOLD, 'demo_fit_smpl.npz'), **out)
 
 

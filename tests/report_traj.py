@@ -1,3 +1,4 @@
+"""Report (not a test): device fit traces next to the reference float32 traces.  PYTHONPATH=. python tests/report_traj.py"""
 import os, numpy as np
 from mvsmplfitting_amd import _lib, synthetic as syn
 from mvsmplfitting_amd.engine import stage_weights as esw

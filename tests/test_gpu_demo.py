@@ -59,9 +59,10 @@ def test_demo_closure_with_the_shipped_vposer_checkpoint():
 
 @pytest.mark.parametrize('sparse', [False, True])
 def test_demo_four_stage_fit(sparse):
-    """The yaml's four stages from the reference's initial guess.  Trajectories are chaotic w.r.t. rounding (the
-    reference's own float32 and float64 fits end at 36882 and 36490 after 783 / 867 closures), so the assertion is on
-    the quality of the optimum and on the effort, with the two reference runs as the yard-stick."""
+    """The yaml's four stages from the reference's initial guess.  Which optimum is reached is chaotic in the last bits
+    on this ill-conditioned problem: the reference's own float32 / float64 fits end at 36882 / 36490 and its float32
+    fits from six starts perturbed by 1e-6 (relative) spread over 34257 ... 38929 after 580 ... 605 closures (all in the
+    golden file).  The assertion is on the quality of the optimum and on the effort, with that spread as yard-stick."""
     g, vpw, model, cams, stages = _load()
     eng = make_engine(model, vpw)
     eng.set_problems(cams, g['gt_xy'][None], g['conf'][None])
@@ -70,10 +71,10 @@ def test_demo_four_stage_fit(sparse):
     xf, st = eng.fit(x0, st_w)
     final = float(st['final_loss'].cpu().numpy()[0])
     ncl = int(st['n_closure'].cpu().numpy()[0])
-    ref_hi = max(float(g['fit_final32']), float(g['fit_final64']))
-    ref_n = (int(g['fit_ncl32'].sum()), int(g['fit_ncl64'].sum()))
-    assert np.isfinite(final) and final <= 1.05 * ref_hi, (final, ref_hi)
-    assert 0.4 * min(ref_n) <= ncl <= 2.5 * max(ref_n), (ncl, ref_n)
+    ref_hi = max(float(g['fit_final32']), float(g['fit_final64']), float(g['fit_spread32'].max()))
+    ref_n = [int(g['fit_ncl32'].sum()), int(g['fit_ncl64'].sum())] + [int(n) for n in g['fit_spread_ncl32'].sum(1)]
+    assert np.isfinite(final) and final <= 1.02 * ref_hi, (final, ref_hi)
+    assert 0.5 * min(ref_n) <= ncl <= 2.0 * max(ref_n), (ncl, ref_n)
     chk = float(eng.closure(xf, dict(st_w[-1]), want_grad=False)['loss'].cpu().numpy()[0])
     assert chk <= final * (1 + 1e-3)
     eng.close()

@@ -6,7 +6,8 @@ Both runs are float32 programs with different summation orders, so they agree to
 drift apart as the line search amplifies last-bit differences (the reference's own float32 and float64 runs - both in
 the goldens - drift the same way: 1e-7 at the start, 1e-5..1e-4 after ~30 closures, a different branch somewhere
 between closure 35 and 50; on the demo's ill-conditioned start after ~8).  The assertion: over the first outer step
-the device trace stays within TOL(k) of the reference float32 trace, TOL growing geometrically from 3e-6 to 3e-3 - a
+the device trace stays within TOL(k) of the reference float32 trace, TOL growing geometrically from 2e-5 to 3e-3
+(measured: 1e-8 ... 3e-5 on x, up to 1.4e-5 relative on the loss of a far line-search trial; tests/report_traj.py) - a
 wrong branch in the state machine (bracket / zoom / cubic step / history update) shows up as an O(1e-1) jump at the
 closure where it happens."""
 import os
@@ -24,7 +25,7 @@ pytestmark = pytest.mark.gpu
 N_STEP = 35                 # closures of the first outer step (max_eval = 37)
 
 
-def tol(k, n=N_STEP, lo=3e-6, hi=3e-3):
+def tol(k, n=N_STEP, lo=2e-5, hi=3e-3):
     return lo * (hi / lo) ** (min(k, n - 1) / (n - 1))
 
 
