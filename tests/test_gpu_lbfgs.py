@@ -75,12 +75,14 @@ def test_device_fit_against_reference_fit(name, use_vp, sparse):
     xf, st = eng.fit(x0, stages)
     final = st['final_loss'].cpu().numpy().astype(np.float64)
     ncl = st['n_closure'].cpu().numpy()
-    ref_final = g['final']
-    ref_ncl = g['ncl'].sum(1)
-    # trajectories are chaotic w.r.t. rounding: assert same quality, similar effort
+    ref_final = np.maximum(g['final'], g['final32'])            # the reference's float64 and float32 fits
+    ref_lo = np.minimum(g['ncl'].sum(1), g['ncl32'].sum(1))
+    ref_hi = np.maximum(g['ncl'].sum(1), g['ncl32'].sum(1))
+    # trajectories are chaotic w.r.t. rounding after the first outer step (step-for-step agreement
+    # before that: tests/test_gpu_trajectory.py): assert same quality, similar effort
     assert np.all(np.isfinite(final))
-    assert np.all(final <= 1.25 * ref_final + 1.0), (final, ref_final)
-    assert np.all(ncl > 0.25 * ref_ncl) and np.all(ncl < 4 * ref_ncl), (ncl, ref_ncl)
+    assert np.all(final <= 1.05 * ref_final), (final, ref_final)
+    assert np.all(ncl > 0.4 * ref_lo) and np.all(ncl < 2.5 * ref_hi), (ncl, ref_lo, ref_hi)
     # the returned loss is the objective at (about) the returned parameters
     w = dict(stages[-1])
     chk = eng.closure(xf, w, want_grad=False)['loss'].cpu().numpy()
