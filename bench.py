@@ -174,6 +174,7 @@ def main():
     xf = None
     gathered = None
     n_max = 0
+    passes = None
     for _ in range(args.steps):
         xf, st = eng.fit(x0_d, stages)
         if world > 1:
@@ -182,6 +183,7 @@ def main():
         n_iter += int(st['n_iter'].sum().item())
         n_max = int(st['n_closure'].max().item())
         finals = st['final_loss']
+        passes = st.get('passes')
     barrier()
     dt = time.perf_counter() - t0
 
@@ -251,6 +253,7 @@ def main():
             'closures_per_fit_per_frame': round(tot_closure / args.steps / (B * world), 1),
             'closure_rounds_per_fit': n_max,      # = closures of the slowest frame of rank 0's batch (the batch advances in lock-step rounds)
             'final_loss_median': float(np.median(fl)),
+            'vertex_passes_last_fit': passes,
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

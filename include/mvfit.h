@@ -163,6 +163,17 @@ int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint
 int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
 
+/* Counters of the vertex passes of the last mvfit_fit in its asynchronous mode (all zero in the other modes):
+ * out4 = { chunk passes (32 problems x 6890 vertices) run, chunk passes skipped because all their problems had finished, pose operands overwritten before
+ * their pass read them (expected 0), passes that gave up waiting for their operands (expected 0) }. */
+int mvfit_fit_stats(mvfit_ctx* ctx, uint32_t* out4);
+
+/* Test hook for the asynchronous fit: the vertex pass that belongs to closure round `round` (0-based, of every
+ * problem) writes its vertices to verts[B,Nv,3] (dev) instead of the internal buffer; together with mvfit_fit_trace
+ * (the trial points) this lets a test check that the pass of round r really computed the trial point of round r.
+ * verts = NULL switches it off. */
+int mvfit_debug_capture_pass(mvfit_ctx* ctx, int round, float* verts);
+
 /* Optional closure trace of the NEXT mvfit_fit calls (test / debugging hook; the reference equivalent is printing
  * inside fitting_func): for every problem the first max_closures closure evaluations are recorded as
  *   trace[b][k][0:MVFIT_D] = the trial point the closure was evaluated at, trace[b][k][MVFIT_D] = its loss.

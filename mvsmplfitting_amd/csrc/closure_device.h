@@ -1167,4 +1167,56 @@ __device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int t
     if (tid < 3) P.tau[(size_t)b * 4 + tid] = L.opt.x[X_TR + tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Asynchronous fit: hand the vertex-pass operands of THIS trial point to the pass kernel that is already queued on
+// the other CUs (another XCD's L2 is not coherent with ours): 16-byte write-through (sc1) stores - 56 words of
+// split-fp16 coefficients in MFMA A-operand order, 72 words of skinning transforms, 1 word of translation - and
+// later, once every storing wave has drained them (publish_tag), one relaxed agent-scope store of the problem's tag.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const float4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)byte_off, 0, /*aux = sc1*/ 16);
+}
+
+__device__ void publish_pose_async(const ClosureLds& L, const AsyncRing& R, int slot, int b, int tid) {
+    const unsigned Bp = (unsigned)R.Bpad;
+    if (tid < 56) {
+        // word w: block G = w / 4, (hi | lo) = (w / 2) & 1, row half h = w & 1: coefficients p = 16 G + 8 h + t
+        const int G = tid >> 2, hl = (tid >> 1) & 1, h = tid & 1;
+        _Float16 q[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float cv = L.coef[16 * G + 8 * h + t];
+            const _Float16 hi = (_Float16)cv;
+            q[t] = hl ? (_Float16)(cv - (float)hi) : hi;
+        }
+        float4 v;
+        __builtin_memcpy(&v, q, 16);
+        const unsigned chunk = (unsigned)b >> 5;
+        const unsigned word = (((unsigned)slot * (Bp >> 5) + chunk) * (KROWS / 16) + G) * 2 + hl;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.coefH, 0, 0x7fffffff, 0x00020000);
+        store16_sc1(rs, (word * 64 + 32 * h + ((unsigned)b & 31)) * 16, v);
+    } else if (tid >= 64 && tid < 64 + 72) {
+        const int i = tid - 64;
+        const float4 v = reinterpret_cast<const float4*>(&L.pose.A[0][0])[i];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.Amat, 0, 0x7fffffff, 0x00020000);
+        store16_sc1(rs, (((unsigned)slot * Bp + (unsigned)b) * 72 + i) * 16, v);
+    } else if (tid == 192) {
+        const float4 v = make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], 0.f);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.tau, 0, 0x7fffffff, 0x00020000);
+        store16_sc1(rs, ((unsigned)slot * Bp + (unsigned)b) * 16, v);
+    }
+}
+
+// every storing wave has to have drained its sc1 stores before the tag goes out (the wait is free here: it sits
+// behind the adjoint's own loads); ONE lane stores the tag, relaxed at agent scope
+__device__ __forceinline__ void publish_tag(const AsyncRing& R, int slot, int b, unsigned round, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // from the last wave: wave 0 goes straight into the L-BFGS recurrences, whose first global load would otherwise
+    // wait for this store's write-through acknowledgement
+    if (tid == STEP_NT - 64) __hip_atomic_store(R.tag + (size_t)slot * R.Bpad + b, round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace mvfit

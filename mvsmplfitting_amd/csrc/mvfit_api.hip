@@ -27,6 +27,7 @@ namespace mvfit {
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream);
 hipError_t vertex_pass_configure();
+hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
 size_t sdf_entry_bytes();
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // next trial point in L.opt.x.  Returns true when the problem is finished.
 __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
-                          LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0) {
+                          LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
+                          const AsyncRing* ring = nullptr) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
@@ -213,6 +215,11 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     PH_T(0);
     sparse_forward(M, L, from_pass, tid, !have_pose);
     PH_T(2);
+    // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
+    // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
+    const unsigned a_round = ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
+    const int a_slot = ring ? (int)(a_round % (unsigned)ring->nslots) : 0;
+    if (ring) publish_pose_async(L, *ring, a_slot, blockIdx.x, tid);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     PH_T(3);
     if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
@@ -223,6 +230,7 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
         }
     }
     closure_backward(M, L, nviews, W, tid);
+    if (ring) publish_tag(*ring, a_slot, blockIdx.x, a_round, tid);        // the stores have long drained by now
     PH_T(8);
     LbState S;
     LbVecs<float> V;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 // history ring lives in LDS behind the closure workspace.
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
-                                                                 int max_rounds) {
+                                                                 int max_rounds, AsyncRing ring) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
@@ -343,11 +351,19 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         int t = tid;
         asm volatile("" : "+v"(t));
         done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
-                         F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap);
+                         F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
+                         ring.tag ? &ring : nullptr);
         if (done) break;                                  // block-uniform
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
-    if (tid == 0 && done) atomicAdd(F.n_done, 1);
+    if (tid == 0 && done) {
+        const int finished = atomicAdd(F.n_done, 1) + 1;
+        if (ring.tag) {
+            // passes of later rounds have nothing to wait for from this problem; the last problem tells the host
+            __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (finished == (int)gridDim.x) __hip_atomic_store(ring.host_done, finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (!done)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
@@ -486,6 +502,14 @@ struct mvfit_ctx {
     bool has_vposer = false;
     bool has_joints3d = false;
     float *d_gt3d = nullptr, *d_c3d = nullptr;   // staging of mvfit_set_joints3d ([B][17][3], [B][17])
+    // asynchronous full-mode fit: ring of pose operands + the side stream the vertex passes are queued on
+    AsyncRing ring{};
+    hipStream_t pass_stream = nullptr;
+    hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr}, ev_init = nullptr;
+    int* h_async_done = nullptr;       // pinned host word the last finishing problem writes
+    unsigned async_stats[4] = {0, 0, 0, 0};
+    float* capture_verts = nullptr;    // mvfit_debug_capture_pass: the pass of closure round capture_round writes here
+    int capture_round = -1;
     float* trace = nullptr;            // caller's device buffer (mvfit_fit_trace), not owned
     int trace_cap = 0;
     int gmm_M = 0;
@@ -913,6 +937,11 @@ static void free_problem_buffers(mvfit_ctx* c) {
                   c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
                   c->d_sdf_adj, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
+    {
+        void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats};
+        for (void* q : rp) if (q) hipFree(q);
+        c->ring = AsyncRing{};
+    }
     c->B = c->V = c->Bpad = 0;          // nothing is allocated: a failed re-allocation cannot leave a stale shape behind
     c->d_gt3d = c->d_c3d = nullptr;
     c->d_camR = c->d_camt = c->d_camf = c->d_camc = c->d_gt = c->d_wc = nullptr;
@@ -932,6 +961,10 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     for (void* p : c->allocs) if (p) hipFree(p);
     if (c->h_done) hipHostFree(c->h_done);
     for (hipEvent_t e : c->ev_done) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_batch) if (e) hipEventDestroy(e);
+    if (c->ev_init) hipEventDestroy(c->ev_init);
+    if (c->pass_stream) hipStreamDestroy(c->pass_stream);
+    if (c->h_async_done) hipHostFree(c->h_async_done);
     for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_step) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -1209,6 +1242,125 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     return MVFIT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Asynchronous full-mode fit (default when no SDF term is active and the batch leaves CUs for the passes).
+//
+// The objective reads 69 of the 6890 vertices and the optimiser kernel evaluates those itself (sparse_forward: the
+// same arithmetic as the pass on the selected vertices), so the 6890-vertex LBS pass of a trial point is not on the
+// optimiser's critical path - but every closure still gets its full pass, like the reference's return_verts=True:
+//   ctx stream   ONE fit_persistent_kernel launch (one workgroup per problem, L-BFGS history in LDS) runs the whole
+//                staged fit; in closure round r it publishes the pose operands of the trial point into ring slot
+//                r % kRingSlots (write-through stores + a per-problem tag);
+//   pass stream  one lbs_vertex_pass launch per closure round, queued ahead by the host in batches of kPassBatch;
+//                the pass of round r waits (bounded spin on the tags of its 32 problems) until the optimiser has
+//                published round r, then computes all 6890 vertices of those trial points on the CUs the optimiser
+//                does not occupy - concurrently with the optimiser's own work on closure r.
+// Nothing the optimiser does waits on a pass (one-directional hand-off: no deadlock; a pass that times out just runs
+// on whatever the slot holds).  Passes whose 32 problems have all finished return at once.  stats: passes run /
+// skipped / operands overwritten before their pass could read them (ring too short for the drift between problems;
+// expected 0) / timed out (expected 0).
+// Measured alternatives on configs[1]: chaining pass -> step per round costs pass + step (37 us per round, 766 k
+// closures/s); forking the two inside one hipGraph round overlaps them but the cross-queue join costs ~12 us per round
+// (632 k); windows of 24 rounds of the persistent kernel followed by their 24 passes lose the lock-step at every
+// window end (947 k).
+// ---------------------------------------------------------------------------------------------------------
+static const int kRingSlots = 128;
+static const int kPassBatch = 24;
+static const int kAsyncMaxB = 160;        // one CU per problem for the optimiser: leave >= 96 CUs to the passes
+
+static int ensure_async(mvfit_ctx* c) {
+    if (!c->pass_stream) {
+        HIP_OK(c, hipStreamCreateWithFlags(&c->pass_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->ev_batch) HIP_OK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_OK(c, hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
+        HIP_OK(c, hipHostMalloc(&c->h_async_done, 64));
+    }
+    if (c->ring.tag) return MVFIT_OK;
+    AsyncRing& R = c->ring;
+    const size_t Bp = (size_t)c->Bpad;
+    R.nslots = kRingSlots; R.Bpad = c->Bpad;
+    HIP_OK(c, hipMalloc(&R.coefH, kRingSlots * Bp * KROWS * 4));
+    HIP_OK(c, hipMalloc(&R.Amat, kRingSlots * Bp * 288 * 4));
+    HIP_OK(c, hipMalloc(&R.tau, kRingSlots * Bp * 4 * 4));
+    HIP_OK(c, hipMalloc(&R.tag, kRingSlots * Bp * 4));
+    HIP_OK(c, hipMalloc(&R.done_round, Bp * 4));
+    HIP_OK(c, hipMalloc(&R.stats, 4 * 4));
+    HIP_OK(c, hipMemset(R.coefH, 0, kRingSlots * Bp * KROWS * 4));
+    HIP_OK(c, hipMemset(R.Amat, 0, kRingSlots * Bp * 288 * 4));
+    HIP_OK(c, hipMemset(R.tau, 0, kRingSlots * Bp * 4 * 4));
+    void* dp = nullptr;
+    HIP_OK(c, hipHostGetDevicePointer(&dp, c->h_async_done, 0));
+    R.host_done = reinterpret_cast<int*>(dp);
+    return MVFIT_OK;
+}
+
+static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out) {
+    int rc = ensure_async(c);
+    if (rc) return rc;
+    const int B = c->B;
+    const AsyncRing& R = c->ring;
+    volatile int* h_done = c->h_async_done;
+    *h_done = 0;
+    // polled words: re-initialised every call
+    HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * c->Bpad * 4, c->stream));
+    HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
+    HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
+    HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
+    HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
+    hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
+                       (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R);
+    HIP_OK(c, hipGetLastError());
+    // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
+    int k = 0;
+    static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
+    for (;; ++k) {
+        for (int i = 0; i < kPassBatch && !dbg_nopass; ++i) {
+            const unsigned r = (unsigned)(k * kPassBatch + i);
+            const int slot = (int)(r % (unsigned)kRingSlots);
+            DevPose P = c->P;                                          // side outputs / unused fields as in the chained mode
+            P.coefH = R.coefH + (size_t)slot * c->Bpad * (KROWS / 4);
+            P.coefT = nullptr;
+            P.Amat = R.Amat + (size_t)slot * c->Bpad * 288;
+            P.tau = R.tau + (size_t)slot * c->Bpad * 4;
+            P.tag = R.tag + (size_t)slot * c->Bpad;
+            P.done_round = R.done_round;
+            P.stats = R.stats;
+            P.round = r;
+            P.pad_ = 0;
+            float* vout = c->d_verts;
+            if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
+            hipError_t e = launch_pass_gate(P, B, c->pass_stream);
+            if (e == hipSuccess) e = launch_vertex_pass(c->M, P, B, vout, c->ksplit, c->pass_stream);
+            if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
+        }
+        HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
+        if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
+        if (*h_done >= B) break;
+        if ((k + 1) * kPassBatch >= cap) break;
+    }
+    HIP_OK(c, hipStreamSynchronize(c->stream));                        // the optimiser kernel (all problems, or the round cap)
+    // the ctx stream continues behind the last passes (nothing of the fit's result depends on them: ordering only)
+    HIP_OK(c, hipStreamWaitEvent(c->stream, c->ev_batch[k & 3], 0));
+    HIP_OK(c, hipMemcpyAsync(c->async_stats, R.stats, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    *seen_out = c->h_done[0];
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_debug_capture_pass(mvfit_ctx* c, int round, float* verts) {
+    if (!c) return MVFIT_E_ARG;
+    c->capture_round = verts ? round : -1;
+    c->capture_verts = verts;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_fit_stats(mvfit_ctx* c, uint32_t* out4) {
+    if (!c || !out4) return MVFIT_E_ARG;
+    for (int i = 0; i < 4; ++i) out4[i] = c->async_stats[i];
+    return MVFIT_OK;
+}
+
 extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfgs_opts* o, float* params,
                          float* final_loss, int32_t* n_closure, int32_t* n_iter) {
     if (!c || !sw || !o || !params) return MVFIT_E_ARG;
@@ -1238,23 +1390,33 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     if (rc) return rc;
     // the interpenetration term reads every vertex: it forces the (vertex pass, step) round structure
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
+    // MVFIT_ROUND_MODE=serial keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
+    const char* rmode = getenv("MVFIT_ROUND_MODE");
+    const bool async = !sparse && !any_sdf && !c->profile && c->M.bs_h2 != nullptr && c->B <= kAsyncMaxB &&
+                       !(rmode && !strcmp(rmode, "serial"));
+    for (unsigned& v : c->async_stats) v = 0;
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
     HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
                        (const float*)params,
-                       sw[0].flags, sparse ? 0 : 1);
+                       sw[0].flags, (sparse || async) ? 0 : 1);
     HIP_OK(c, hipGetLastError());
     int* h_done = c->h_done;
     *h_done = 0;
     int rounds = 0;
     const int cap = o->max_rounds > 0 ? o->max_rounds : (o->num_stages * o->maxiters * (O.max_eval + 30) + 8);
-    if (sparse) {
+    if (async) {
+        int seen = 0;
+        rc = fit_async(c, SW, O, cap, &seen);
+        if (rc) return rc;
+        *h_done = seen;
+    } else if (sparse) {
         while (rounds < cap) {
             const int chunk = std::min(cap - rounds, 1 << 20);
             hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
                                (const ObsBlock*)c->d_obs, c->V, SW, O, c->P,
-                               c->F, chunk);
+                               c->F, chunk, AsyncRing{});
             HIP_OK(c, hipGetLastError());
             rounds += chunk;
             HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));

@@ -148,6 +148,27 @@ struct DevPose {
     float* tau;
     float* vposed_sel;
     float* xs_sel;
+    // asynchronous fit (mvfit_fit without the SDF term): the operands are a ring slot that the optimiser kernel
+    // publishes while this pass is already queued; tag != nullptr makes the pass wait for them (vertex_pass.hip)
+    const unsigned* tag;         // [Bpad] of this slot: round + 1 of the trial point each problem's operands belong to
+    const unsigned* done_round;  // [Bpad] closures evaluated by a finished problem (0xffffffff while it is running)
+    unsigned* stats;             // [4] passes run / chunk passes skipped (all problems finished) / missed / timed out
+    unsigned round;              // closure round this pass belongs to
+    unsigned pad_;
+};
+
+// Pose-operand ring of the asynchronous fit: slot (r % nslots) holds, per problem, the vertex-pass operands of the
+// trial point of that problem's closure round r.  Producer: fit_persistent_kernel (write-through sc1 stores, then
+// the problem's tag); consumer: the vertex pass launched for round r (polls the tags of its 32 problems).
+struct AsyncRing {
+    float4* coefH;               // [nslots][Bpad / 32][KROWS / 16][hi, lo][64]
+    float* Amat;                 // [nslots][Bpad][288]
+    float* tau;                  // [nslots][Bpad][4]
+    unsigned* tag;               // [nslots][Bpad]
+    unsigned* done_round;        // [Bpad]
+    unsigned* stats;             // [4]
+    int* host_done;              // pinned host word: set to the number of problems by the last one to finish
+    int nslots, Bpad;
 };
 
 // SDF interpenetration term (fitting.py:352-393), per problem

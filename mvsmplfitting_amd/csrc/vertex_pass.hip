@@ -44,6 +44,63 @@ constexpr int VP_GPS = KGROUPS / VP_KSPLIT;      // 7 groups of 4 k-steps per sl
 // SPARSE_W: every vertex has at most 4 non-zero skinning weights (true of the SMPL family): the blend reads
 // 4 (weight, joint) pairs per vertex (M.wsp_w / M.wsp_j, ascending joint index) instead of the dense 24-column
 // row - the same non-zero products in the same order, i.e. bit-identical transforms for 1/6 of the FMAs.
+// Asynchronous fit (mvfit_fit): the operands of a pass are a ring slot the optimiser kernel publishes while the pass
+// is already queued.  The waiting is done by pass_gate_kernel - ONE workgroup queued in front of each pass on the pass
+// stream (216 waiting workgroups per pass cost the optimiser 5 % of its speed; one costs nothing measurable): lane b
+// polls the tag of problem b (relaxed agent-scope loads, s_sleep between polls, bounded by the wall clock - on a
+// timeout the pass simply runs on what the slot holds).  The kernel boundary behind it is the acquire.
+__global__ void pass_gate_kernel(const unsigned* __restrict__ tag, const unsigned* __restrict__ done_round,
+                                 unsigned* __restrict__ stats, unsigned round, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;      // grid covers B; every wave polls its own 64 problems
+    const bool mine = b < B;
+    const unsigned want = round + 1u;
+    unsigned t = want, d = 0u;
+    bool timed_out = false;
+    const long long t_start = wall_clock64();
+    for (;;) {
+        if (mine) {
+            t = __hip_atomic_load(tag + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d = __hip_atomic_load(done_round + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // operands of this round are there (a larger tag: a later round already overwrote the slot) | the problem
+        // finished before this round
+        const bool ok = !mine || t >= want || d <= round;
+        if (__all(ok)) break;
+        if (wall_clock64() - t_start > 300000) { timed_out = true; break; }            // 3 ms at 100 MHz
+        __builtin_amdgcn_s_sleep(32);
+    }
+    const unsigned long long missed = __ballot(mine && d > round && t > want);
+    if ((threadIdx.x & 63) == 0) {
+        if (missed) atomicAdd(stats + 2, (unsigned)__popcll(missed));
+        if (timed_out) atomicAdd(stats + 3, 1u);
+    }
+}
+
+hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream) {
+    hipLaunchKernelGGL(pass_gate_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, P.tag, P.done_round, P.stats, P.round, B);
+    return hipGetLastError();
+}
+
+// In the pass itself: a chunk whose 32 problems had all finished before this round has nothing to compute.
+__device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B, float* smem, int tid) {
+    if (!P.tag) return true;
+    int* verdict = reinterpret_cast<int*>(smem);
+    if (tid < 64) {
+        const int b = b0 + tid;
+        const bool mine = tid < 32 && b < B;
+        const unsigned d = mine ? P.done_round[b] : 0u;
+        const unsigned long long live = __ballot(mine && d > P.round);
+        if (tid == 0) {
+            *verdict = live != 0ull;
+            if (blockIdx.x == 0) atomicAdd(P.stats + (live ? 0 : 1), 1u);      // chunk passes run / skipped
+        }
+    }
+    __syncthreads();
+    const bool run = *verdict != 0;
+    __syncthreads();                                   // smem[0] is reused by the staging below
+    return run;
+}
+
 template <bool SPARSE_W>
 __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
                                                                 float* __restrict__ verts) {
@@ -62,6 +119,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int tile = blockIdx.x;
     const int chunk = blockIdx.y;
     const int b0 = chunk * 32;
+    if (!pass_chunk_live(P, b0, B, smem, tid)) return;
     const bool mfma_role = wave < 4;
 #ifdef MVFIT_TIMING
     const long long t_start = clock64();
@@ -296,6 +354,14 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // All eight waves run the skinning blend as in the exact-fp32 kernel; partials meet in LDS in a fixed order.
 // ---------------------------------------------------------------------------------------------------------
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#ifndef VP_NT_LOADS
+#define VP_NT_LOADS 1
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 nt_load16(const float4* p) {
+    return __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)));
+}
 constexpr int VP_NBLK = KROWS / 16;             // 14 blocks of 16 k-steps
 constexpr int VP_BPW = VP_NBLK / 2;             // 7 per contraction wave
 
@@ -316,6 +382,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int tile = blockIdx.x;
     const int chunk = blockIdx.y;
     const int b0 = chunk * 32;
+    if (!pass_chunk_live(P, b0, B, smem, tid)) return;
+    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr;       // uniform
     const bool mfma_role = wave < 6;
     const int kc_w = wave % 3, kh_w = wave / 3;
 #ifdef MVFIT_TIMING
@@ -336,7 +404,13 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int g = 0; g < VP_BPW; ++g) { ah[g] = ca[(2 * g) * 64]; al[g] = ca[(2 * g + 1) * 64]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < VP_BPW; ++g) { bh[g] = cb[(2 * g) * 64]; bl[g] = cb[(2 * g + 1) * 64]; }
+        // asynchronous fit: the optimiser kernel runs on the other CUs of this XCD and lives on its L2-resident working
+        // set (objective basis rows, Gram matrices, VPoser weights); the basis stream (each element used once per
+        // launch) and the vertex stores are then issued non-temporal so that they do not push it out
+        for (int g = 0; g < VP_BPW; ++g) {
+            bh[g] = stream_nt ? nt_load16(&cb[(2 * g) * 64]) : cb[(2 * g) * 64];
+            bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     float* Wt_w = Wt_l + (wave & 3) * NJ * 32;
@@ -473,13 +547,15 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
                 o.x += tau_l[b * 4 + k0];
                 o.y += tau_l[b * 4 + k1];
-                if (2 * q + 1 < nvalid) *reinterpret_cast<float2*>(dst) = o;
-                else if (2 * q < nvalid) dst[0] = o.x;
+                if (2 * q + 1 < nvalid) {
+                    if (stream_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
+                    else *reinterpret_cast<float2*>(dst) = o;
+                } else if (2 * q < nvalid) dst[0] = o.x;
             }
         }
     }
     // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
-    {
+    if (!P.tag) {
         const int s0 = sel_s0, nsel = sel_s1 - s0;
         for (int i = tid; i < nsel * 96; i += VP_NT) {
             const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;

@@ -208,7 +208,10 @@ class MvFit:
         rc = self._lib.mvfit_fit(self._ctx, arr, C.byref(o), x.data_ptr(), final.data_ptr(),
                                  ncl.data_ptr(), nit.data_ptr())
         self._check(rc)
-        return x, dict(final_loss=final, n_closure=ncl, n_iter=nit)
+        st4 = (C.c_uint32 * 4)()
+        self._check(self._lib.mvfit_fit_stats(self._ctx, st4))
+        return x, dict(final_loss=final, n_closure=ncl, n_iter=nit,
+                       passes=dict(run=int(st4[0]), skipped=int(st4[1]), missed=int(st4[2]), timed_out=int(st4[3])))
 
     def fit_trace(self, max_closures=0):
         """Record (x_trial[118], loss) of the first ``max_closures`` closure calls of every problem during the next
@@ -221,6 +224,17 @@ class MvFit:
         self._trace = torch.full((self.B, int(max_closures), D + 1), float('nan'), device=self.device)
         self._check(self._lib.mvfit_fit_trace(self._ctx, self._trace.data_ptr(), int(max_closures)))
         return self._trace
+
+    def capture_pass(self, round_index=None):
+        """Test hook (include/mvfit.h:mvfit_debug_capture_pass): the vertex pass of closure round ``round_index`` of
+        the next asynchronous fits writes into the returned [B, Nv, 3] tensor.  None switches it off."""
+        if round_index is None:
+            self._check(self._lib.mvfit_debug_capture_pass(self._ctx, -1, None))
+            self._capture = None
+            return None
+        self._capture = torch.full((self.B, self.nv, 3), float('nan'), device=self.device)
+        self._check(self._lib.mvfit_debug_capture_pass(self._ctx, int(round_index), self._capture.data_ptr()))
+        return self._capture
 
     def sdf(self, faces, vertices, grid_size=32):
         """phi[B,G,G,G] of the SDF voxelisation op (include/mvfit.h:mvfit_sdf).  faces: int tensor whose

@@ -1,0 +1,85 @@
+"""GPU: the asynchronous full-mode fit (mvfit_fit without the SDF term): ONE optimiser kernel runs the staged fit and
+publishes the vertex-pass operands of every trial point into a ring; one 6890-vertex LBS pass per closure round runs
+concurrently on the other CUs behind a gate kernel that waits for the round's operands.  Checked here:
+  * the pass that belongs to closure round r computed the vertices of the trial point of round r (capture hook +
+    closure trace), also after the ring wrapped;
+  * every closure got its pass: no operand was overwritten before it was read, no gate timed out;
+  * the optimiser is not perturbed: parameters / loss / closure counts equal the objective-vertices-only fit bit for
+    bit (the same kernel computes both; the passes only consume what it publishes)."""
+import os
+
+import numpy as np
+import pytest
+
+from mvsmplfitting_amd import _lib
+from mvsmplfitting_amd.engine import stage_weights as eng_stage_weights
+from tests.gpu_helpers import make_engine
+from tests.helpers import GOLD, body_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B=5):
+    g = dict(np.load(os.path.join(GOLD, 'fit_l2.npz')))
+    eng = make_engine(body_model(0, 4))
+    cams = (g['cam_R'], g['cam_t'], g['cam_f'], g['cam_c'])
+    rng = np.random.default_rng(3)
+    gt = np.repeat(g['gt_xy'][:1], B, 0) + rng.normal(0, 3.0, (B,) + g['gt_xy'].shape[1:]).astype(np.float32)
+    conf = np.repeat(g['conf'][:1], B, 0)
+    eng.set_problems(cams, gt, conf)
+    x0 = np.zeros((B, 118), np.float32)
+    x0[:, 85] = 1.0
+    x0[:, :86] += rng.normal(0, 0.02, (B, 86)).astype(np.float32)
+    return eng, x0
+
+
+@pytest.mark.parametrize('round_index', [0, 9, 131, 200])
+def test_pass_of_round_r_computes_the_trial_point_of_round_r(round_index):
+    eng, x0 = _setup()
+    stages = eng_stage_weights(1536.0, flags=0)
+    tr = eng.fit_trace(256)
+    cap = eng.capture_pass(round_index)
+    xf, st = eng.fit(x0, stages)
+    eng.capture_pass(None)
+    tr = tr.cpu().numpy()
+    cap = cap.cpu().numpy()
+    ncl = st['n_closure'].cpu().numpy()
+    assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0
+    assert st['passes']['run'] >= ncl.max()                      # one chunk pass per closure round (B <= 32: one chunk)
+    assert ncl.max() > 210, ncl                                  # the ring (128 slots) wrapped before round 131 / 200
+    eng.fit_trace(0)
+    x_r = tr[:, round_index, :118].copy()
+    have = round_index < ncl                                      # problems that evaluated a closure in this round
+    assert have.any()
+    x_r[~have] = x0[~have]
+    verts, _ = eng.vertices(x_r)
+    verts = verts.cpu().numpy()
+    for b in np.flatnonzero(have):
+        # same pass kernel, operands from the fit kernel's single-wave chain vs the stand-alone pointer-jumping chain:
+        # equal to rounding
+        assert np.abs(cap[b] - verts[b]).max() < 2e-6, (b, np.abs(cap[b] - verts[b]).max())
+    eng.close()
+
+
+def test_async_fit_equals_objective_vertices_only_fit():
+    eng, x0 = _setup(B=33)
+    full = eng_stage_weights(1536.0, flags=0)
+    sparse = eng_stage_weights(1536.0, flags=_lib.F_SPARSE_VERTS)
+    xa, sa = eng.fit(x0, full)
+    xs, ss = eng.fit(x0, sparse)
+    assert sa['passes']['run'] > 0 and ss['passes']['run'] == 0
+    assert sa['passes']['missed'] == 0 and sa['passes']['timed_out'] == 0
+    assert np.array_equal(xa.cpu().numpy(), xs.cpu().numpy())
+    assert np.array_equal(sa['final_loss'].cpu().numpy(), ss['final_loss'].cpu().numpy())
+    assert np.array_equal(sa['n_closure'].cpu().numpy(), ss['n_closure'].cpu().numpy())
+    eng.close()
+
+
+def test_chained_round_mode_still_available(monkeypatch):
+    """MVFIT_ROUND_MODE=serial: vertex pass -> step kernel per round (the structure the SDF term needs)."""
+    monkeypatch.setenv('MVFIT_ROUND_MODE', 'serial')
+    eng, x0 = _setup(B=4)
+    xf, st = eng.fit(x0, eng_stage_weights(1536.0, flags=0))
+    assert st['passes'] == dict(run=0, skipped=0, missed=0, timed_out=0)
+    assert np.all(np.isfinite(st['final_loss'].cpu().numpy()))
+    eng.close()

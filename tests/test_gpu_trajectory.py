@@ -73,7 +73,8 @@ def test_fp32_fit_follows_reference_fp32_trajectory(name, use_vp, sparse):
 
 def test_demo_fit_follows_reference_fp32_trajectory():
     """configs[0] (real cameras / keypoints / VPoser checkpoint): the start is ill-conditioned (scale 2, translation
-    10) and the reference's float32 and float64 runs part ways after 8 closures; the first 8 are compared."""
+    10) and the reference's own float32 and float64 runs part ways at closure 7 (5e-2 apart there, 1e-6 before); the
+    first 7 closures are compared."""
     g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
     vpw = {k: v for k, v in np.load(os.path.join(GOLD, 'vposer_poser_epoch091_decoder.npz')).items() if k != 'source'}
     eng = make_engine(body_model(), vpw)
@@ -85,7 +86,7 @@ def test_demo_fit_follows_reference_fp32_trajectory():
     eng.fit(to118(g['x0'], True)[None].astype(np.float32), stages)
     tr = tr.cpu().numpy().astype(np.float64)[0]
     eng.close()
-    worst, rows = _compare(tr, g['fit_trace32'], g['fit_trace64'], True, 8)
+    worst, rows = _compare(tr, g['fit_trace32'], g['fit_trace64'], True, 7)
     # x here is O(10) (translation): scale the absolute tolerance accordingly
-    worst = max(max(r[1] / (10 * tol(r[0], 8)), r[2] / tol(r[0], 8)) for r in rows)
-    assert worst <= 1.0, rows
+    worst = max(max(r[1] / (10 * tol(r[0], 7)), r[2] / tol(r[0], 7)) for r in rows)
+    assert worst <= 1.0, [(r[0], float('%.2g' % r[1]), float('%.2g' % r[2]), float('%.2g' % r[3])) for r in rows]
