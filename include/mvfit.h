@@ -224,6 +224,9 @@ int mvfit_profile_read(mvfit_ctx* ctx, double* vertex_pass_ms_avg, int* launches
  * inside ONE hipEvent pair on the ctx stream; *avg_ms = elapsed / launches.  A pair around a single launch
  * (mvfit_profile_read) contains the markers' own few microseconds; this amortises them. */
 int mvfit_profile_vertex_pass(mvfit_ctx* ctx, int launches, double* avg_ms);
+/* flavour 0: as above; 1: the pass exactly as the asynchronous fit launches it (operands from its ring, non-temporal
+ * basis stream and vertex stores, no side outputs) - needs a preceding asynchronous mvfit_fit on this batch. */
+int mvfit_profile_vertex_pass_ex(mvfit_ctx* ctx, int launches, int flavour, double* avg_ms);
 
 /* Known-answer test entry for the device L-BFGS state machine (same template as production,
  * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.

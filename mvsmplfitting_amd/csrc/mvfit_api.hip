@@ -25,7 +25,7 @@
 namespace mvfit {
 
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
-                              hipStream_t stream);
+                              hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t vertex_pass_configure();
 hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
@@ -1330,7 +1330,12 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             float* vout = c->d_verts;
             if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
             hipError_t e = launch_pass_gate(P, B, c->pass_stream);
-            if (e == hipSuccess) e = launch_vertex_pass(c->M, P, B, vout, c->ksplit, c->pass_stream);
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (c->profile && c->ev_vp.size() < 4096) {            // mvfit_profile: the dispatch's own begin / end stamps
+                hipEventCreate(&ea); hipEventCreate(&eb);
+                c->ev_vp.emplace_back(ea, eb);
+            }
+            if (e == hipSuccess) e = launch_vertex_pass(c->M, P, B, vout, c->ksplit, c->pass_stream, ea, eb);
             if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
         }
         HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
@@ -1392,7 +1397,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
     // MVFIT_ROUND_MODE=serial keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
     const char* rmode = getenv("MVFIT_ROUND_MODE");
-    const bool async = !sparse && !any_sdf && !c->profile && c->M.bs_h2 != nullptr && c->B <= kAsyncMaxB &&
+    const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && c->B <= kAsyncMaxB &&
                        !(rmode && !strcmp(rmode, "serial"));
     for (unsigned& v : c->async_stats) v = 0;
     const int B = c->B;
@@ -1530,15 +1535,23 @@ extern "C" int mvfit_profile(mvfit_ctx* c, int enable) {
 // n back-to-back launches of the vertex pass on the pose operands the last closure / fit left behind,
 // bracketed by ONE hipEvent pair on the ctx stream: elapsed / n is the per-launch duration with the event
 // markers' own ~2-4 us amortised away (a pair around a single launch over-reports by about that much).
-extern "C" int mvfit_profile_vertex_pass(mvfit_ctx* c, int launches, double* avg_ms) {
+static int profile_vertex_pass(mvfit_ctx* c, int launches, int flavour, double* avg_ms) {
     if (!c || !avg_ms || launches <= 0) return MVFIT_E_ARG;
     if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
     HIP_OK(c, hipSetDevice(c->device));
+    DevPose P = c->P;
+    if (flavour == 1) {
+        // the pass as the asynchronous fit launches it: operands from ring slot 0 (whatever trial points the last fit
+        // left there), non-temporal basis stream / vertex stores, no side outputs; round 0 is live for every problem
+        if (!c->ring.tag) return fail(c, MVFIT_E_STATE, "no asynchronous fit has run on this batch yet");
+        P.coefH = c->ring.coefH; P.coefT = nullptr; P.Amat = c->ring.Amat; P.tau = c->ring.tau;
+        P.tag = c->ring.tag; P.done_round = c->ring.done_round; P.stats = c->ring.stats; P.round = 0;
+    }
     hipEvent_t a, b;
     HIP_OK(c, hipEventCreate(&a)); HIP_OK(c, hipEventCreate(&b));
-    hipError_t e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, c->stream);      // warm
+    hipError_t e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->ksplit, c->stream);      // warm
     HIP_OK(c, hipEventRecord(a, c->stream));
-    for (int i = 0; i < launches && e == hipSuccess; ++i) e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, c->stream);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->ksplit, c->stream);
     HIP_OK(c, hipEventRecord(b, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
@@ -1547,6 +1560,14 @@ extern "C" int mvfit_profile_vertex_pass(mvfit_ctx* c, int launches, double* avg
     if (e != hipSuccess || e2 != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass timing failed");
     *avg_ms = (double)ms / launches;
     return MVFIT_OK;
+}
+
+extern "C" int mvfit_profile_vertex_pass(mvfit_ctx* c, int launches, double* avg_ms) {
+    return profile_vertex_pass(c, launches, 0, avg_ms);
+}
+
+extern "C" int mvfit_profile_vertex_pass_ex(mvfit_ctx* c, int launches, int flavour, double* avg_ms) {
+    return profile_vertex_pass(c, launches, flavour, avg_ms);
 }
 
 static double drain(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, int* n) {

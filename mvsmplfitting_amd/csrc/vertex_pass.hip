@@ -22,6 +22,8 @@
 //   * while the basis streams, all 8 waves compute the skinning transforms T = W . A on the VALU and keep
 //     them in registers; k-slice partials then meet in LDS in a fixed order (deterministic), all waves
 //     apply T and store.
+#include <cstdlib>
+#include <hip/hip_ext.h>
 #include "mvfit_device.h"
 
 namespace mvfit {
@@ -82,9 +84,9 @@ hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream) {
 }
 
 // In the pass itself: a chunk whose 32 problems had all finished before this round has nothing to compute.
-__device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B, float* smem, int tid) {
+__device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B, float* word, int tid) {
     if (!P.tag) return true;
-    int* verdict = reinterpret_cast<int*>(smem);
+    int* verdict = reinterpret_cast<int*>(word);
     if (tid < 64) {
         const int b = b0 + tid;
         const bool mine = tid < 32 && b < B;
@@ -97,7 +99,7 @@ __device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B,
     }
     __syncthreads();
     const bool run = *verdict != 0;
-    __syncthreads();                                   // smem[0] is reused by the staging below
+    __syncthreads();                                   // the word is reused (next chunk / staging)
     return run;
 }
 
@@ -571,8 +573,261 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// More than 32 problems: one workgroup per vertex tile walks ALL 32-problem chunks with the tile's basis held in
+// registers - each basis element is read ONCE per launch whatever the number of problems (the single-chunk kernel
+// above, launched per (tile, chunk), re-reads it per chunk).  Per-chunk operands (coefficients, transforms) arrive as
+// direct global -> LDS loads requested one chunk ahead; no registers are held while they fly.
+// ---------------------------------------------------------------------------------------------------------
+template <bool SPARSE_W>
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_split_loop_kernel(DevModel M, DevPose P, int B,
+                                                                float* __restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A_l = smem;                              // [32][A_STRIDE]
+    float* Wt_l = A_l + 32 * A_STRIDE;              // [4 copies][24][32]
+    float* tau_l = Wt_l + 4 * NJ * 32;              // [2 parities][32][4]
+    float* part = tau_l + 2 * 32 * 4;               // [2 K-halves][3][32][33]
+    float* out_l = part + 2 * 3 * 32 * 33;          // [32 b][96]  skinned positions before "+ transl"
+    float* vps_l = out_l + 32 * 96;                 // [32 b][96]  v_posed (only read for the side outputs)
+    float4* coef_l = reinterpret_cast<float4*>(vps_l + 32 * 96);   // [VP_NBLK][hi, lo][64 lanes] A operands of the chunk
+    float* live_w = reinterpret_cast<float*>(coef_l + VP_NBLK * 2 * 64);   // [4] verdict word of pass_chunk_live
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int nchunks = (B + 31) >> 5;
+    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr;       // uniform
+    const bool mfma_role = wave < 6;
+    const int kc_w = wave % 3, kh_w = wave / 3;
+#ifdef MVFIT_TIMING
+    const long long t_start = clock64();
+#else
+    const long long t_start = 0;
+#endif
+    // (requested now: the side-output loop at the end would otherwise start with a cold dependent load)
+    const int sel_s0 = M.tile_sel_start[tile], sel_s1 = M.tile_sel_start[tile + 1];
+    const int vp2 = tid & 15, bb = tid >> 4;              // wave w blends problems [4 w, 4 w + 4)
+
+    // ---- per-chunk operands: requested one chunk ahead as direct global -> LDS loads (no registers are held while
+    //      they fly: the basis already takes 112 of them) ----
+    auto load_operands = [&](int chunk, float* tau_dst) {     // every wave requests its share
+        const float4* csrc = P.coefH + (size_t)chunk * VP_NBLK * 2 * 64 + lane;                 // 28 x 1 KiB
+        for (int i = wave; i < VP_NBLK * 2; i += VP_NT / 64)
+            __builtin_amdgcn_global_load_lds(csrc + i * 64, coef_l + i * 64, 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                                            // 4 x (1 KiB + 128 B)
+            const int b = 4 * wave + q;
+            const float4* src = reinterpret_cast<const float4*>(P.Amat + (size_t)(chunk * 32 + b) * 288) + lane;   // Bpad rows exist
+            float* dst = A_l + b * A_STRIDE;
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<float4*>(dst), 16, 0, 0);                   // words 0 .. 63
+            if (lane < 8) __builtin_amdgcn_global_load_lds(src + 64, reinterpret_cast<float4*>(dst + 256), 16, 0, 0);   // words 64 .. 71
+        }
+        if (wave == 7 && lane < 32)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(P.tau + (size_t)chunk * 32 * 4) + lane,
+                                             reinterpret_cast<float4*>(tau_dst), 16, 0, 0);
+    };
+
+    int chunk = blockIdx.y;
+    load_operands(chunk, tau_l);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chunk-invariant operands: the basis (B operands, kept in registers over all chunks of this workgroup:
+    //      each basis element is read ONCE per launch whatever the number of problems), v_template, skinning weights ----
+    float vt_init = 0.f;
+    float4 bh[VP_BPW], bl[VP_BPW];
+    if (mfma_role) {
+        vt_init = (kh_w == 0) ? M.vt_planes[kc_w * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale : 0.f;
+        const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + kc_w) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+        // asynchronous fit: the optimiser kernel runs on the other CUs of this XCD and lives on its L2-resident working
+        // set (objective basis rows, Gram matrices, VPoser weights); the basis stream (each element used once per
+        // launch) and the vertex stores are then issued non-temporal so that they do not push it out
+#pragma unroll
+        for (int g = 0; g < VP_BPW; ++g) {
+            bh[g] = stream_nt ? nt_load16(&cb[(2 * g) * 64]) : cb[(2 * g) * 64];
+            bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* Wt_w = Wt_l + (wave & 3) * NJ * 32;
+    // 4-pair skinning table of the tile's 32 vertices: kept in LDS (the Wt_l area is free in this variant), read at
+    // the blend - 16 registers less to hold across the chunk loop next to the 112 of the basis
+    float4* sw_l = reinterpret_cast<float4*>(Wt_l);
+    int4* sj_l = reinterpret_cast<int4*>(Wt_l + 32 * 4);
+    {
+        const float4* wsrc = reinterpret_cast<const float4*>(M.wt_tiles + (size_t)tile * NJ * 32);
+        if (SPARSE_W) {
+            if (tid < 32) sw_l[tid] = M.wsp_w[(size_t)tile * TILE_V + tid];
+            else if (tid < 64) sj_l[tid - 32] = M.wsp_j[(size_t)tile * TILE_V + tid - 32];
+        } else {
+            const float4 w40 = wsrc[lane], w41 = wsrc[lane + 64], w42 = wsrc[lane + 128];
+            reinterpret_cast<float4*>(Wt_w)[lane] = w40;
+            reinterpret_cast<float4*>(Wt_w)[lane + 64] = w41;
+            reinterpret_cast<float4*>(Wt_w)[lane + 128] = w42;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const float inv_scale = 1.0f / M.bs_scale;        // power of two: exact
+    const int vbase = tile * TILE_V;
+    const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
+
+    for (int it = 0; chunk < nchunks; ++it) {
+        const int b0 = chunk * 32;
+        const int next = chunk + (int)gridDim.y;
+        float* tau_c = tau_l + (it & 1) * 32 * 4;
+        float* tau_n = tau_l + ((it + 1) & 1) * 32 * 4;
+        if (!pass_chunk_live(P, b0, B, live_w, tid)) {            // uniform; all its problems finished earlier
+            if (next < nchunks) load_operands(next, tau_n);
+            chunk = next;
+            continue;
+        }
+        // ---- this chunk's operands have been requested one chunk ago: wait for this wave's share, then the barrier
+        //      makes every wave's share (the coefficients are staged by all of them) visible ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        VP_T(1, t_start);
+        // ---- skinning blend (lbs.py:209-213), all waves ----
+        float tr[3][2][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+        if (SPARSE_W) {
+            const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i) __builtin_amdgcn_sched_barrier(0);     // 12 transform rows in flight at a time, not 24 (registers)
+                const float4 spw = sw_l[2 * vp2 + i];
+                const int4 spj = sj_l[2 * vp2 + i];
+                const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
+                const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
+                        tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
+                        tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
+                        tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
+                        tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
+                    }
+            }
+        } else {
+            const float* arow = A_l + bb * A_STRIDE;
+#pragma unroll 4
+            for (int j = 0; j < NJ; ++j) {
+                const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
+                const float wv[2] = {w.x, w.y};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
+                        tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
+                        tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
+                        tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
+                    }
+                }
+            }
+        }
+        VP_T(2, t_start);
+        __builtin_amdgcn_sched_barrier(0);                    // the blend's LDS reads stay above, the A operands below
+        if (mfma_role) {
+            // ---- blendshape contraction: plane kc_w, K-half kh_w; small products first.  The A operands come from
+            //      LDS two blocks ahead of their MFMAs (not all 14 words at once: the basis holds 112 registers) ----
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = vt_init;
+            const float4* cl = coef_l + (kh_w * VP_BPW * 2) * 64 + lane;
+            float4 ah[VP_BPW], al[VP_BPW];
+#pragma unroll
+            for (int g = 0; g < VP_BPW; ++g) { ah[g] = cl[(2 * g) * 64]; al[g] = cl[(2 * g + 1) * 64]; }
+#pragma unroll
+            for (int g = 0; g < VP_BPW; ++g) {
+                const half8 Ah = __builtin_bit_cast(half8, ah[g]), Al = __builtin_bit_cast(half8, al[g]);
+                const half8 Bh = __builtin_bit_cast(half8, bh[g]), Bl = __builtin_bit_cast(half8, bl[g]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
+            }
+            // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            float* pdst = part + ((kh_w * 3 + kc_w) * 32) * 33 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                pdst[b * 33] = acc[r];
+            }
+        }
+        VP_T(3, t_start);
+        __syncthreads();
+        // every MFMA wave has consumed this chunk's coefficients, this wave has blended its transforms: request the
+        // next chunk's operands now - they fly under the epilogue and the stores of this one
+        if (next < nchunks) load_operands(next, tau_n);
+
+        // ---- all waves: combine the two K-halves (fixed order), undo the basis scale, apply T ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = 2 * vp2 + i;
+            float vp[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                vp[k] = (part[((0 * 3 + k) * 32 + bb) * 33 + v] + part[((1 * 3 + k) * 32 + bb) * 33 + v]) * inv_scale;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+                vps_l[bb * 96 + v * 3 + k] = vp[k];
+            }
+        }
+        VP_T(4, t_start);
+        __syncthreads();
+        VP_T(5, t_start);
+
+        // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
+        {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
+                const int b = i / 48, q = i - b * 48;
+                if (b0 + b < B) {
+                    float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
+                    const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
+                    float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+                    o.x += tau_c[b * 4 + k0];
+                    o.y += tau_c[b * 4 + k1];
+                    if (2 * q + 1 < nvalid) {
+                        if (stream_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
+                        else *reinterpret_cast<float2*>(dst) = o;
+                    } else if (2 * q < nvalid) dst[0] = o.x;
+                }
+            }
+        }
+        // ---- side outputs for the vertices the objective reads (consumed by the step kernel of the chained mode) ----
+        if (!P.tag) {
+            const int s0 = sel_s0, nsel = sel_s1 - s0;
+            for (int i = tid; i < nsel * 96; i += VP_NT) {
+                const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
+                if (b0 + b >= B) continue;
+                const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
+                P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
+                P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
+            }
+        }
+        VP_T(6, t_start);
+        // No barrier at the loop end: the next iteration starts with one (behind this wave's operand wait).
+        chunk = next;
+    }
+#ifdef MVFIT_TIMING
+    if (blockIdx.x == 5 && threadIdx.x == 0) g_vp[7] += 1;
+#endif
+}
+
 size_t vertex_pass_split_lds_bytes() {
     return sizeof(float) * (size_t)(32 * A_STRIDE + 4 * NJ * 32 + 32 * 4 + 2 * 3 * 32 * 33 + 2 * 32 * 96);
+}
+size_t vertex_pass_split_loop_lds_bytes() {
+    return sizeof(float) * (size_t)(32 * A_STRIDE + 4 * NJ * 32 + 2 * 32 * 4 + 2 * 3 * 32 * 33 + 2 * 32 * 96 + VP_NBLK * 2 * 64 * 4 + 4);
 }
 
 size_t vertex_pass_lds_bytes() {
@@ -580,17 +835,36 @@ size_t vertex_pass_lds_bytes() {
                                     VP_KSPLIT * 3 * 32 * 33 + 2 * 32 * 96);
 }
 
+// ev_start / ev_stop (both or neither): the runtime stamps them with the dispatch's own begin / end (hipExtLaunchKernelGGL)
+// - the kernel's duration without the few microseconds a pair of hipEventRecord markers around a launch would add.
+template <typename K>
+static void vp_launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+                      const DevModel& M, const DevPose& P, int B, float* verts) {
+    if (ev_start) hipExtLaunchKernelGGL(kernel, grid, dim3(VP_NT), lds, stream, ev_start, ev_stop, 0, M, P, B, verts);
+    else hipLaunchKernelGGL(kernel, grid, dim3(VP_NT), lds, stream, M, P, B, verts);
+}
+
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
-                              hipStream_t stream) {
+                              hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     (void)ksplit;
     dim3 grid(M.ntiles, (B + 31) / 32);
     if (M.bs_h2) {        // split-fp16 contraction (default); MVFIT_EXACT_FP32=1 at mvfit_create keeps the fp32 MFMA chain
-        if (M.wsp_w) hipLaunchKernelGGL(lbs_vertex_pass_split_kernel<true>, grid, dim3(VP_NT), vertex_pass_split_lds_bytes(), stream, M, P, B, verts);
-        else hipLaunchKernelGGL(lbs_vertex_pass_split_kernel<false>, grid, dim3(VP_NT), vertex_pass_split_lds_bytes(), stream, M, P, B, verts);
+        // more than one 32-problem chunk: one workgroup per vertex tile walks ALL chunks with the tile's basis held in
+        // registers - the basis is read once per launch whatever the number of problems (MVFIT_VP_CHUNK_GRID=1: one
+        // workgroup per (tile, chunk) as for a single chunk)
+        static const bool chunk_grid = getenv("MVFIT_VP_CHUNK_GRID") != nullptr;
+        if (grid.y == 1 || chunk_grid) {
+            if (M.wsp_w) vp_launch(lbs_vertex_pass_split_kernel<true>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+            else vp_launch(lbs_vertex_pass_split_kernel<false>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+        } else {
+            const dim3 g1(M.ntiles, 1);
+            if (M.wsp_w) vp_launch(lbs_vertex_pass_split_loop_kernel<true>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+            else vp_launch(lbs_vertex_pass_split_loop_kernel<false>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+        }
         return hipGetLastError();
     }
-    if (M.wsp_w) hipLaunchKernelGGL(lbs_vertex_pass_kernel<true>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
-    else hipLaunchKernelGGL(lbs_vertex_pass_kernel<false>, grid, dim3(VP_NT), vertex_pass_lds_bytes(), stream, M, P, B, verts);
+    if (M.wsp_w) vp_launch(lbs_vertex_pass_kernel<true>, grid, vertex_pass_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+    else vp_launch(lbs_vertex_pass_kernel<false>, grid, vertex_pass_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
     return hipGetLastError();
 }
 
@@ -604,8 +878,14 @@ hipError_t vertex_pass_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
 }
 
 }  // namespace mvfit

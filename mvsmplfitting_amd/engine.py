@@ -291,10 +291,11 @@ class MvFit:
     def profile(self, enable=True):
         self._check(self._lib.mvfit_profile(self._ctx, 1 if enable else 0))
 
-    def profile_vertex_pass_ms(self, launches=64):
-        """Average duration (ms) of `launches` back-to-back vertex-pass launches inside one hipEvent pair."""
+    def profile_vertex_pass_ms(self, launches=64, as_in_async_fit=False):
+        """Average duration (ms) of `launches` back-to-back vertex-pass launches inside one hipEvent pair;
+        ``as_in_async_fit``: the launch flavour of the asynchronous fit (include/mvfit.h)."""
         a = C.c_double()
-        self._check(self._lib.mvfit_profile_vertex_pass(self._ctx, int(launches), C.byref(a)))
+        self._check(self._lib.mvfit_profile_vertex_pass_ex(self._ctx, int(launches), 1 if as_in_async_fit else 0, C.byref(a)))
         return a.value
 
     def profile_read(self):

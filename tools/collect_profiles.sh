@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the MI355X box (gpurun): kernel stats of the bench command + PMC traffic of the vertex pass at 32 / 128
+# problems.  Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>/...  (copy the summaries into profiles/)
+set -u
+TAG=${1:-r2}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+for B in 32 128; do
+  for CN in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $OUT/pmc_b${B}_$CN -o p -- python $R/tools/pmc_vertex_pass.py drive $B 40 > /dev/null 2> $OUT/pmc_b${B}_$CN.log
+  done
+done
+cd $R
+python tools/pmc_vertex_pass.py parse $OUT/pmc.json B32=$OUT/pmc_b32_FETCH_SIZE B32=$OUT/pmc_b32_WRITE_SIZE B128=$OUT/pmc_b128_FETCH_SIZE B128=$OUT/pmc_b128_WRITE_SIZE
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+head -12 $OUT/kernel_stats.csv

@@ -1,0 +1,75 @@
+"""HBM-side traffic of the LBS vertex pass from rocprofv3 PMC counters -> profiles/<tag>_pmc.json (read by bench.py).
+
+Two roles:
+  * `python tools/pmc_vertex_pass.py drive B [launches]`  - the workload the counters are collected on: `launches`
+    vertex passes over B problems (mvfit_vertices), nothing else of interest;
+  * `python tools/pmc_vertex_pass.py parse <out.json> <name>=<dir> ...` - reads the *_counter_collection.csv files of
+    the passes (separate rocprofv3 runs per counter, as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
+    WRITE_SIZE do not fit one pass) and writes per kernel: launches, FETCH_SIZE / WRITE_SIZE averages (KiB),
+    traffic = 2 x FETCH_SIZE (gfx950 reports half of a 16-byte-per-lane stream) + WRITE_SIZE.
+
+On the GPU box (see tools/collect_profiles.sh):
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/b32_fetch -o p -- python tools/pmc_vertex_pass.py drive 32
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def drive(B, launches=40):
+    import numpy as np
+    import torch
+    from mvsmplfitting_amd import synthetic as syn
+    from mvsmplfitting_amd.engine import MvFit
+    eng = MvFit(syn.make_body_model(0, skin_topk=4))
+    cams = syn.make_camera_ring(8)
+    rng = np.random.default_rng(B)
+    x = np.zeros((B, 118), np.float32)
+    x[:, :86] = rng.normal(0, 0.2, (B, 86))
+    x[:, 85] = 1.0
+    eng.set_problems(cams, np.zeros((B, 8, 17, 2), np.float32), np.ones((B, 8, 17), np.float32))
+    for _ in range(launches):
+        eng.vertices(x)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def parse(out_json, specs):
+    res = {}
+    for spec in specs:
+        name, d = spec.split('=', 1)
+        acc = {}
+        for fn in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            with open(fn) as f:
+                for row in csv.DictReader(f):
+                    k = row['Kernel_Name']
+                    if 'vertex_pass' not in k:
+                        continue
+                    key = (k.split('(')[0].replace('void ', ''), row['Counter_Name'])
+                    a = acc.setdefault(key, [0, 0.0])
+                    a[0] += 1
+                    a[1] += float(row['Counter_Value'])
+        for (k, cn), (n, tot) in acc.items():
+            e = res.setdefault(name, {}).setdefault(k, {})
+            e[cn + '_KiB_avg'] = tot / n
+            e['launches_' + cn] = n
+    for name, ks in res.items():
+        for k, e in ks.items():
+            if 'FETCH_SIZE_KiB_avg' in e and 'WRITE_SIZE_KiB_avg' in e:
+                e['traffic_bytes'] = (2.0 * e['FETCH_SIZE_KiB_avg'] + e['WRITE_SIZE_KiB_avg']) * 1024.0
+                e['traffic_note'] = '2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes'
+    with open(out_json, 'w') as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'drive':
+        drive(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 40)
+    else:
+        parse(sys.argv[2], sys.argv[3:])
