@@ -214,6 +214,12 @@ int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 int mvfit_triangulate(mvfit_ctx* ctx, int B, int V, const float* keypoints, const double* intris, const double* extris,
                       double* joints3d);
 
+/* Per-view projection of point sets with the cameras of mvfit_set_problems: the reference's visualisation path
+ * cam(verts) / cam(joints) per view (code/utils/utils.py:581-583,603-607; PerspectiveCamera.forward code/camera.py:93-117).
+ *   points[B,num_points,3] dev (e.g. the vertices of mvfit_vertices, num_points = 6890) ->
+ *   uv[B,V,num_points,2] dev, float pixels (the reference truncates to int32 on the host afterwards). */
+int mvfit_project_points(mvfit_ctx* ctx, const float* points, int num_points, float* uv);
+
 /* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
  * the last call, measured with hipEvents on the ctx stream; *launches = number measured.
  * Enable with mvfit_profile(ctx, 1) (adds two event records per launch). */

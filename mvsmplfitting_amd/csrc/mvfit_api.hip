@@ -33,6 +33,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
 size_t sdf_entry_bytes();
 hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
                               hipStream_t stream);
+hipError_t launch_project_points(const DevProblems& Q, const float* pts, int N, float* uv, hipStream_t stream);
 hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
                                float* phi, hipStream_t stream);
 
@@ -1523,6 +1524,16 @@ extern "C" int mvfit_triangulate(mvfit_ctx* c, int B, int V, const float* keypoi
     HIP_OK(c, hipSetDevice(c->device));
     hipError_t e = launch_triangulate(keypoints, intris, extris, B, V, NKP, joints3d, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "triangulate launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_project_points(mvfit_ctx* c, const float* points, int num_points, float* uv) {
+    if (!c) return MVFIT_E_ARG;
+    if (!points || !uv || num_points <= 0) return fail(c, MVFIT_E_ARG, "mvfit_project_points: bad argument (num_points=%d)", num_points);
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first (the cameras come from there)");
+    HIP_OK(c, hipSetDevice(c->device));
+    hipError_t e = launch_project_points(c->Q, points, num_points, uv, c->stream);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "projection launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
 

@@ -280,6 +280,16 @@ class MvFit:
         self._check(self._lib.mvfit_triangulate(self._ctx, B, V, kp.data_ptr(), K.data_ptr(), E.data_ptr(), out.data_ptr()))
         return out
 
+    def project(self, points):
+        """uv [B, V, N, 2] = every view's pinhole projection of points [B, N, 3] with the cameras of set_problems
+        (include/mvfit.h:mvfit_project_points; reference cam(verts), utils/utils.py:603-607)."""
+        p = self._dev(points)
+        if p.dim() != 3 or p.shape[0] != self.B or p.shape[2] != 3:
+            raise MvFitError('points must be [B, N, 3] with B = %d' % self.B)
+        uv = torch.empty(self.B, self.V, int(p.shape[1]), 2, device=self.device)
+        self._check(self._lib.mvfit_project_points(self._ctx, p.data_ptr(), int(p.shape[1]), uv.data_ptr()))
+        return uv
+
     def sdf_term_read(self):
         """(samples [B,Nv,4] = phi_v and its local-coordinate gradient, S [B]) of the last evaluated term."""
         smp = torch.empty(self.B, self.nv, 4, device=self.device)

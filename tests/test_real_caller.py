@@ -68,9 +68,13 @@ def _setting_and_data(model, cams, vpw, gt, cf, use_vposer):
     return rp, setting, data
 
 
-def _run(nls, model, cams, vpw, gt, cf, use_vposer, optim_type, n_stages=4):
+def _run(nls, model, cams, vpw, gt, cf, use_vposer, optim_type, n_stages=4, warm_start=None):
     rp, setting, data = _setting_and_data(model, cams, vpw, gt, cf, use_vposer)
     kw = dict(YAML_KW, use_vposer=use_vposer, optim_type=optim_type)
+    if warm_start is not None:            # a later frame of a sequence (main.py:76-79: load_init, seq_start False)
+        rp.set_flat(warm_start)
+        setting['seq_start'] = False
+        kw['is_seq'] = True
     for k in ('data_weights', 'body_pose_prior_weights', 'shape_weights', 'coll_loss_weights'):
         kw[k] = kw[k][:n_stages]
     res = nls.non_linear_solver(setting, data, **kw)
@@ -141,6 +145,29 @@ def test_unmodified_non_linear_solver_runs_on_the_patched_seams(seams, use_vpose
     # trajectory (they differ only through last-bit differences amplified over a few hundred closures)
     for name, res, x in (('lbfgsls on the HIP closure seam', res_ls, x_ls), ('lbfgs_hip', res_hip, x_hip)):
         assert np.isfinite(res['loss'])
+        assert abs(res['loss'] - res_ref['loss']) <= 1e-6 * abs(res_ref['loss']), (name, res['loss'], res_ref['loss'])
+        assert np.abs(x - x_ref).max() <= 1e-5, (name, np.abs(x - x_ref).max())
+
+
+def test_sequence_mode_of_the_unmodified_caller(seams):
+    """is_seq (main.py:76-79, init_guess.py:137-166, non_linear_solver.py:158-162): a later frame
+    of a sequence starts from the previous frame's result, the caller skips the first two stages and scales the third
+    stage's pose weight by 0.15.  All of that is the caller's logic - under the patch it drives the device-resident fit
+    with two stages, and the result equals the un-patched reference's."""
+    nls, mf, Stub, ref, patch = seams
+    prob = _problem(False, seed=44)
+    lay, D = cn.param_layout(False)
+    prev = np.random.default_rng(8).normal(0, 0.05, D)      # "previous frame": near the rest pose, scale 1
+    prev[lay['scale'][0]] = 1.0
+    res_ref, x_ref = _run(nls, *prob, False, 'lbfgsls', warm_start=prev)
+    patch()
+    res_hip, x_hip = _run(nls, *prob, False, 'lbfgs_hip', warm_start=prev)
+    fits = [d for k, d in Stub.calls if k == 'fit']
+    assert len(fits) == 2                                                         # stages 0 and 1 were skipped
+    res_ls, x_ls = _run(nls, *prob, False, 'lbfgsls', warm_start=prev)
+    w3 = [d['body_pose_weight'] for k, d in Stub.calls if k == 'closure']
+    assert abs(w3[0] - 57.4 * 0.15) < 1e-6 and abs(w3[-1] - 4.78) < 1e-9          # :162 and the last stage
+    for name, res, x in (('lbfgs_hip', res_hip, x_hip), ('lbfgsls on the HIP closure seam', res_ls, x_ls)):
         assert abs(res['loss'] - res_ref['loss']) <= 1e-6 * abs(res_ref['loss']), (name, res['loss'], res_ref['loss'])
         assert np.abs(x - x_ref).max() <= 1e-5, (name, np.abs(x - x_ref).max())
 
