@@ -214,6 +214,17 @@ int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 int mvfit_triangulate(mvfit_ctx* ctx, int B, int V, const float* keypoints, const double* intris, const double* extris,
                       double* joints3d);
 
+/* Per-frame initial guess, stage 2 (code/utils/init_guess.py:95-106): similarity alignment src -> dst by the
+ * reference's umeyama (code/utils/umeyama.py:16-109, incl. its full-rank formula U diag(d) Vh^T and the two-candidate
+ * choice with the translation of the second candidate) and cv2.Rodrigues of the chosen rotation; batched over B frames
+ * that share the source points (the rest-pose keypoints).  All float64 like the reference's NumPy.
+ *   src[npts,3] dev, dst[B,npts,3] dev (npts = 4: the torso joints 5, 6, 11, 12 with use_torso, or 17) ->
+ *   rot[B,3,3], rvec[B,3] (the model's global_orient), trans[B,3], scale[B] dev.
+ * The signs of the singular-vector pairs - which the reference's formula is sensitive to and LAPACK chooses for it -
+ * are those of the device's Jacobi SVD. */
+int mvfit_umeyama(mvfit_ctx* ctx, int B, int npts, const double* src, const double* dst, int estimate_scale,
+                  double* rot, double* rvec, double* trans, double* scale);
+
 /* Per-view projection of point sets with the cameras of mvfit_set_problems: the reference's visualisation path
  * cam(verts) / cam(joints) per view (code/utils/utils.py:581-583,603-607; PerspectiveCamera.forward code/camera.py:93-117).
  *   points[B,num_points,3] dev (e.g. the vertices of mvfit_vertices, num_points = 6890) ->

@@ -75,4 +75,155 @@ hipError_t launch_triangulate(const float* kps, const double* intris, const doub
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Second stage of the initial guess (code/utils/init_guess.py:95-106): similarity alignment of the rest-pose keypoints
+// to the triangulated ones - the reference's umeyama (code/utils/umeyama.py:16-109) with its two local changes kept
+// as they are (full-rank branch U diag(d) Vh^T, :73; two candidates with the first two rotation columns negated in
+// place and the translation taken from the second one, :84-104) - and cv2.Rodrigues of the chosen rotation.
+// One thread per frame, float64 like the reference's NumPy.  The 3x3 SVD is a one-sided (Hestenes) Jacobi; the SIGNS of
+// the singular-vector pairs are whatever it produces - the reference's are whatever LAPACK produced, its full-rank
+// formula is not invariant under that freedom (tests/test_umeyama.py accepts any of the four patterns).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det3(const double* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// A (row-major 3x3) = U diag(S) Vh, S descending
+__device__ void svd3(const double* A, double* U, double* S, double* Vh) {
+    double W[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) W[i] = A[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < 3; ++r) { al += W[3 * r + p] * W[3 * r + p]; be += W[3 * r + q] * W[3 * r + q]; ga += W[3 * r + p] * W[3 * r + q]; }
+                off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
+                if (fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    const double wp = W[3 * r + p], wq = W[3 * r + q];
+                    W[3 * r + p] = c * wp - sn * wq; W[3 * r + q] = sn * wp + c * wq;
+                    const double vp = V[3 * r + p], vq = V[3 * r + q];
+                    V[3 * r + p] = c * vp - sn * vq; V[3 * r + q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int k = 0; k < 3; ++k) nrm[k] = sqrt(W[k] * W[k] + W[3 + k] * W[3 + k] + W[6 + k] * W[6 + k]);
+    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (nrm[ord[j]] > nrm[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    for (int k = 0; k < 3; ++k) {
+        const int c = ord[k];
+        S[k] = nrm[c];
+        for (int r = 0; r < 3; ++r) { U[3 * r + k] = nrm[c] > 0 ? W[3 * r + c] / nrm[c] : 0.0; Vh[3 * k + r] = V[3 * r + c]; }
+    }
+    // a vanishing singular value leaves its left vector undefined: complete the basis (right-handed)
+    if (S[2] <= S[0] * 1e-14) {
+        if (S[1] <= S[0] * 1e-14) {            // rank <= 1: any unit vector orthogonal to u0
+            const int m = fabs(U[0]) < fabs(U[3]) ? (fabs(U[0]) < fabs(U[6]) ? 0 : 2) : (fabs(U[3]) < fabs(U[6]) ? 1 : 2);
+            double e[3] = {0, 0, 0}; e[m] = 1.0;
+            const double dp = U[0] * e[0] + U[3] * e[1] + U[6] * e[2];
+            double v[3] = {e[0] - dp * U[0], e[1] - dp * U[3], e[2] - dp * U[6]};
+            const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            U[1] = v[0] / nv; U[4] = v[1] / nv; U[7] = v[2] / nv;
+        }
+        U[2] = U[3] * U[7] - U[6] * U[4];
+        U[5] = U[6] * U[1] - U[0] * U[7];
+        U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+// cv2.Rodrigues, matrix -> rotation vector
+__device__ void rotvec3(const double* R, double* rv) {
+    double r[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    const double s = sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+    const double c = fmin(fmax((R[0] + R[4] + R[8] - 1.0) * 0.5, -1.0), 1.0);
+    const double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { rv[0] = rv[1] = rv[2] = 0.0; return; }
+        double x = sqrt(fmax((R[0] + 1) * 0.5, 0.0));
+        double y = sqrt(fmax((R[4] + 1) * 0.5, 0.0)) * (R[1] < 0 ? -1.0 : 1.0);
+        double z = sqrt(fmax((R[8] + 1) * 0.5, 0.0)) * (R[2] < 0 ? -1.0 : 1.0);
+        if (fabs(x) < fabs(y) && fabs(x) < fabs(z) && ((R[5] > 0) != (y * z > 0))) z = -z;
+        const double k = theta / sqrt(x * x + y * y + z * z);
+        rv[0] = x * k; rv[1] = y * k; rv[2] = z * k;
+        return;
+    }
+    const double k = 0.5 / s * theta;
+    rv[0] = r[0] * k; rv[1] = r[1] * k; rv[2] = r[2] * k;
+}
+
+__global__ void umeyama_kernel(const double* __restrict__ src, const double* __restrict__ dst, int B, int npts, int estimate_scale,
+                               double* __restrict__ rot_out, double* __restrict__ rvec_out, double* __restrict__ trans_out,
+                               double* __restrict__ scale_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* D = dst + (size_t)b * npts * 3;
+    double sm[3] = {0, 0, 0}, dm[3] = {0, 0, 0};
+    for (int i = 0; i < npts; ++i) for (int a = 0; a < 3; ++a) { sm[a] += src[3 * i + a]; dm[a] += D[3 * i + a]; }
+    for (int a = 0; a < 3; ++a) { sm[a] /= npts; dm[a] /= npts; }
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, var = 0.0;                   // A = dst_demean^T src_demean / num  (:45)
+    for (int i = 0; i < npts; ++i) {
+        double sd[3], dd[3];
+        for (int a = 0; a < 3; ++a) { sd[a] = src[3 * i + a] - sm[a]; dd[a] = D[3 * i + a] - dm[a]; var += sd[a] * sd[a]; }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] += dd[r] * sd[c];
+    }
+    for (int i = 0; i < 9; ++i) A[i] /= npts;
+    var /= npts;                                                            // src_demean.var(axis=0).sum()
+    double d[3] = {1.0, 1.0, det3(A) < 0 ? -1.0 : 1.0};                     // :48-50
+    double U[9], S[3], Vh[9];
+    svd3(A, U, S, Vh);
+    const double tol = S[0] * 3.0 * 2.220446049250313e-16;                  // np.linalg.matrix_rank
+    const int rank = (S[0] > tol) + (S[1] > tol) + (S[2] > tol);
+    double T[9];
+    const double nanv = nan("");
+    if (rank == 0 || S[0] == 0.0) {
+        for (int i = 0; i < 9; ++i) rot_out[(size_t)b * 9 + i] = nanv;
+        for (int a = 0; a < 3; ++a) { rvec_out[(size_t)b * 3 + a] = nanv; trans_out[(size_t)b * 3 + a] = nanv; }
+        scale_out[b] = nanv;
+        return;
+    }
+    if (rank == 2) {                                                        // :60-68: U diag(.) Vh
+        double e[3] = {1.0, 1.0, 1.0};
+        if (!(det3(U) * det3(Vh) > 0)) e[2] = -1.0;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            T[3 * r + c] = U[3 * r] * e[0] * Vh[c] + U[3 * r + 1] * e[1] * Vh[3 + c] + U[3 * r + 2] * e[2] * Vh[6 + c];
+    } else {                                                                // :73: U diag(d) V.T with V = numpy's Vh
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+            T[3 * r + c] = U[3 * r] * d[0] * Vh[3 * c] + U[3 * r + 1] * d[1] * Vh[3 * c + 1] + U[3 * r + 2] * d[2] * Vh[3 * c + 2];
+    }
+    const double scale = estimate_scale ? (S[0] * d[0] + S[1] * d[1] + S[2] * d[2]) / var : 1.0;      // :78-80
+    double loss[2], R1[9];
+    for (int i = 0; i < 9; ++i) R1[i] = ((i % 3) < 2 ? -T[i] : T[i]);      // second candidate: columns 0, 1 negated (:87)
+    for (int cand = 0; cand < 2; ++cand) {
+        const double* R = cand ? R1 : T;
+        double t[3], acc = 0.0;
+        for (int a = 0; a < 3; ++a) t[a] = dm[a] - scale * (R[3 * a] * sm[0] + R[3 * a + 1] * sm[1] + R[3 * a + 2] * sm[2]);
+        for (int i = 0; i < npts; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const double e = scale * (R[3 * a] * src[3 * i] + R[3 * a + 1] * src[3 * i + 1] + R[3 * a + 2] * src[3 * i + 2]) + t[a] - D[3 * i + a];
+                acc += e * e;
+            }
+        loss[cand] = sqrt(acc);
+    }
+    const double* Rsel = loss[0] > loss[1] ? R1 : T;                       // :105-108
+    for (int i = 0; i < 9; ++i) rot_out[(size_t)b * 9 + i] = Rsel[i];
+    for (int a = 0; a < 3; ++a)                                            // :104: T holds the second candidate by now
+        trans_out[(size_t)b * 3 + a] = dm[a] - scale * (R1[3 * a] * sm[0] + R1[3 * a + 1] * sm[1] + R1[3 * a + 2] * sm[2]);
+    scale_out[b] = scale;
+    double rv[3];
+    rotvec3(Rsel, rv);                                                      // init_guess.py:96
+    for (int a = 0; a < 3; ++a) rvec_out[(size_t)b * 3 + a] = rv[a];
+}
+
+hipError_t launch_umeyama(const double* src, const double* dst, int B, int npts, int estimate_scale, double* rot, double* rvec,
+                          double* trans, double* scale, hipStream_t stream) {
+    hipLaunchKernelGGL(umeyama_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, src, dst, B, npts, estimate_scale, rot, rvec, trans, scale);
+    return hipGetLastError();
+}
+
 }  // namespace mvfit

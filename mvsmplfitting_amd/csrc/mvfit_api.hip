@@ -33,6 +33,8 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
 size_t sdf_entry_bytes();
 hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
                               hipStream_t stream);
+hipError_t launch_umeyama(const double* src, const double* dst, int B, int npts, int estimate_scale, double* rot, double* rvec,
+                          double* trans, double* scale, hipStream_t stream);
 hipError_t launch_project_points(const DevProblems& Q, const float* pts, int N, float* uv, hipStream_t stream);
 hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
                                float* phi, hipStream_t stream);
@@ -1524,6 +1526,17 @@ extern "C" int mvfit_triangulate(mvfit_ctx* c, int B, int V, const float* keypoi
     HIP_OK(c, hipSetDevice(c->device));
     hipError_t e = launch_triangulate(keypoints, intris, extris, B, V, NKP, joints3d, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "triangulate launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_umeyama(mvfit_ctx* c, int B, int npts, const double* src, const double* dst, int estimate_scale,
+                             double* rot, double* rvec, double* trans, double* scale) {
+    if (!c) return MVFIT_E_ARG;
+    if (B <= 0 || npts < 3 || !src || !dst || !rot || !rvec || !trans || !scale)
+        return fail(c, MVFIT_E_ARG, "mvfit_umeyama: bad argument (B=%d npts=%d)", B, npts);
+    HIP_OK(c, hipSetDevice(c->device));
+    hipError_t e = launch_umeyama(src, dst, B, npts, estimate_scale, rot, rvec, trans, scale, c->stream);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "umeyama launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
 

@@ -280,6 +280,25 @@ class MvFit:
         self._check(self._lib.mvfit_triangulate(self._ctx, B, V, kp.data_ptr(), K.data_ptr(), E.data_ptr(), out.data_ptr()))
         return out
 
+    def umeyama(self, src, dst, estimate_scale=True):
+        """The reference's similarity alignment + cv2.Rodrigues (include/mvfit.h:mvfit_umeyama): src [npts,3],
+        dst [B,npts,3] float64 -> dict(rot [B,3,3], rvec [B,3], trans [B,3], scale [B]) float64 tensors."""
+        s_ = torch.as_tensor(np.asarray(src, np.float64) if not isinstance(src, torch.Tensor) else src,
+                             dtype=torch.float64, device=self.device).contiguous()
+        d_ = torch.as_tensor(np.asarray(dst, np.float64) if not isinstance(dst, torch.Tensor) else dst,
+                             dtype=torch.float64, device=self.device).contiguous()
+        if s_.dim() != 2 or d_.dim() != 3 or d_.shape[1:] != s_.shape or s_.shape[1] != 3:
+            raise MvFitError('src must be [npts,3] and dst [B,npts,3]')
+        B, npts = int(d_.shape[0]), int(s_.shape[0])
+        out = dict(rot=torch.empty(B, 3, 3, dtype=torch.float64, device=self.device),
+                   rvec=torch.empty(B, 3, dtype=torch.float64, device=self.device),
+                   trans=torch.empty(B, 3, dtype=torch.float64, device=self.device),
+                   scale=torch.empty(B, dtype=torch.float64, device=self.device))
+        self._check(self._lib.mvfit_umeyama(self._ctx, B, npts, s_.data_ptr(), d_.data_ptr(), 1 if estimate_scale else 0,
+                                            out['rot'].data_ptr(), out['rvec'].data_ptr(), out['trans'].data_ptr(),
+                                            out['scale'].data_ptr()))
+        return out
+
     def project(self, points):
         """uv [B, V, N, 2] = every view's pinhole projection of points [B, N, 3] with the cameras of set_problems
         (include/mvfit.h:mvfit_project_points; reference cam(verts), utils/utils.py:603-607)."""

@@ -1,17 +1,29 @@
-"""Mirror of the first stage of the reference's per-frame initial guess (code/utils/init_guess.py:80-83):
-``recompute3D(extris, intris, keypoints)`` with the reference's argument meaning (code/utils/recompute3D.py:22-62) -
-``keypoints`` a list over views of [1, 17, 3] arrays (u, v, confidence) - evaluated by libmvfit
-(include/mvfit.h:mvfit_triangulate).  ``recompute3D_batch`` takes [B, V, 17, 3] for a batch of frames of one rig.
+"""Mirror of the reference's per-frame initial guess (code/utils/init_guess.py:18-134 ``init_guess`` for several views,
+:190-212 ``fix_params``), batched over the frames of one rig and evaluated by libmvfit:
 
-The remaining stages of init_guess (Umeyama alignment, cv2.Rodrigues) are not mirrored: the reference's umeyama
-multiplies by ``V.T`` of numpy's ``Vh`` (code/utils/umeyama.py:58,73), which makes its rotation depend on LAPACK's
-singular-vector sign convention, i.e. it has no implementation-independent value to be equal to."""
+  recompute3D(extris, intris, keypoints)      code/utils/recompute3D.py:22-62   -> mvfit_triangulate
+  umeyama(joints, joints3d, est_scale)        code/utils/umeyama.py:16-109      -> mvfit_umeyama
+  cv2.Rodrigues(rot)                          init_guess.py:96                   -> mvfit_umeyama (rvec)
+  rest-pose keypoints of the model            init_guess.py:38-52                -> mvfit_vertices at zero parameters
+
+``recompute3D`` keeps the reference's argument meaning (``keypoints`` a list over views of [1, 17, 3] arrays
+(u, v, confidence)); ``init_guess_batch`` takes [B, V, 17, 3].  The single-view depth guess (init_guess.py:54-78) is
+not mirrored (the path is multi-view).
+
+About the rotation: the reference's umeyama evaluates ``U diag(d) Vh^T`` in its full-rank branch (umeyama.py:73), which
+depends on the signs LAPACK happened to give the singular-vector pairs; libmvfit uses the signs of its own Jacobi SVD,
+then - like the reference - keeps the better of the two candidates (columns 0, 1 negated) by alignment residual.  The result
+is the reference's formula evaluated on a valid SVD (tests/test_umeyama.py checks it against the restatement for the four
+possible sign patterns); it equals the reference's own numbers only where LAPACK's signs coincide with the Jacobi SVD's
+(the scale always does).  The fit that follows starts from an equally (un)reasonable guess either way."""
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-from .engine import MvFit
+from .engine import MvFit, D
+
+TORSO = (5, 6, 11, 12)          # L / R shoulder, L / R hip in the 17-keypoint order (init_guess.py:57-60,90-92)
 
 
 def recompute3D_batch(engine: MvFit, extris, intris, keypoints) -> torch.Tensor:
@@ -24,4 +36,48 @@ def recompute3D(engine: MvFit, extris, intris, keypoints) -> np.ndarray:
     return engine.triangulate(kp, np.asarray(intris), np.asarray(extris))[0].cpu().numpy()
 
 
-__all__ = ['recompute3D', 'recompute3D_batch']
+def rest_keypoints(engine: MvFit, scale: float = 1.0) -> torch.Tensor:
+    """The 17 keypoints of the model at zero pose / shape / translation and the given scale (init_guess.py:31-52);
+    needs set_problems to have been called (any observations)."""
+    x = torch.zeros(engine.B, D, device=engine.device)
+    x[:, 85] = float(scale)
+    _, joints = engine.vertices(x)
+    return joints[0].to(torch.float64)
+
+
+def init_guess_batch(engine: MvFit, extris, intris, keypoints, est_scale=True, fixed_scale=None, use_torso=True,
+                     joints3d=None) -> dict:
+    """init_guess (init_guess.py:18-106) for B frames: keypoints [B, V, 17, 3] (u, v, confidence), extris [V,4,4],
+    intris [V,3,3] float64.  ``joints3d`` [B,17,3] replaces the triangulation (use_3d, :84-85).  Returns
+    dict(global_orient [B,3], transl [B,3], scale [B], joints3d [B,17,3]) float64 tensors on the device."""
+    kp = np.asarray(keypoints, np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints
+    if kp.shape[1] < 2 and joints3d is None:
+        raise NotImplementedError('single-view depth guess (init_guess.py:54-78) is not mirrored')
+    s0 = 1.0 if fixed_scale is None else float(fixed_scale)                      # :24
+    rest = rest_keypoints(engine, s0)
+    j3 = engine.triangulate(kp, intris, extris) if joints3d is None else \
+        torch.as_tensor(np.asarray(joints3d, np.float64), dtype=torch.float64, device=engine.device)
+    idx = list(TORSO) if use_torso else list(range(17))
+    out = engine.umeyama(rest[idx], j3[:, idx].contiguous(), estimate_scale=est_scale)
+    scale = out['scale'] if est_scale else torch.full_like(out['scale'], s0)     # :98-101
+    return dict(global_orient=out['rvec'], transl=out['trans'], scale=scale, joints3d=j3, rot=out['rot'])
+
+
+def initial_params(guess: dict, use_vposer: bool, fixed_shape=None) -> torch.Tensor:
+    """The flat [B, 118] start of the fit after init_guess + fix_params (init_guess.py:190-212): betas zero (or the
+    fixed shape), global_orient / transl / scale from the guess, body_pose = [1, 1, 1, 1, 1, 1, 0 ...] without VPoser
+    (:199-203), zero embedding with it (:110-112)."""
+    go = guess['global_orient']
+    B = go.shape[0]
+    x = torch.zeros(B, D, dtype=torch.float32, device=go.device)
+    if fixed_shape is not None:
+        x[:, 0:10] = torch.as_tensor(np.asarray(fixed_shape, np.float32), device=go.device).reshape(1, 10)
+    x[:, 10:13] = go.to(torch.float32)
+    if not use_vposer:
+        x[:, 13:19] = 1.0
+    x[:, 82:85] = guess['transl'].to(torch.float32)
+    x[:, 85] = guess['scale'].to(torch.float32)
+    return x
+
+
+__all__ = ['recompute3D', 'recompute3D_batch', 'rest_keypoints', 'init_guess_batch', 'initial_params', 'TORSO']

@@ -1,0 +1,64 @@
+"""GPU: the batched per-frame initial guess (mvsmplfitting_amd.init_guess.init_guess_batch = mvfit_triangulate +
+mvfit_umeyama, reference code/utils/init_guess.py:18-106) on the reference's demo frame: the golden file holds what the
+reference's own recompute3D + umeyama produced there (oracle/make_golden_demo.py; cv2.Rodrigues replaced by scipy's
+conversion, cv2 being absent in the build container)."""
+import os
+
+import numpy as np
+import pytest
+
+from mvsmplfitting_amd import init_guess as ig
+from oracle import umeyama_np as un
+from tests.gpu_helpers import make_engine
+from tests.helpers import GOLD, body_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_demo_initial_guess_equals_the_reference():
+    g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
+    eng = make_engine(body_model())
+    cams = tuple(g[k].astype(np.float32) for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'))
+    kps = g['keypoints'][None].astype(np.float32)                          # [1, 6, 17, 3]
+    eng.set_problems(cams, kps[..., :2], kps[..., 2])
+    out = ig.init_guess_batch(eng, g['extris'], g['intris'], kps, est_scale=True, use_torso=True)
+    j3 = out['joints3d'][0].cpu().numpy()
+    assert np.abs(j3 - g['init_joints3d']).max() < 1e-6 * np.abs(g['init_joints3d']).max()
+    rest = ig.rest_keypoints(eng).cpu().numpy()
+    assert np.abs(rest - g['init_joints_rest']).max() < 1e-5               # float32 forward vs the reference's float64
+    # the guess, against the restatement evaluated on the device's own inputs, for one singular-vector sign pattern
+    rot, trans, scale = out['rot'][0].cpu().numpy(), out['transl'][0].cpu().numpy(), float(out['scale'][0])
+    t = list(ig.TORSO)
+    hits = [sg for sg in un.SIGN_PATTERNS
+            if np.abs(un.umeyama(rest[t], j3[t], True, signs=sg)[0] - rot).max() < 1e-7]
+    assert hits, 'rotation equals the reference formula for none of the sign patterns'
+    r_ref, t_ref, s_ref, _ = un.umeyama(rest[t], j3[t], True, signs=hits[0])
+    assert np.abs(trans - t_ref).max() < 1e-7 and abs(scale - s_ref) < 1e-9
+    # the scale does not depend on the sign pattern: it is the reference's (x0 of the golden fit); rotation and
+    # translation are the reference's only if LAPACK's signs happen to be the Jacobi SVD's (not on this frame)
+    x0 = g['x0']
+    assert abs(scale - x0[16]) < 1e-4 * x0[16]
+    # fix_params: the flat start of the fit
+    x = ig.initial_params(out, use_vposer=True).cpu().numpy()
+    assert x.shape == (1, 118) and np.all(x[0, 13:82] == 0) and abs(x[0, 85] - scale) < 1e-5
+    x2 = ig.initial_params(out, use_vposer=False).cpu().numpy()
+    assert np.all(x2[0, 13:19] == 1.0) and np.all(x2[0, 19:82] == 0)
+    eng.close()
+
+
+def test_batched_initial_guess_is_per_frame():
+    """B frames of one rig in one call == the frames one by one."""
+    d = dict(np.load(os.path.join(GOLD, 'triangulate.npz')))
+    eng = make_engine(body_model())
+    ext, intr, kps = d['v8_extris'], d['v8_intris'], d['v8_kps']
+    B, V = kps.shape[0], kps.shape[1]
+    cams = (ext[:, :3, :3].astype(np.float32), ext[:, :3, 3].astype(np.float32), intr[:, 0, 0].astype(np.float32),
+            intr[:, :2, 2].astype(np.float32))
+    eng.set_problems(cams, kps[..., :2], kps[..., 2])
+    all_ = ig.init_guess_batch(eng, ext, intr, kps)
+    for b in range(B):
+        eng.set_problems(cams, kps[b:b + 1, ..., :2], kps[b:b + 1, ..., 2])
+        one = ig.init_guess_batch(eng, ext, intr, kps[b:b + 1])
+        for k in ('global_orient', 'transl', 'scale'):
+            assert np.array_equal(one[k][0].cpu().numpy(), all_[k][b].cpu().numpy()), (b, k)
+    eng.close()

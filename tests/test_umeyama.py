@@ -1,0 +1,77 @@
+"""Similarity alignment of the per-frame initial guess (reference code/utils/umeyama.py:16-109,
+init_guess.py:95-106).  CPU: the restatement against the reference function itself (numpy's singular-vector signs =
+pattern (1,1,1)) and the rotation-vector conversion against scipy (cv2 is absent).  GPU: mvfit_umeyama must equal the
+restatement for ONE of the four singular-vector sign patterns - the reference's full-rank formula U diag(d) Vh^T is
+not invariant under the SVD's sign freedom, so "what LAPACK returned" is the only thing it can be equal to - and its
+scale, candidate choice (smaller residual) and translation-from-the-second-candidate quirk must hold."""
+import numpy as np
+import pytest
+
+from oracle import ref_import as ri
+from oracle import umeyama_np as un
+
+
+def _cases(n=12, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        npts = 4 if i % 2 == 0 else 17
+        src = rng.normal(0, 0.3, (npts, 3))
+        a = rng.normal(size=3)
+        a *= rng.uniform(0.2, 3.0) / np.linalg.norm(a)
+        from scipy.spatial.transform import Rotation
+        R = Rotation.from_rotvec(a).as_matrix()
+        s = rng.uniform(0.5, 3.0)
+        dst = s * src @ R.T + rng.normal(0, 2.0, 3) + rng.normal(0, 0.01, (npts, 3))
+        out.append((src, dst))
+    return out
+
+
+@pytest.mark.skipif(not ri.available(), reason='reference tree not mounted')
+def test_restatement_equals_reference_umeyama():
+    ri.load()
+    from utils.umeyama import umeyama as ref_umeyama
+    for est in (True, False):
+        for src, dst in _cases():
+            r0, t0, s0 = ref_umeyama(src.copy(), dst.copy(), est)
+            r1, t1, s1, _ = un.umeyama(src, dst, est)
+            assert np.abs(r0 - r1).max() < 1e-12 and np.abs(t0 - t1).max() < 1e-12 and abs(s0 - s1) < 1e-12
+
+
+def test_rotvec_equals_scipy():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(1)
+    for i in range(200):
+        a = rng.normal(size=3)
+        a *= (np.pi - 1e-7 if i < 5 else rng.uniform(0, np.pi - 1e-3)) / np.linalg.norm(a)
+        R = Rotation.from_rotvec(a).as_matrix()
+        want = Rotation.from_matrix(R).as_rotvec()
+        got = un.rotvec(R)
+        assert np.abs(got - want).max() < 1e-6 or np.abs(got + want).max() < 1e-6       # theta = pi: +-axis is the same rotation
+    assert np.array_equal(un.rotvec(np.eye(3)), np.zeros(3))
+
+
+@pytest.mark.gpu
+def test_gpu_umeyama_equals_restatement_for_one_sign_pattern():
+    import torch
+    from tests.gpu_helpers import make_engine
+    from tests.helpers import body_model
+    eng = make_engine(body_model())
+    for est in (True, False):
+        cases = _cases(16, seed=3)
+        for npts in (4, 17):
+            sub = [c for c in cases if c[0].shape[0] == npts]
+            src = sub[0][0]
+            dst = np.stack([c[1] if i else sub[0][1] for i, c in enumerate(sub)])      # one src (the rest pose), many dst
+            out = eng.umeyama(src, dst, estimate_scale=est)
+            rot, rvec, trans, scale = (out[k].cpu().numpy() for k in ('rot', 'rvec', 'trans', 'scale'))
+            for b in range(dst.shape[0]):
+                hits = []
+                for sg in un.SIGN_PATTERNS:
+                    r1, t1, s1, losses = un.umeyama(src, dst[b], est, signs=sg)
+                    hits.append(np.abs(rot[b] - r1).max() < 1e-9 and np.abs(trans[b] - t1).max() < 1e-8)
+                    assert abs(scale[b] - s1) < 1e-10 * max(1.0, abs(s1))              # the scale does not depend on the signs
+                assert any(hits), (est, npts, b)
+                assert abs(np.linalg.det(rot[b]) - 1) < 1e-9
+                assert np.abs(rvec[b] - un.rotvec(rot[b])).max() < 1e-9
+    eng.close()
