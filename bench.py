@@ -170,11 +170,14 @@ def vertex_pass_variants(model, views, skin_topk):
         return ms
     for name, B, env, kern, key in (
             ('exact_fp32_B32', 32, {'MVFIT_EXACT_FP32': '1'}, 'lbs_vertex_pass_kernel<true>', None),
-            ('split_fp16_B128', 128, {}, 'lbs_vertex_pass_split_loop_kernel<true>', 'B128')):
+            ('split_fp16_B128', 128, {}, 'lbs_vertex_pass_split_loop_kernel<true>', 'B128'),
+            ('half_basis_B32', 32, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_kernel<true>', None),
+            ('half_basis_B128', 128, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_loop_kernel<true>', None)):
         ms = measure(B, env)
-        ach = bytes_fwd(B, skin_topk) / (ms * 1e-3) / 1e9
+        nbytes = bytes_fwd(B, skin_topk) - (8557380 + 413400 if 'HALF' in ''.join(env) else 0)     # half-width posedirs + shapedirs
+        ach = nbytes / (ms * 1e-3) / 1e9
         out[name] = dict(kernel=kern if skin_topk else kern.replace('<true>', '<false>'), problems=B,
-                         avg_launch_us=round(ms * 1e3, 2), algorithmic_bytes=bytes_fwd(B, skin_topk),
+                         avg_launch_us=round(ms * 1e3, 2), algorithmic_bytes=nbytes,
                          achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
                          traffic=pmc_traffic(key, 'split_loop') if key else None)
     return out

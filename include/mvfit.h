@@ -120,7 +120,9 @@ typedef struct mvfit_lbfgs_opts {
  * re-tiles the constants into HBM.  hip_stream may be NULL (default stream). */
 /* Environment switches read here (testing / comparison): MVFIT_EXACT_FP32=1 keeps the vertex pass's blendshape
  * contraction as an exact fp32 MFMA chain (default: error-compensated split-fp16 products, fp32 accumulate);
- * MVFIT_DENSE_SKINNING=1 keeps the dense 24-column skinning blend even when every vertex has <= 4 weights. */
+ * MVFIT_DENSE_SKINNING=1 keeps the dense 24-column skinning blend even when every vertex has <= 4 weights;
+ * MVFIT_HALF_BASIS=1 (BASELINE configs[4], half-width blendshape operands): the vertex pass streams only the fp16 hi
+ * halves of the basis (2 bytes per element; vertices then differ from the fp32 result by up to ~2e-5, tests). */
 /* Error contract: MVFIT_E_ARG for a null / incomplete model leaves *out = NULL.  Any later failure (unsupported
  * model, device allocation) still stores a ctx in *out: it carries the message (mvfit_last_error) and owns whatever
  * was allocated so far - release it with mvfit_destroy, it is not usable for anything else. */

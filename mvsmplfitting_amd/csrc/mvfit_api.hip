@@ -611,7 +611,12 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         M.bs4 = dev_upload(c, bs);
         // the same basis as split-fp16 MFMA B operands (vertex_pass.hip: lbs_vertex_pass_split_kernel):
         // x * scale = hi + lo, scale = the power of two that brings max |x| into [2^13, 2^14)
-        M.bs_h2 = nullptr; M.bs_scale = 1.f;
+        M.bs_h2 = nullptr; M.bs_scale = 1.f; M.half_basis = 0;
+        {   // MVFIT_HALF_BASIS=1 (BASELINE configs[4]: half-width blendshape operands): the contraction streams only the
+            // fp16 hi halves of the basis - 2 bytes per element like bf16, with 11 instead of 8 significant bits
+            const char* hb = getenv("MVFIT_HALF_BASIS");
+            M.half_basis = (hb && hb[0] == '1') ? 1 : 0;
+        }
         const char* exact = getenv("MVFIT_EXACT_FP32");
         if (!(exact && exact[0] == '1')) {
             float mx = 0.f;

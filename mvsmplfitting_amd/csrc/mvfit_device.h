@@ -77,6 +77,7 @@ struct DevModel {
     // 32 T + (lane & 31), values scaled by bs_scale (a power of two)
     const float4* bs_h2;
     float bs_scale;
+    int half_basis;          // 1: the contraction reads only the hi halves of the split basis (2 bytes per element, configs[4])
     const float* vt_planes;  // [3][nv_pad]
     const float* wt_tiles;   // [ntiles][24][32]
     // sparse skinning (null unless every vertex has <= 4 non-zero weights): per padded vertex 4 weights and

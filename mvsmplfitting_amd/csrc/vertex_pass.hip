@@ -411,7 +411,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // launch) and the vertex stores are then issued non-temporal so that they do not push it out
         for (int g = 0; g < VP_BPW; ++g) {
             bh[g] = stream_nt ? nt_load16(&cb[(2 * g) * 64]) : cb[(2 * g) * 64];
-            bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+            if (!M.half_basis) bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+            else bl[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             const half8 Ah = __builtin_bit_cast(half8, ah[g]), Al = __builtin_bit_cast(half8, al[g]);
             const half8 Bh = __builtin_bit_cast(half8, bh[g]), Bl = __builtin_bit_cast(half8, bl[g]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+            if (!M.half_basis) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
         }
         // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -644,7 +645,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int g = 0; g < VP_BPW; ++g) {
             bh[g] = stream_nt ? nt_load16(&cb[(2 * g) * 64]) : cb[(2 * g) * 64];
-            bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+            if (!M.half_basis) bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+            else bl[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -673,6 +675,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int it = 0; chunk < nchunks; ++it) {
         const int b0 = chunk * 32;
         const int next = chunk + (int)gridDim.y;
+#ifdef MVFIT_TIMING
+        const long long t_it = clock64();               // timeline of the second chunk (steady state), tests/vp_timeline.py
+#define VPL_T(k_) do { if (it == 1) VP_T(k_, t_it); } while (0)
+#else
+#define VPL_T(k_) do { } while (0)
+#endif
         float* tau_c = tau_l + (it & 1) * 32 * 4;
         float* tau_n = tau_l + ((it + 1) & 1) * 32 * 4;
         if (!pass_chunk_live(P, b0, B, live_w, tid)) {            // uniform; all its problems finished earlier
@@ -683,8 +691,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // ---- this chunk's operands have been requested one chunk ago: wait for this wave's share, then the barrier
         //      makes every wave's share (the coefficients are staged by all of them) visible ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VPL_T(0);
         __syncthreads();
-        VP_T(1, t_start);
+        VPL_T(1);
         // ---- skinning blend (lbs.py:209-213), all waves ----
         float tr[3][2][4];
 #pragma unroll
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
         }
-        VP_T(2, t_start);
+        VPL_T(2);
         __builtin_amdgcn_sched_barrier(0);                    // the blend's LDS reads stay above, the A operands below
         if (mfma_role) {
             // ---- blendshape contraction: plane kc_w, K-half kh_w; small products first.  The A operands come from
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 const half8 Ah = __builtin_bit_cast(half8, ah[g]), Al = __builtin_bit_cast(half8, al[g]);
                 const half8 Bh = __builtin_bit_cast(half8, bh[g]), Bl = __builtin_bit_cast(half8, bl[g]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);      // (Bl = 0 with MVFIT_HALF_BASIS: the registers here are too tight for a second code path)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
             }
             // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -760,7 +769,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 pdst[b * 33] = acc[r];
             }
         }
-        VP_T(3, t_start);
+        VPL_T(3);
         __syncthreads();
         // every MFMA wave has consumed this chunk's coefficients, this wave has blended its transforms: request the
         // next chunk's operands now - they fly under the epilogue and the stores of this one
@@ -780,9 +789,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 vps_l[bb * 96 + v * 3 + k] = vp[k];
             }
         }
-        VP_T(4, t_start);
+        VPL_T(4);
         __syncthreads();
-        VP_T(5, t_start);
+        VPL_T(5);
 
         // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
         {
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
             }
         }
-        VP_T(6, t_start);
+        VPL_T(6);
         // No barrier at the loop end: the next iteration starts with one (behind this wave's operand wait).
         chunk = next;
     }

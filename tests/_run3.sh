@@ -1,1 +1,2 @@
-python -m pytest tests/test_umeyama.py tests/test_gpu_init_guess.py tests/test_project.py -q 2>&1 | tail -15
+python -m pytest tests/test_gpu_closure.py -q -x -k "half_width or split_fp16" 2>&1 | tail -5
+MVFIT_HALF_BASIS=1 PYTHONPATH=. python tests/report_vertex_pass.py 32 128
