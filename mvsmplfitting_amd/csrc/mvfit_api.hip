@@ -1334,7 +1334,8 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             P.done_round = R.done_round;
             P.stats = R.stats;
             P.round = r;
-            P.pad_ = 0;
+            static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
+            P.pad_ = dbg_nt;                  // experiment switch: bit 0 = plain basis loads, bit 1 = plain vertex stores
             float* vout = c->d_verts;
             if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
             hipError_t e = launch_pass_gate(P, B, c->pass_stream);

@@ -385,7 +385,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int chunk = blockIdx.y;
     const int b0 = chunk * 32;
     if (!pass_chunk_live(P, b0, B, smem, tid)) return;
-    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr;       // uniform
+    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr && !(P.pad_ & 1u);       // uniform
+    const bool store_nt = VP_NT_LOADS && P.tag != nullptr && !(P.pad_ & 2u);
     const bool mfma_role = wave < 6;
     const int kc_w = wave % 3, kh_w = wave / 3;
 #ifdef MVFIT_TIMING
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 o.x += tau_l[b * 4 + k0];
                 o.y += tau_l[b * 4 + k1];
                 if (2 * q + 1 < nvalid) {
-                    if (stream_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
+                    if (store_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
                     else *reinterpret_cast<float2*>(dst) = o;
                 } else if (2 * q < nvalid) dst[0] = o.x;
             }
@@ -598,7 +599,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
     const int nchunks = (B + 31) >> 5;
-    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr;       // uniform
+    const bool stream_nt = VP_NT_LOADS && P.tag != nullptr && !(P.pad_ & 1u);       // uniform
+    const bool store_nt = VP_NT_LOADS && P.tag != nullptr && !(P.pad_ & 2u);
     const bool mfma_role = wave < 6;
     const int kc_w = wave % 3, kh_w = wave / 3;
 #ifdef MVFIT_TIMING
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     o.x += tau_c[b * 4 + k0];
                     o.y += tau_c[b * 4 + k1];
                     if (2 * q + 1 < nvalid) {
-                        if (stream_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
+                        if (store_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
                         else *reinterpret_cast<float2*>(dst) = o;
                     } else if (2 * q < nvalid) dst[0] = o.x;
                 }

@@ -1,0 +1,77 @@
+"""Sequence mode (reference ``is_seq``) for a batch of sequences.
+
+In the reference a later frame of a sequence starts from the previous frame's result (code/main.py:76-79 ->
+``load_init``, code/utils/init_guess.py:137-166), ``non_linear_solver`` then skips the first two stages and scales the
+third stage's pose-prior weight by 0.15 (code/utils/non_linear_solver.py:158-162); a frame whose predecessor ended with
+a loss above 5000 falls back to the full initial guess and all four stages (init_guess.py:141-145).  Frames of ONE
+sequence are therefore a dependent chain; different sequences are independent.  The schedule here is the wavefront
+that follows: time step t fits frame t of all S sequences as one batch on the device (S problems per mvfit_fit), the
+chain runs along t.  Sequences whose previous loss tripped the 5000 rule are fitted in a second batch with the full
+schedule at that step.  (Driving the reference's own caller in sequence mode under patch_reference needs none of this -
+the caller's logic does it frame by frame, tests/test_real_caller.py.)"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import MvFit, D
+
+RESTART_LOSS = 5000.0          # init_guess.py:142
+SEQ_POSE_FACTOR = 0.15         # non_linear_solver.py:162
+
+
+def sequence_stages(stages):
+    """The stage list of a warm-started frame: stages 0 and 1 skipped, stage 2 with body_pose_weight * 0.15 - and the
+    bending weight that non_linear_solver derives from it afterwards (:177-179)."""
+    out = [dict(s) for s in stages[2:]]
+    if out:
+        out[0]['body_pose_weight'] = out[0]['body_pose_weight'] * SEQ_POSE_FACTOR
+        out[0]['bending_prior_weight'] = 3.17 * out[0]['body_pose_weight']
+    return out
+
+
+def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, **fit_kw):
+    """gt_xy [S, T, V, 17, 2], w_conf [S, T, V, 17]: S sequences of T frames of one rig (or per-sequence cameras
+    [S, V, ...]); x_init [S, T, 118]: the full initial guess of every frame (used for frame 0 and after a restart).
+    Returns (x [S, T, 118] tensor, dict(final_loss [S, T], n_closure [S, T], restarted [S, T] bool))."""
+    gt = np.asarray(gt_xy, np.float32)
+    wc = np.asarray(w_conf, np.float32)
+    S, T = gt.shape[0], gt.shape[1]
+    xi = torch.as_tensor(np.asarray(x_init, np.float32) if not isinstance(x_init, torch.Tensor) else x_init,
+                         dtype=torch.float32, device=engine.device).reshape(S, T, D)
+    warm = sequence_stages(stages)
+    xs = torch.empty(S, T, D, device=engine.device)
+    final = torch.empty(S, T, device=engine.device)
+    ncl = torch.zeros(S, T, dtype=torch.int32, device=engine.device)
+    restarted = np.zeros((S, T), bool)
+    prev_x, prev_loss = None, None
+    for t in range(T):
+        if t == 0:
+            cold = np.ones(S, bool)
+        else:
+            pl = prev_loss.cpu().numpy()
+            cold = ~(pl <= RESTART_LOSS)                 # NaN (no loss returned) restarts too
+        restarted[:, t] = cold
+        for sel, stg in ((np.flatnonzero(cold), stages), (np.flatnonzero(~cold), warm)):
+            if sel.size == 0:
+                continue
+            cam_sel = tuple(np.asarray(c)[sel] for c in cams) if np.ndim(cams[0]) == 4 else cams
+            engine.set_problems(cam_sel, gt[sel, t], wc[sel, t])
+            idx = torch.as_tensor(sel, device=engine.device)
+            if stg is stages:
+                x0 = xi[idx, t]
+            else:
+                # load_init (init_guess.py:147-166): shape, orientation, translation, scale and the VPoser embedding come
+                # from the previous frame; without VPoser the body pose restarts from fix_params' value (:199-203)
+                x0 = prev_x[idx].clone()
+                if not (int(stg[0].get('flags', 0)) & 1):
+                    x0[:, 13:82] = xi[idx, t, 13:82]
+            xf, st = engine.fit(x0, stg, **fit_kw)
+            xs[idx, t] = xf
+            final[idx, t] = st['final_loss']
+            ncl[idx, t] = st['n_closure']
+        prev_x, prev_loss = xs[:, t], final[:, t]
+    return xs, dict(final_loss=final, n_closure=ncl, restarted=restarted)
+
+
+__all__ = ['fit_sequences', 'sequence_stages', 'RESTART_LOSS', 'SEQ_POSE_FACTOR']
