@@ -41,7 +41,7 @@ namespace mvfit {
 constexpr int LB_EPL = 2;          // elements per lane
 constexpr int LB_D = 96;           // row stride of every optimiser vector (>= D); lanes >= LB_D / LB_EPL idle
 constexpr int LB_HIST = 100;
-constexpr int LB_PD = 8;           // Gram rows in flight in the recurrences
+constexpr int LB_PD = 8;  // Gram rows in flight in the recurrences
 constexpr int LB_GS = 104;         // row stride of the Gram matrices (columns indexed by history slot)
 constexpr int LB_GPAD = 2 * LB_PD;                  // pad rows on both sides (prefetch runs up to 2 LB_PD - 1 rows past the end)
 constexpr int LB_GROWS = 2 * LB_HIST + 2 * LB_GPAD; // rows: pad | slots 0..99 | slots 0..99 again | pad
@@ -283,6 +283,10 @@ __device__ __forceinline__ void lb_recur_loop(const T* Mg, int n, int head, int 
     MP p1 = M + (LB_GPAD + head + (DESC ? n - 1 : 0)) * LB_GS + s1;
     constexpr int RS = DESC ? -LB_GS : LB_GS;
     T g0[LB_PD], g1[LB_PD];
+    // Drain this wave's earlier global stores (Gram insertion) first: with stores still counted in vmcnt the compiler
+    // cannot tell which of the row loads below have returned and waits for ALL of them at the top of every group of
+    // LB_PD steps - one full memory latency per group (~110 cycles per step instead of ~25, ISA-verified).
+    if (!LDSM) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
     for (int u = 0; u < LB_PD; ++u) { g0[u] = p0[u * RS]; g1[u] = TWO ? p1[u * RS] : (T)0; }
     // Steps st >= n of the last group run unguarded: the broadcast then reads a lane that owns no live

@@ -2,7 +2,7 @@
 import sys, os, ctypes as C, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip init_guess.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
+subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip init_guess.hip project.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
 import numpy as np, torch
 from mvsmplfitting_amd import _lib, synthetic as syn
 from mvsmplfitting_amd.engine import MvFit, stage_weights
