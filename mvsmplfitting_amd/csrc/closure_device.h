@@ -1179,11 +1179,24 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)byte_off, 0, /*aux = sc1*/ 16);
 }
 
+constexpr int PUBLISH_WAVE = 3;      // idle in the loss phase that follows (data term: waves 0-1 at <= 7 views; 3-D term and priors: waves 5-7)
+
 __device__ void publish_pose_async(const ClosureLds& L, const AsyncRing& R, int slot, int b, int tid) {
+    // All 129 words go out from ONE wave, which also stores the tag later: the hand-off needs no workgroup barrier.
+    const int l = tid - 64 * PUBLISH_WAVE;
+    if (l < 0 || l >= 64) return;
     const unsigned Bp = (unsigned)R.Bpad;
-    if (tid < 56) {
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(R.coefH, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(R.Amat, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(R.tau, 0, 0x7fffffff, 0x00020000);
+    {   // 72 words of skinning transforms: lanes 0..63, then 0..7
+        const unsigned base = ((unsigned)slot * Bp + (unsigned)b) * 72;
+        store16_sc1(rs_a, (base + l) * 16, reinterpret_cast<const float4*>(&L.pose.A[0][0])[l]);
+        if (l < 8) store16_sc1(rs_a, (base + 64 + l) * 16, reinterpret_cast<const float4*>(&L.pose.A[0][0])[64 + l]);
+    }
+    if (l < 56) {
         // word w: block G = w / 4, (hi | lo) = (w / 2) & 1, row half h = w & 1: coefficients p = 16 G + 8 h + t
-        const int G = tid >> 2, hl = (tid >> 1) & 1, h = tid & 1;
+        const int G = l >> 2, hl = (l >> 1) & 1, h = l & 1;
         _Float16 q[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -1195,28 +1208,19 @@ __device__ void publish_pose_async(const ClosureLds& L, const AsyncRing& R, int 
         __builtin_memcpy(&v, q, 16);
         const unsigned chunk = (unsigned)b >> 5;
         const unsigned word = (((unsigned)slot * (Bp >> 5) + chunk) * (KROWS / 16) + G) * 2 + hl;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.coefH, 0, 0x7fffffff, 0x00020000);
-        store16_sc1(rs, (word * 64 + 32 * h + ((unsigned)b & 31)) * 16, v);
-    } else if (tid >= 64 && tid < 64 + 72) {
-        const int i = tid - 64;
-        const float4 v = reinterpret_cast<const float4*>(&L.pose.A[0][0])[i];
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.Amat, 0, 0x7fffffff, 0x00020000);
-        store16_sc1(rs, (((unsigned)slot * Bp + (unsigned)b) * 72 + i) * 16, v);
-    } else if (tid == 192) {
-        const float4 v = make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], 0.f);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(R.tau, 0, 0x7fffffff, 0x00020000);
-        store16_sc1(rs, ((unsigned)slot * Bp + (unsigned)b) * 16, v);
+        store16_sc1(rs_c, (word * 64 + 32 * h + ((unsigned)b & 31)) * 16, v);
+    } else if (l == 56) {
+        store16_sc1(rs_t, ((unsigned)slot * Bp + (unsigned)b) * 16, make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], 0.f));
     }
 }
 
-// every storing wave has to have drained its sc1 stores before the tag goes out (the wait is free here: it sits
-// behind the adjoint's own loads); ONE lane stores the tag, relaxed at agent scope
+// The tag goes out from the same wave once its stores have drained (free by now: they were issued before the loss and
+// the whole adjoint, whose own load waits already covered them); ONE lane, relaxed at agent scope.
 __device__ __forceinline__ void publish_tag(const AsyncRing& R, int slot, int b, unsigned round, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // from the last wave: wave 0 goes straight into the L-BFGS recurrences, whose first global load would otherwise
-    // wait for this store's write-through acknowledgement
-    if (tid == STEP_NT - 64) __hip_atomic_store(R.tag + (size_t)slot * R.Bpad + b, round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((tid >> 6) == PUBLISH_WAVE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((tid & 63) == 0) __hip_atomic_store(R.tag + (size_t)slot * R.Bpad + b, round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace mvfit
