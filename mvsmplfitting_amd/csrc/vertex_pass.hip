@@ -103,6 +103,130 @@ __device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B,
     return run;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Pieces shared by the three pass kernels (exact-fp32, split-fp16, split-fp16 chunk loop).  All force-inlined: the
+// kernels differ in how the operands arrive and in the contraction, not in the skinning blend or the epilogue.
+// A thread's blend item: vertices {2 vp2, 2 vp2 + 1} x problem bb, all three rows of T (24 accumulators).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void vp_blend_zero(float (&tr)[3][2][4]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+}
+
+// T[k][i][:] += sum_t w_t A_b[j_t][k][:] for ONE of the thread's two vertices: the 4 (weight, joint) pairs of a vertex
+// with <= 4 non-zero weights, in ascending joint order - the non-zero products of the dense blend in the same order
+__device__ __forceinline__ void vp_blend_pairs(float (&tr)[3][2][4], int i, const float* arow, const float4& spw, const int4& spj) {
+    const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
+    const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
+            tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
+            tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
+            tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
+            tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
+        }
+}
+
+// T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213), all 24 joints; Wt_w = this wave's copy of the tile's weights
+__device__ __forceinline__ void vp_blend_dense(float (&tr)[3][2][4], const float* arow, const float* Wt_w, int vp2) {
+#pragma unroll 4
+    for (int j = 0; j < NJ; ++j) {
+        const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
+        const float wv[2] = {w.x, w.y};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
+                tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
+                tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
+                tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
+            }
+        }
+    }
+}
+
+// MFMA D layout -> LDS partials [slice][coordinate][32 problems][33]: col (vertex) = lane & 31,
+// row (problem) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void vp_put_partial(float* part, int slice, int kc, const floatx16& acc, int lane) {
+    float* pdst = part + ((slice * 3 + kc) * 32) * 33 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        pdst[b * 33] = acc[r];
+    }
+}
+
+// all waves: combine the K slices of the contraction in a fixed order (deterministic), undo the basis scale (SCALED:
+// a power of two, exact) and apply T: out = skinned position before "+ transl", vps = v_posed (side outputs only)
+template <int NSLICE, bool SCALED>
+__device__ __forceinline__ void vp_apply(const float* part, const float (&tr)[3][2][4], float* out_l, float* vps_l,
+                                         int bb, int vp2, float inv_scale) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = 2 * vp2 + i;
+        float vp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float sm = part[((0 * 3 + k) * 32 + bb) * 33 + v];
+#pragma unroll
+            for (int q = 1; q < NSLICE; ++q) sm += part[((q * 3 + k) * 32 + bb) * 33 + v];
+            vp[k] = SCALED ? sm * inv_scale : sm;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+            vps_l[bb * 96 + v * 3 + k] = vp[k];
+        }
+    }
+}
+
+// coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12 * 6890 % 8 == 0); nvalid = floats of the
+// tile row that exist (last tile); store_nt: non-temporal (asynchronous fit, see the split kernel)
+__device__ __forceinline__ void vp_store_rows(float* __restrict__ verts, const float* out_l, const float* tau, int nv, int vbase,
+                                              int nvalid, int b0, int B, int tid, bool store_nt) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
+        const int b = i / 48, q = i - b * 48;
+        if (b0 + b < B) {
+            float* dst = verts + ((size_t)(b0 + b) * nv + vbase) * 3 + 2 * q;
+            const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
+            float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
+            o.x += tau[b * 4 + k0];
+            o.y += tau[b * 4 + k1];
+            if (2 * q + 1 < nvalid) {
+                if (store_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
+                else *reinterpret_cast<float2*>(dst) = o;
+            } else if (2 * q < nvalid) dst[0] = o.x;
+        }
+    }
+}
+
+// side outputs for the vertices the objective reads (consumed by the step kernel of the chained mode)
+__device__ __forceinline__ void vp_side_outputs(const DevModel& M, const DevPose& P, const float* vps_l, const float* out_l,
+                                                int sel_s0, int sel_s1, int b0, int B, int tid) {
+    const int nsel = sel_s1 - sel_s0;
+    for (int i = tid; i < nsel * 96; i += VP_NT) {
+        const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
+        if (b0 + b >= B) continue;
+        const int lv = M.tile_sel_local[sel_s0 + sl], slot = M.tile_sel_slot[sel_s0 + sl];
+        P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
+        P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
+    }
+}
+
 template <bool SPARSE_W>
 __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_kernel(DevModel M, DevPose P, int B,
                                                                 float* __restrict__ verts) {
@@ -199,47 +323,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     VP_T(1, t_start);
     // ---- skinning blend T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213), all waves ----
     float tr[3][2][4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+    vp_blend_zero(tr);
     if (SPARSE_W) {
-        const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float wq[4] = {spw[i].x, spw[i].y, spw[i].z, spw[i].w};
-            const int jq[4] = {spj[i].x, spj[i].y, spj[i].z, spj[i].w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
-                    tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
-                    tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
-                    tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
-                    tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
-                }
-        }
+        vp_blend_pairs(tr, 0, A_l + bb * A_STRIDE, spw[0], spj[0]);
+        vp_blend_pairs(tr, 1, A_l + bb * A_STRIDE, spw[1], spj[1]);
     } else {
-        const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll 4
-        for (int j = 0; j < NJ; ++j) {
-            const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
-            const float wv[2] = {w.x, w.y};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
-                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
-                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
-                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
-                }
-            }
-        }
+        vp_blend_dense(tr, A_l + bb * A_STRIDE, Wt_w, vp2);
     }
     VP_T(2, t_start);
     // (A workgroup barrier here - blend everywhere first, then MFMA - was measured slower: the fp32 MFMA
@@ -267,72 +356,21 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 acc[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bv[kc][g].w, acc[kc], 0, 0, 0);
             }
         }
-        // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-        for (int kc = 0; kc < 3; ++kc) {
-            float* pdst = part + ((wave * 3 + kc) * 32) * 33 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                pdst[b * 33] = acc[kc][r];
-            }
-        }
+        for (int kc = 0; kc < 3; ++kc) vp_put_partial(part, wave, kc, acc[kc], lane);
     }
     VP_T(3, t_start);
     __syncthreads();
 
     // ---- all waves: combine the k-slices (fixed order) and apply T ----
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int v = 2 * vp2 + i;
-        float vp[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float sm = part[((0 * 3 + k) * 32 + bb) * 33 + v];
-#pragma unroll
-            for (int q = 1; q < VP_KSPLIT; ++q) sm += part[((q * 3 + k) * 32 + bb) * 33 + v];
-            vp[k] = sm;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
-            vps_l[bb * 96 + v * 3 + k] = vp[k];
-        }
-    }
+    vp_apply<VP_KSPLIT, false>(part, tr, out_l, vps_l, bb, vp2, 1.0f);
     VP_T(4, t_start);
     __syncthreads();
     VP_T(5, t_start);
 
-    // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
-    {
-        const int vbase = tile * TILE_V;
-        const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
-            const int b = i / 48, q = i - b * 48;
-            if (b0 + b < B) {
-                float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
-                const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
-                float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
-                o.x += tau_l[b * 4 + k0];
-                o.y += tau_l[b * 4 + k1];
-                if (2 * q + 1 < nvalid) *reinterpret_cast<float2*>(dst) = o;
-                else if (2 * q < nvalid) dst[0] = o.x;
-            }
-        }
-    }
-    // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
-    {
-        const int s0 = sel_s0, nsel = sel_s1 - s0;
-        for (int i = tid; i < nsel * 96; i += VP_NT) {
-            const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
-            if (b0 + b >= B) continue;
-            const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
-            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
-            P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
-        }
-    }
+    // ---- store x + transl, then the side outputs for the step kernel ----
+    vp_store_rows(verts, out_l, tau_l, M.nv, tile * TILE_V, min(TILE_V, M.nv - tile * TILE_V) * 3, b0, B, tid, false);
+    vp_side_outputs(M, P, vps_l, out_l, sel_s0, sel_s1, b0, B, tid);
     VP_T(6, t_start);
 #ifdef MVFIT_TIMING
     if (blockIdx.x == 5 && threadIdx.x == 0) g_vp[7] += 1;
@@ -359,8 +397,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef VP_NT_LOADS
 #define VP_NT_LOADS 1
 #endif
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 nt_load16(const float4* p) {
     return __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)));
 }
@@ -451,47 +487,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     VP_T(1, t_start);
     // ---- skinning blend (lbs.py:209-213), all waves ----
     float tr[3][2][4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+    vp_blend_zero(tr);
     if (SPARSE_W) {
-        const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float wq[4] = {spw[i].x, spw[i].y, spw[i].z, spw[i].w};
-            const int jq[4] = {spj[i].x, spj[i].y, spj[i].z, spj[i].w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
-                    tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
-                    tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
-                    tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
-                    tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
-                }
-        }
+        vp_blend_pairs(tr, 0, A_l + bb * A_STRIDE, spw[0], spj[0]);
+        vp_blend_pairs(tr, 1, A_l + bb * A_STRIDE, spw[1], spj[1]);
     } else {
-        const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll 4
-        for (int j = 0; j < NJ; ++j) {
-            const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
-            const float wv[2] = {w.x, w.y};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
-                    tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
-                    tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
-                    tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
-                }
-            }
-        }
+        vp_blend_dense(tr, A_l + bb * A_STRIDE, Wt_w, vp2);
     }
     VP_T(2, t_start);
     if (mfma_role) {
@@ -507,68 +508,20 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             if (!M.half_basis) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
         }
-        // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        float* pdst = part + ((kh_w * 3 + kc_w) * 32) * 33 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            pdst[b * 33] = acc[r];
-        }
+        vp_put_partial(part, kh_w, kc_w, acc, lane);
     }
     VP_T(3, t_start);
     __syncthreads();
 
     // ---- all waves: combine the two K-halves (fixed order), undo the basis scale, apply T ----
-    const float inv_scale = 1.0f / M.bs_scale;        // power of two: exact
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int v = 2 * vp2 + i;
-        float vp[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            vp[k] = (part[((0 * 3 + k) * 32 + bb) * 33 + v] + part[((1 * 3 + k) * 32 + bb) * 33 + v]) * inv_scale;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
-            vps_l[bb * 96 + v * 3 + k] = vp[k];
-        }
-    }
+    vp_apply<2, true>(part, tr, out_l, vps_l, bb, vp2, 1.0f / M.bs_scale);        // power of two: exact
     VP_T(4, t_start);
     __syncthreads();
     VP_T(5, t_start);
 
-    // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
-    {
-        const int vbase = tile * TILE_V;
-        const int nvalid = min(TILE_V, M.nv - vbase) * 3;      // floats valid in this tile row
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
-            const int b = i / 48, q = i - b * 48;
-            if (b0 + b < B) {
-                float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
-                const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
-                float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
-                o.x += tau_l[b * 4 + k0];
-                o.y += tau_l[b * 4 + k1];
-                if (2 * q + 1 < nvalid) {
-                    if (store_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
-                    else *reinterpret_cast<float2*>(dst) = o;
-                } else if (2 * q < nvalid) dst[0] = o.x;
-            }
-        }
-    }
-    // ---- side outputs for the vertices the objective reads (consumed by the step kernel) ----
-    if (!P.tag) {
-        const int s0 = sel_s0, nsel = sel_s1 - s0;
-        for (int i = tid; i < nsel * 96; i += VP_NT) {
-            const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
-            if (b0 + b >= B) continue;
-            const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
-            P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
-            P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
-        }
-    }
+    // ---- store x + transl, then (chained mode only) the side outputs for the step kernel ----
+    vp_store_rows(verts, out_l, tau_l, M.nv, tile * TILE_V, min(TILE_V, M.nv - tile * TILE_V) * 3, b0, B, tid, store_nt);
+    if (!P.tag) vp_side_outputs(M, P, vps_l, out_l, sel_s0, sel_s1, b0, B, tid);
     VP_T(6, t_start);
 #ifdef MVFIT_TIMING
     if (blockIdx.x == 5 && threadIdx.x == 0) g_vp[7] += 1;
@@ -698,50 +651,13 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         VPL_T(1);
         // ---- skinning blend (lbs.py:209-213), all waves ----
         float tr[3][2][4];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tr[k][i][e] = 0.f;
+        vp_blend_zero(tr);
         if (SPARSE_W) {
-            const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i) __builtin_amdgcn_sched_barrier(0);     // 12 transform rows in flight at a time, not 24 (registers)
-                const float4 spw = sw_l[2 * vp2 + i];
-                const int4 spj = sj_l[2 * vp2 + i];
-                const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
-                const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
-                        tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
-                        tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
-                        tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
-                        tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
-                    }
-            }
+            vp_blend_pairs(tr, 0, A_l + bb * A_STRIDE, sw_l[2 * vp2], sj_l[2 * vp2]);
+            __builtin_amdgcn_sched_barrier(0);            // 12 transform rows in flight at a time, not 24 (registers)
+            vp_blend_pairs(tr, 1, A_l + bb * A_STRIDE, sw_l[2 * vp2 + 1], sj_l[2 * vp2 + 1]);
         } else {
-            const float* arow = A_l + bb * A_STRIDE;
-#pragma unroll 4
-            for (int j = 0; j < NJ; ++j) {
-                const float2 w = *reinterpret_cast<const float2*>(Wt_w + j * 32 + 2 * vp2);
-                const float wv[2] = {w.x, w.y};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float4 a = *reinterpret_cast<const float4*>(arow + j * 12 + 4 * k);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        tr[k][i][0] = fmaf(wv[i], a.x, tr[k][i][0]);
-                        tr[k][i][1] = fmaf(wv[i], a.y, tr[k][i][1]);
-                        tr[k][i][2] = fmaf(wv[i], a.z, tr[k][i][2]);
-                        tr[k][i][3] = fmaf(wv[i], a.w, tr[k][i][3]);
-                    }
-                }
-            }
+            vp_blend_dense(tr, A_l + bb * A_STRIDE, Wt_w, vp2);
         }
         VPL_T(2);
         __builtin_amdgcn_sched_barrier(0);                    // the blend's LDS reads stay above, the A operands below
@@ -763,13 +679,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc, 0, 0, 0);      // (Bl = 0 with MVFIT_HALF_BASIS: the registers here are too tight for a second code path)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc, 0, 0, 0);
             }
-            // D layout: col (vertex) = lane&31, row (problem) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            float* pdst = part + ((kh_w * 3 + kc_w) * 32) * 33 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                pdst[b * 33] = acc[r];
-            }
+            vp_put_partial(part, kh_w, kc_w, acc, lane);
         }
         VPL_T(3);
         __syncthreads();
@@ -778,53 +688,14 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (next < nchunks) load_operands(next, tau_n);
 
         // ---- all waves: combine the two K-halves (fixed order), undo the basis scale, apply T ----
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int v = 2 * vp2 + i;
-            float vp[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                vp[k] = (part[((0 * 3 + k) * 32 + bb) * 33 + v] + part[((1 * 3 + k) * 32 + bb) * 33 + v]) * inv_scale;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
-                vps_l[bb * 96 + v * 3 + k] = vp[k];
-            }
-        }
+        vp_apply<2, true>(part, tr, out_l, vps_l, bb, vp2, inv_scale);
         VPL_T(4);
         __syncthreads();
         VPL_T(5);
 
-        // ---- coalesced store of x + transl: 32 rows of 96 floats (8-byte aligned: 12*6890 % 8 == 0) ----
-        {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int i = tid + r * VP_NT;                     // 32 * 48 = 1536 = 3 * 512
-                const int b = i / 48, q = i - b * 48;
-                if (b0 + b < B) {
-                    float* dst = verts + ((size_t)(b0 + b) * M.nv + vbase) * 3 + 2 * q;
-                    const int k0 = (2 * q) % 3, k1 = (2 * q + 1) % 3;
-                    float2 o = *reinterpret_cast<const float2*>(out_l + b * 96 + 2 * q);
-                    o.x += tau_c[b * 4 + k0];
-                    o.y += tau_c[b * 4 + k1];
-                    if (2 * q + 1 < nvalid) {
-                        if (store_nt) __builtin_nontemporal_store(__builtin_bit_cast(f32x2, o), reinterpret_cast<f32x2*>(dst));
-                        else *reinterpret_cast<float2*>(dst) = o;
-                    } else if (2 * q < nvalid) dst[0] = o.x;
-                }
-            }
-        }
-        // ---- side outputs for the vertices the objective reads (consumed by the step kernel of the chained mode) ----
-        if (!P.tag) {
-            const int s0 = sel_s0, nsel = sel_s1 - s0;
-            for (int i = tid; i < nsel * 96; i += VP_NT) {
-                const int sl = i / 96, rem = i - sl * 96, b = rem / 3, k = rem - 3 * b;
-                if (b0 + b >= B) continue;
-                const int lv = M.tile_sel_local[s0 + sl], slot = M.tile_sel_slot[s0 + sl];
-                P.vposed_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = vps_l[b * 96 + lv * 3 + k];
-                P.xs_sel[(size_t)(b0 + b) * NC_MAX + 3 * slot + k] = out_l[b * 96 + lv * 3 + k];
-            }
-        }
+        // ---- store x + transl, then (chained mode only) the side outputs for the step kernel ----
+        vp_store_rows(verts, out_l, tau_c, M.nv, vbase, nvalid, b0, B, tid, store_nt);
+        if (!P.tag) vp_side_outputs(M, P, vps_l, out_l, sel_s0, sel_s1, b0, B, tid);
         VPL_T(6);
         // No barrier at the loop end: the next iteration starts with one (behind this wave's operand wait).
         chunk = next;
