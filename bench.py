@@ -49,17 +49,29 @@ def bytes_fwd(B, skin_topk=0):
     return const + PER_PROBLEM_BYTES * B
 
 
-def pmc_traffic(key, kernel_substr):
-    """Measured HBM-side bytes per launch from the committed PMC summary, or None."""
+def pmc_value(key, kernel_substr, field='traffic_bytes'):
+    """A per-launch figure of the committed PMC summary (profiles/r2_pmc.json), or None."""
     try:
         with open(PMC_JSON) as f:
             d = json.load(f)
         for k, e in d.get(key, {}).items():
-            if kernel_substr in k and 'traffic_bytes' in e:
-                return round(e['traffic_bytes'])
+            if kernel_substr in k and field in e:
+                return round(e[field])
     except Exception:
         pass
     return None
+
+
+def pmc_traffic(key, kernel_substr):
+    """Measured HBM-side bytes per launch, or None."""
+    return pmc_value(key, kernel_substr, 'traffic_bytes')
+
+
+def mfma_util(key, kernel_substr, launch_us):
+    """Matrix-pipe utilisation of a launch: SQ_VALU_MFMA_BUSY_CYCLES (PMC, summed over the chip's SIMDs) over launch
+    duration x 2.4 GHz x 1024 SIMDs.  Small by design: the contraction is the only MFMA work of the path (north_star)."""
+    busy = pmc_value(key, kernel_substr, 'mfma_busy_cycles_per_launch')
+    return None if busy is None else round(busy / (launch_us * 1e-6 * 2.4e9 * 1024), 4)
 
 
 def build_inputs(eng, frames, views, seed0):
@@ -337,6 +349,9 @@ def main():
                     if (args.views == 8 and args.skin_topk == 4) else None,
                     traffic_source='profiles/r2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/collect_profiles.sh)',
                     algorithmic_bytes=bytes_fwd(B, args.skin_topk), avg_launch_us=round(ms_fit * 1e3, 2),
+                    mfma_util=mfma_util('B32' if B == 32 else ('B128' if B == 128 else ''), kname.split('<')[0], ms_fit * 1e3)
+                    if (args.views == 8 and args.skin_topk == 4) else None,
+                    mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r2_pmc.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',
                     timed_region='every vertex-pass launch of one complete fit (%d launches), begin / end of each dispatch stamped by '
                                  'the runtime (hipExtLaunchKernelGGL events on the stream the kernel is launched on)' % pr['vertex_pass_launches'],
                     launch_flavour='asynchronous fit: operands from the ring, non-temporal basis stream and vertex stores, the optimiser '

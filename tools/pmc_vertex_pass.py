@@ -8,6 +8,8 @@ Two roles:
     WRITE_SIZE do not fit one pass) and writes per kernel: launches, FETCH_SIZE / WRITE_SIZE averages (KiB),
     traffic = 2 x FETCH_SIZE (gfx950 reports half of a 16-byte-per-lane stream) + WRITE_SIZE.
 
+A third pass (`--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES`) gives the matrix-pipe utilisation.
+
 On the GPU box (see tools/collect_profiles.sh):
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/b32_fetch -o p -- python tools/pmc_vertex_pass.py drive 32
 """
@@ -56,13 +58,17 @@ def parse(out_json, specs):
                     a[1] += float(row['Counter_Value'])
         for (k, cn), (n, tot) in acc.items():
             e = res.setdefault(name, {}).setdefault(k, {})
-            e[cn + '_KiB_avg'] = tot / n
+            e[cn + ('_KiB_avg' if cn in ('FETCH_SIZE', 'WRITE_SIZE') else '_avg')] = tot / n
             e['launches_' + cn] = n
     for name, ks in res.items():
         for k, e in ks.items():
             if 'FETCH_SIZE_KiB_avg' in e and 'WRITE_SIZE_KiB_avg' in e:
                 e['traffic_bytes'] = (2.0 * e['FETCH_SIZE_KiB_avg'] + e['WRITE_SIZE_KiB_avg']) * 1024.0
                 e['traffic_note'] = '2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, separate --pmc passes'
+            if 'SQ_VALU_MFMA_BUSY_CYCLES_avg' in e:
+                # cycles the matrix pipes were busy, summed over all SIMDs of the chip (32 per v_mfma_f32_32x32x16_f16);
+                # bench.py divides by launch duration x 2.4 GHz x 1024 SIMDs for the utilisation
+                e['mfma_busy_cycles_per_launch'] = e['SQ_VALU_MFMA_BUSY_CYCLES_avg']
     with open(out_json, 'w') as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True))
