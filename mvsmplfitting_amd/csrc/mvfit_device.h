@@ -22,7 +22,8 @@ constexpr int NC_MAX = NS_MAX * 3;
 constexpr int KNNZ_MAX = 160;     // non-zeros of the 17 x ns keypoint selection
 constexpr int KP_NZ = 12;         // padded per-keypoint list length (LSP regressor rows have 4-9 non-zeros)
 constexpr int VS_NZ = 2;          // padded per-vertex list length (a vertex usually feeds one keypoint)
-constexpr int A_STRIDE = 292;     // per-problem stride of the 24x12 skinning transforms in LDS (vertex pass)
+constexpr int A_STRIDE = 288;     // per-problem stride of the 24x12 skinning transforms in LDS (vertex pass): the HBM stride, so that a chunk's
+                                  // transforms are one linear global -> LDS copy
 constexpr int STEP_NT = 512;      // threads of the per-problem kernels (8 waves)
 constexpr int STEP_NW = STEP_NT / 64;
 

@@ -571,14 +571,11 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const float4* csrc = P.coefH + (size_t)chunk * VP_NBLK * 2 * 64 + lane;                 // 28 x 1 KiB
         for (int i = wave; i < VP_NBLK * 2; i += VP_NT / 64)
             __builtin_amdgcn_global_load_lds(csrc + i * 64, coef_l + i * 64, 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                                                            // 4 x (1 KiB + 128 B)
-            const int b = 4 * wave + q;
-            const float4* src = reinterpret_cast<const float4*>(P.Amat + (size_t)(chunk * 32 + b) * 288) + lane;   // Bpad rows exist
-            float* dst = A_l + b * A_STRIDE;
-            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<float4*>(dst), 16, 0, 0);                   // words 0 .. 63
-            if (lane < 8) __builtin_amdgcn_global_load_lds(src + 64, reinterpret_cast<float4*>(dst + 256), 16, 0, 0);   // words 64 .. 71
-        }
+        // the chunk's 32 x 288 transforms are one contiguous 36 KiB block in HBM and (A_STRIDE == 288) in LDS: 36 x 1 KiB
+        static_assert(A_STRIDE == 288, "linear copy");
+        const float4* asrc = reinterpret_cast<const float4*>(P.Amat + (size_t)chunk * 32 * 288) + lane;      // Bpad rows exist
+        for (int i = wave; i < 32 * 288 / 256; i += VP_NT / 64)
+            __builtin_amdgcn_global_load_lds(asrc + i * 64, reinterpret_cast<float4*>(A_l) + i * 64, 16, 0, 0);
         if (wave == 7 && lane < 32)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(P.tau + (size_t)chunk * 32 * 4) + lane,
                                              reinterpret_cast<float4*>(tau_dst), 16, 0, 0);
