@@ -233,6 +233,15 @@ int mvfit_umeyama(mvfit_ctx* ctx, int B, int npts, const double* src, const doub
  *   uv[B,V,num_points,2] dev, float pixels (the reference truncates to int32 on the host afterwards). */
 int mvfit_project_points(mvfit_ctx* ctx, const float* points, int num_points, float* uv);
 
+/* The path's only collective (north_star: "RCCL over xGMI only for the final gather"; in the Python adapters it is one
+ * torch.distributed.all_gather, mvsmplfitting_amd/sharding.py): all-gather over the caller's RCCL communicator on the ctx
+ * stream - rank r's bytes_per_rank bytes at `send` land at recv + r * bytes_per_rank on every rank.  For hosts that own
+ * a communicator (a C / C++ driver); the reference has no counterpart (single process, code/main.py:60-120).
+ *   rccl_comm: the host's ncclComm_t.  libmvfit does not link RCCL - ncclAllGather is bound at run time to the RCCL
+ *   library already loaded in the process (the one the communicator belongs to); MVFIT_E_STATE if there is none.
+ *   send[bytes_per_rank], recv[nranks * bytes_per_rank] dev; asynchronous like every other call (mvfit_sync). */
+int mvfit_gather(mvfit_ctx* ctx, void* rccl_comm, const void* send, void* recv, size_t bytes_per_rank);
+
 /* Timing hook for bench.py: average duration (ms) of the LBS vertex-pass kernel launches since
  * the last call, measured with hipEvents on the ctx stream; *launches = number measured.
  * Enable with mvfit_profile(ctx, 1) (adds two event records per launch). */

@@ -9,6 +9,7 @@
 //   fit_sparse_kernel  the whole fit of one problem in a single launch (objective restricted to the
 //                      vertices it reads; no vertex pass inside the loop)
 //   lbfgs_kat_kernel   float64 instantiation of the state machine on analytic objectives
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1494,6 +1495,29 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                        o->num_stages);
     HIP_OK(c, hipGetLastError());
     if (!finished) return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished", cap);
+    return MVFIT_OK;
+}
+
+// The path's only collective: all-gather of the ranks' fitted parameters over RCCL, for hosts that own a
+// communicator.  libmvfit does not link RCCL: the communicator belongs to the RCCL copy the host process loaded (PyTorch
+// ships its own), so ncclAllGather is bound at run time to THAT library - the one already resident - never to a second one.
+extern "C" int mvfit_gather(mvfit_ctx* c, void* rccl_comm, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!c) return MVFIT_E_ARG;
+    if (!rccl_comm || !send || !recv) return fail(c, MVFIT_E_ARG, "mvfit_gather: null communicator or buffer");
+    if (bytes_per_rank == 0) return MVFIT_OK;
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);     // ncclAllGather
+    static allgather_fn fn = nullptr;
+    if (!fn) {
+        fn = reinterpret_cast<allgather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+        for (const char* so : {"librccl.so", "librccl.so.1"}) {
+            if (fn) break;
+            if (void* h = dlopen(so, RTLD_NOW | RTLD_NOLOAD)) fn = reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather"));
+        }
+    }
+    if (!fn) return fail(c, MVFIT_E_STATE, "mvfit_gather: no RCCL library is loaded in this process (ncclAllGather not found)");
+    HIP_OK(c, hipSetDevice(c->device));
+    const int rc = fn(send, recv, bytes_per_rank, /* ncclInt8 */ 0, rccl_comm, c->stream);
+    if (rc != 0) return fail(c, MVFIT_E_HIP, "mvfit_gather: ncclAllGather returned %d", rc);
     return MVFIT_OK;
 }
 

@@ -309,6 +309,17 @@ class MvFit:
         self._check(self._lib.mvfit_project_points(self._ctx, p.data_ptr(), int(p.shape[1]), uv.data_ptr()))
         return uv
 
+    def gather(self, rccl_comm, send, nranks):
+        """All-gather of a contiguous device tensor over a raw RCCL communicator (include/mvfit.h:mvfit_gather) - the
+        entry point of hosts that own an ncclComm_t; the Python adapters use torch.distributed (sharding.py), which does
+        not hand out its communicator.  rccl_comm: the ncclComm_t as an integer / c_void_p.  -> [nranks, *send.shape]."""
+        s_ = send.contiguous()
+        if not s_.is_cuda:
+            raise MvFitError('send must be a device tensor')
+        recv = torch.empty((int(nranks),) + tuple(s_.shape), dtype=s_.dtype, device=s_.device)
+        self._check(self._lib.mvfit_gather(self._ctx, rccl_comm, s_.data_ptr(), recv.data_ptr(), s_.numel() * s_.element_size()))
+        return recv
+
     def sdf_term_read(self):
         """(samples [B,Nv,4] = phi_v and its local-coordinate gradient, S [B]) of the last evaluated term."""
         smp = torch.empty(self.B, self.nv, 4, device=self.device)
