@@ -225,28 +225,26 @@ static_assert(sizeof(SdfEntry) == 16, "entry layout");
 
 constexpr int SDF_NIT = 16;          // 64-vertex rows per wave: nv <= 8 * 16 * 64
 
-__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_adjoint_kernel(DevModel M, const float* __restrict__ verts,
+// per problem: entries in the list, S = sum_v phi_v
+struct SdfHead { int n; float S; int pad0, pad1; };
+#ifndef SDF_NS_
+#define SDF_NS_ 8
+#endif
+constexpr int SDF_NS = SDF_NS_;      // workgroups (entry slices) per problem in the pull-back
+
+// Kernel 1 of the adjoint, one workgroup per problem: S, the box adjoint and the entry list.
+__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const float* __restrict__ verts,
                                                                  const SdfBox* __restrict__ box, const float4* __restrict__ samp,
-                                                                 DevPose P, const int* __restrict__ gate,
-                                                                 SdfEntry* __restrict__ entries, SdfAdj* __restrict__ out) {
+                                                                 const int* __restrict__ gate,
+                                                                 SdfEntry* __restrict__ entries, SdfHead* __restrict__ head) {
     __shared__ double sh_d[8][5];
     __shared__ int sh_cnt[8];
-    __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
-    __shared__ float sh_A[NJ * 12];
-    __shared__ __attribute__((aligned(16))) SdfEntry sh_e[SDF_EB];
-    __shared__ float sh_T[SDF_EB][12];
-    __shared__ float sh_vp[SDF_EB][3];
-    __shared__ float sh_part[SDF_EB][3][4];
-    __shared__ float sh_gvp[SDF_EB][3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
-    const int nv = M.nv;
     const SdfBox bx = box[b];
     const float* vb = verts + (size_t)b * nv * 3;
     const float4* sb = samp + (size_t)b * nv;
     SdfEntry* eb = entries + (size_t)b * nv;
-    if (tid < KROWS) sh_coef[tid] = P.coefT[(size_t)(b >> 5) * KROWS * 32 + (size_t)tid * 32 + (b & 31)];
-    if (tid >= 224 && tid < 224 + NJ * 12) sh_A[tid - 224] = P.Amat[(size_t)b * NJ * 12 + (tid - 224)];
     // ---- pass A: every wave owns an ascending chunk of vertices, 64 per row; everything stays in registers ----
     const int chunk = (nv + 7) / 8, c0 = wave * chunk, c1 = min(nv, c0 + chunk);
     float4 q[SDF_NIT];
@@ -313,12 +311,35 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_adjoint_kernel(DevModel M, con
         }
         base += __popcll(bal);
     }
-    __syncthreads();            // the entries written by this workgroup are visible to all of its waves
-    // ---- pull-back through skinning and the blendshape basis, SDF_EB entries at a time ----
+    if (tid == 0) { SdfHead h; h.n = n; h.S = (float)S; h.pad0 = h.pad1 = 0; head[b] = h; }
+}
+
+// Kernel 2: pull-back of the entries through skinning and the blendshape basis (~5.4 KB of basis rows and weights per
+// entry: one CU ingests ~10 B/clk, so a problem's list is cut into SDF_NS contiguous slices, one workgroup each; the
+// slice partials are added in slice order by kernel 3 - deterministic).  Grid (SDF_NS, B).
+__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, DevPose P, const int* __restrict__ gate,
+                                                                  const SdfEntry* __restrict__ entries,
+                                                                  const SdfHead* __restrict__ head, SdfAdj* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
+    __shared__ float sh_A[NJ * 12];
+    __shared__ __attribute__((aligned(16))) SdfEntry sh_e[SDF_EB];
+    __shared__ float sh_T[SDF_EB][12];
+    __shared__ float sh_vp[SDF_EB][3];
+    __shared__ float sh_part[SDF_EB][3][4];
+    __shared__ float sh_gvp[SDF_EB][3];
+    const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x;
+    if (gate && !gate[b]) return;
+    const int ntot = head[b].n;
+    const int lo = (int)((long long)ntot * y / SDF_NS), n = (int)((long long)ntot * (y + 1) / SDF_NS);
+    const SdfEntry* eb = entries + (size_t)b * M.nv;
+    if (lo < n) {                                                    // (uniform) an empty slice writes zeros
+        if (tid < KROWS) sh_coef[tid] = P.coefT[(size_t)(b >> 5) * KROWS * 32 + (size_t)tid * 32 + (b & 31)];
+        if (tid >= 224 && tid < 224 + NJ * 12) sh_A[tid - 224] = P.Amat[(size_t)b * NJ * 12 + (tid - 224)];
+    }
     float acc = 0.f;
     const int oj = tid >= KROWS ? (tid - KROWS) / 12 : 0, oe = tid >= KROWS ? (tid - KROWS) % 12 : 0;
     float gtv = 0.f;
-    for (int e0 = 0; e0 < n; e0 += SDF_EB) {
+    for (int e0 = lo; e0 < n; e0 += SDF_EB) {
         const int ne = min(SDF_EB, n - e0);
         __syncthreads();
         if (tid < ne) reinterpret_cast<float4*>(sh_e)[tid] = reinterpret_cast<const float4*>(eb + e0)[tid];
@@ -374,22 +395,49 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_adjoint_kernel(DevModel M, con
             }
         }
     }
+    SdfAdj& O = part[(size_t)b * SDF_NS + y];
+    if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
+    if (tid < 3) O.gtau[tid] = gtv;
+}
+
+// Kernel 3: slice partials -> the problem's adjoint, in slice order.
+__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_reduce_kernel(const int* __restrict__ gate, const SdfHead* __restrict__ head,
+                                                                const SdfAdj* __restrict__ part, SdfAdj* __restrict__ out) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (gate && !gate[b]) return;
+    const SdfAdj* p = part + (size_t)b * SDF_NS;
+    float acc = 0.f, gtv = 0.f;
+#pragma unroll
+    for (int y = 0; y < SDF_NS; ++y) {
+        acc += tid < KROWS ? p[y].gcoef[tid] : p[y].gA[tid - KROWS];
+        if (tid < 3) gtv += p[y].gtau[tid];
+    }
     SdfAdj& O = out[b];
     if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
     if (tid < 3) O.gtau[tid] = gtv;
-    if (tid == 0) { O.S = (float)S; }
+    if (tid == 0) O.S = head[b].S;
 }
+
+// work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B] SdfHead
+static size_t sdf_part_offset(int B, int nv) { return ((size_t)B * nv * sizeof(SdfEntry) + 255) & ~(size_t)255; }
+static size_t sdf_head_offset(int B, int nv) { return sdf_part_offset(B, nv) + (size_t)B * SDF_NS * sizeof(SdfAdj); }
+size_t sdf_work_bytes(int B, int nv) { return sdf_head_offset(B, nv) + (size_t)B * sizeof(SdfHead); }
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream) {
+    static_assert(SDF_ADJ_NT == KROWS + NJ * 12, "thread per output of the pull-back");
+    unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
+    SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
+    SdfHead* head = reinterpret_cast<SdfHead*>(wk + sdf_head_offset(B, M.nv));
     hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box);
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
                        (const SdfBox*)box, faces, num_faces, G, gate, samp);
-    hipLaunchKernelGGL(sdf_adjoint_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, M, verts, (const SdfBox*)box,
-                       (const float4*)samp, P, gate, reinterpret_cast<SdfEntry*>(entries), adj);
+    hipLaunchKernelGGL(sdf_entries_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
+                       (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), head);
+    hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate,
+                       reinterpret_cast<const SdfEntry*>(entries), (const SdfHead*)head, part);
+    hipLaunchKernelGGL(sdf_reduce_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, gate, (const SdfHead*)head, (const SdfAdj*)part, adj);
     return hipGetLastError();
 }
-
-size_t sdf_entry_bytes() { return sizeof(SdfEntry); }
 
 }  // namespace mvfit
