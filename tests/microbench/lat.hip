@@ -84,21 +84,49 @@ __global__ void k(long long* out, float* fout, int nwaves_active) {
 #pragma unroll 4
     for (int i = 0; i < N / 4; ++i) { float s, c; sincosf(v, &s, &c); v = s + c; }
     t1 = clock64(); if (lane == 0) out[12] = t1 - t0;
-    fout[tid] = v + (float)d + q;
+    // 13: one step of the L-BFGS walk as shipped: broadcast of a pivot lane through an SGPR + FMA
+    float x = v, gq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gq[u] = 1e-3f * (lane + u);
+    t0 = clock64();
+#pragma unroll 8
+    for (int i = 0; i < N; ++i) { const float pv = lane_read(x, (N - 1 - i) & 63); x = fmaf(-pv, gq[i & 7], x); }
+    t1 = clock64(); if (lane == 0) out[13] = t1 - t0;
+    // 14: the same step with the pivot broadcast through LDS (write own value, all lanes read one address)
+    t0 = clock64();
+#pragma unroll 8
+    for (int i = 0; i < N; ++i) { lds[lane] = x; wave_lds_fence(); const float pv = lds[(N - 1 - i) & 63]; x = fmaf(-pv, gq[i & 7], x); }
+    t1 = clock64(); if (lane == 0) out[14] = t1 - t0;
+    // 15: four steps per LDS round trip: pivots read together, carried through the block's triangle in uniform registers
+    t0 = clock64();
+#pragma unroll 2
+    for (int i = 0; i < N; i += 4) {
+        lds[lane] = x; wave_lds_fence();
+        const int i0 = (N - 1 - i) & 63;
+        const float a0 = lds[i0], b1 = lds[(i0 - 1) & 63], b2 = lds[(i0 - 2) & 63], b3 = lds[(i0 - 3) & 63];
+        const float m01 = lds[64 + i0], m02 = lds[65 + i0], m03 = lds[66 + i0], m12 = lds[67 + i0], m13 = lds[68 + i0], m23 = lds[69 + i0];
+        const float a1 = fmaf(-a0, m01, b1);
+        const float a2 = fmaf(-a1, m12, fmaf(-a0, m02, b2));
+        const float a3 = fmaf(-a2, m23, fmaf(-a1, m13, fmaf(-a0, m03, b3)));
+        x = fmaf(-a0, gq[0], x); x = fmaf(-a1, gq[1], x); x = fmaf(-a2, gq[2], x); x = fmaf(-a3, gq[3], x);
+    }
+    t1 = clock64(); if (lane == 0) out[15] = t1 - t0;
+    fout[tid] = v + (float)d + q + x;
 }
 int main() {
     long long* out; float* f;
     hipMalloc(&out, 64 * 8 + 4096 * 4); hipMalloc(&f, 4096);
     int h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (i * 37 + 11) & 1023;
     hipMemcpy(out + 64, h, sizeof(h), hipMemcpyHostToDevice);
-    const char* names[13] = {"fma", "dpp add (x4 per row16_sum)", "wave64_sum f32", "lds read chain", "readlane+use", "shfl_xor (bpermute)",
-                             "wave64_sum f64", "f64 divide", "f32 divide", "global load chain (L2)", "lds write->fence->read->fence", "", "sincosf"};
-    const int per[13] = {N, N, N / 4, N, N, N, N / 4, N / 4, N / 4, N / 4, N / 4, 1, N / 4};
+    const char* names[16] = {"fma", "dpp add (x4 per row16_sum)", "wave64_sum f32", "lds read chain", "readlane+use", "shfl_xor (bpermute)",
+                             "wave64_sum f64", "f64 divide", "f32 divide", "global load chain (L2)", "lds write->fence->read->fence", "", "sincosf",
+                             "walk step: readlane + fma", "walk step: LDS broadcast + fma", "walk step, 4 per LDS round trip (per step)"};
+    const int per[16] = {N, N, N / 4, N, N, N, N / 4, N / 4, N / 4, N / 4, N / 4, 1, N / 4, N, N, N};
     for (int mode = 0; mode < 2; ++mode) {
         for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, out, f, mode); hipDeviceSynchronize(); }
         long long r[16]; hipMemcpy(r, out, sizeof(r), hipMemcpyDeviceToHost);
         printf("mode %d (%s)\n", mode, mode ? "7 other waves hammering LDS" : "other waves exited");
-        for (int i = 0; i < 13; ++i) if (names[i][0]) printf("  %-34s %8.1f cycles/op\n", names[i], (double)r[i] / per[i]);
+        for (int i = 0; i < 16; ++i) if (names[i][0]) printf("  %-34s %8.1f cycles/op\n", names[i], (double)r[i] / per[i]);
     }
     return 0;
 }
