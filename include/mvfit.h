@@ -152,6 +152,11 @@ int mvfit_set_joints3d(mvfit_ctx* ctx, const float* gt3d, const float* conf3d);
 int mvfit_closure(mvfit_ctx* ctx, const mvfit_weights* w, const float* params,
                   float* loss, float* grad, float* verts, float* joints);
 
+/* ModelOutput.full_pose of SMPL.forward (body_models_scale.py:392-412): [B,72] = global_orient | body_pose, the body pose
+ * decoded from the embedding with MVFIT_F_VPOSER (fitting.py:170-173, VPoser.decode 'aa') - what the reference's
+ * save_results stores as 'pose' / 'body_pose' (code/utils/utils.py:744-766).  params[B,MVFIT_D] dev, full_pose[B,72] dev. */
+int mvfit_full_pose(mvfit_ctx* ctx, const float* params, uint32_t flags, float* full_pose);
+
 /* SMPL.forward only (body_models_scale.py:327-412): vertices (+transl) and the 17 keypoints. */
 int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint32_t flags,
                    float* verts /*[B,Nv,3] dev*/, float* joints /*[B,17,3] dev or NULL*/);

@@ -1,0 +1,133 @@
+"""File-to-file batch driver: what the reference's `main.py` does for a data folder (code/main.py:21-130) with every
+frame of a serial fitted in ONE batched device fit (the reference walks the frames one by one):
+
+    keypoint files  <keyp_root>/<serial>/<camera>/<frame>_keypoints.json   (data_parser.py:375-411: cameras and frames
+                    in sorted order, view v = the v-th camera of the camera file; a view without a file does not take
+                    part in that frame - here: zero confidence)
+    camera file     io_formats.load_camera_para  (utils.py:352-394)
+      -> joint weights: hips 11, 12 ignored unless pose_format == 'lsp14' and use_hip (data_parser.py:340-357;
+         model_type 'smpllsp' -> 'lsp14', init.py:63-69, and fit_smpl.yaml has use_hip: true: the default here)
+      -> initial guess on the device (init_guess.py:18-106 + fix_params :190-212): init_guess.init_guess_batch
+      -> staged fit of all frames at once (non_linear_solver.py:156-211), or the warm-start chain with is_seq
+         (main.py:76-79, init_guess.py:137-166): sequence.fit_sequences
+      -> per frame `<result_folder>/<serial>/<frame>/000.pkl` (utils.py:744-766, 859-864: pickle protocol 2, body pose
+         decoded and feet / hands zeroed) and, with save_meshes, `<mesh_folder>/<serial>/<frame>/000.obj` of the model at the
+         SAVED (zeroed) pose (utils.py:866-890).
+
+Images, rendering and the interactive viewer of main.py are out of scope; nothing here reads images, so
+the image height the data weight 500 / H refers to (non_linear_solver.py:150,177) is an argument.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import io_formats as iof
+from .engine import MvFit, stage_weights
+from .init_guess import init_guess_batch, initial_params
+from .sequence import fit_sequences
+
+
+def list_frames(keyp_root):
+    """[(serial, [camera names], [(frame name, [json path or None per camera])])] in the reference's order."""
+    out = []
+    for serial in sorted(os.listdir(keyp_root)):
+        sdir = os.path.join(keyp_root, serial)
+        if not os.path.isdir(sdir):
+            continue
+        cams = sorted(c for c in os.listdir(sdir) if os.path.isdir(os.path.join(sdir, c)))
+        names = set()
+        for c in cams:
+            names.update(f[:-len('_keypoints.json')] for f in os.listdir(os.path.join(sdir, c)) if f.endswith('_keypoints.json'))
+        frames = []
+        for fn in sorted(names):
+            paths = [os.path.join(sdir, c, fn + '_keypoints.json') for c in cams]
+            frames.append((fn, [p if os.path.exists(p) else None for p in paths]))
+        out.append((serial, cams, frames))
+    return out
+
+
+def load_serial(frames, num_views, person=0):
+    """Keypoints [F, V, 17, 3] float32 of one serial (missing view / person: zeros, i.e. zero confidence)."""
+    kp = np.zeros((len(frames), num_views, 17, 3), np.float32)
+    for f, (_, paths) in enumerate(frames):
+        for v, p in enumerate(paths[:num_views]):
+            if p is None:
+                continue
+            people = iof.read_keypoints(p)
+            if len(people) > person:
+                kp[f, v] = people[person]
+    return kp
+
+
+def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, image_height=1536.0, is_seq=False,
+               pose_format='lsp14', use_hip=True, fix_scale=None, fix_shape=None, save_meshes=False, mesh_folder=None,
+               device=0, stages=None, engine: MvFit | None = None):
+    """Fits every frame under keyp_root and writes the reference's result files.  Returns
+    {serial: dict(frames, params [F,118], final_loss [F], n_closure [F], files [F], init [F,118], restarted [F]:
+    frames fitted from their own initial guess - all of them unless is_seq)}."""
+    extris, intris = iof.load_camera_para(cam_file)
+    use_vposer = vposer is not None
+    flags = _lib.F_VPOSER if use_vposer else 0
+    if fix_scale is not None:
+        flags |= _lib.F_FIX_SCALE
+    if fix_shape is not None:
+        flags |= _lib.F_FIX_SHAPE
+    if stages is None:
+        stages = stage_weights(float(image_height), flags=flags)
+    own = engine is None
+    eng = engine if engine is not None else MvFit(model, vposer=vposer, device=device)
+    jw = np.ones(17, np.float32)
+    if pose_format != 'lsp14' or not use_hip:                      # data_parser.py:353-356
+        jw[11] = jw[12] = 0.0
+    results = {}
+    try:
+        for serial, cams, frames in list_frames(keyp_root):
+            V, F = len(cams), len(frames)
+            if F == 0 or V < 2:
+                continue                                            # the single-view depth guess is not mirrored
+            kp = load_serial(frames, V)
+            ex, it = np.asarray(extris[:V], np.float64), np.asarray(intris[:V], np.float64)
+            rig = (ex[:, :3, :3].astype(np.float32), ex[:, :3, 3].astype(np.float32),
+                   it[:, 0, 0].astype(np.float32), it[:, :2, 2].astype(np.float32))
+            gt_xy = kp[..., :2].copy()
+            conf = kp[..., 2] * jw[None, None, :]
+            eng.set_problems(rig, gt_xy, conf)
+            guess = init_guess_batch(eng, ex, it, kp, est_scale=fix_scale is None, fixed_scale=fix_scale)
+            x0 = initial_params(guess, use_vposer, fixed_shape=fix_shape)
+            if is_seq:
+                xs, st = fit_sequences(eng, rig, gt_xy[None], conf[None], x0[None], stages)
+                xf, final, ncl = xs[0], st['final_loss'][0], st['n_closure'][0]
+                restarted = st['restarted'][0]
+                eng.set_problems(rig, gt_xy, conf)                  # back to the whole serial for the outputs below
+            else:
+                xf, st = eng.fit(x0, stages)
+                final, ncl = st['final_loss'], st['n_closure']
+                restarted = np.ones(F, bool)
+            full = eng.full_pose(xf, flags=flags).cpu().numpy()
+            xf_h, final_h = xf.cpu().numpy(), final.cpu().numpy()
+            res = [iof.result_dict(xf_h[f], loss=final_h[f], body_pose_decoded=full[f, 3:] if use_vposer else None)
+                   for f in range(F)]
+            files = [iof.save_result_pkl(result_folder, serial, frames[f][0], res[f]) for f in range(F)]
+            if save_meshes:
+                # the mesh of the SAVED parameters: zeroed feet / hands, model(global_orient, transl, body_pose, betas)
+                xm = xf_h.copy()
+                xm[:, 13:82] = np.stack([r['body_pose'][0] for r in res])
+                verts, _ = eng.vertices(xm, flags=flags & ~_lib.F_VPOSER)
+                verts = verts.cpu().numpy()
+                for f in range(F):
+                    d = os.path.join(mesh_folder or os.path.join(result_folder, 'meshes'), serial, frames[f][0])
+                    os.makedirs(d, exist_ok=True)
+                    iof.save_obj(os.path.join(d, '000.obj'), verts[f], model['faces'])
+            results[serial] = dict(frames=[fr[0] for fr in frames], params=xf_h, final_loss=final_h,
+                                   n_closure=ncl.cpu().numpy(), files=files, init=x0.cpu().numpy(), restarted=restarted)
+    finally:
+        if own:
+            eng.close()
+    return results
+
+
+__all__ = ['list_frames', 'load_serial', 'fit_folder']

@@ -100,7 +100,8 @@ __global__ void pack_joints3d_kernel(const float* __restrict__ gt3d, const float
 }
 
 __global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBlock* __restrict__ obs, DevPose P,
-                                                       const float* __restrict__ params, uint32_t flags) {
+                                                       const float* __restrict__ params, uint32_t flags,
+                                                       float* __restrict__ full_pose = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBloc
     __syncthreads();
     pose_and_chain(M, L, flags, tid);
     publish_pose(L, P, b, tid);
+    // ModelOutput.full_pose (body_models_scale.py:392-412): global_orient | body_pose, the latter decoded from the
+    // embedding with MVFIT_F_VPOSER (fitting.py:170-173)
+    if (full_pose && tid < 72) full_pose[(size_t)b * 72 + tid] = L.pose.theta[tid];
 }
 
 __global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
@@ -1142,7 +1146,8 @@ extern "C" int mvfit_vertices(mvfit_ctx* c, const float* params, uint32_t flags,
     int rc = check_flags(c, flags);
     if (rc) return rc;
     HIP_OK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, flags);
+    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, flags,
+                       (float*)nullptr);
     HIP_OK(c, hipGetLastError());
     rc = run_vertex_pass(c, verts);
     if (rc) return rc;
@@ -1150,6 +1155,18 @@ extern "C" int mvfit_vertices(mvfit_ctx* c, const float* params, uint32_t flags,
         hipLaunchKernelGGL(joints_kernel, dim3(c->B), dim3(64), 0, c->stream, c->M, (const float*)verts, joints);
         HIP_OK(c, hipGetLastError());
     }
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_full_pose(mvfit_ctx* c, const float* params, uint32_t flags, float* full_pose) {
+    if (!c || !params || !full_pose) return MVFIT_E_ARG;
+    if (c->B == 0) return fail(c, MVFIT_E_STATE, "call mvfit_set_problems first");
+    int rc = check_flags(c, flags);
+    if (rc) return rc;
+    HIP_OK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, flags,
+                       full_pose);
+    HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
 }
 
@@ -1167,7 +1184,8 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     // the interpenetration term reads every vertex: it forces the vertex pass
     const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0 && !sdf;
     if (!sparse || verts) {
-        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, w->flags);
+        hipLaunchKernelGGL(prep_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, params, w->flags,
+                           (float*)nullptr);
         HIP_OK(c, hipGetLastError());
         rc = run_vertex_pass(c, vbuf);
         if (rc) return rc;

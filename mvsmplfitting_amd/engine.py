@@ -195,6 +195,14 @@ class MvFit:
                                              joints.data_ptr()))
         return verts, joints
 
+    def full_pose(self, params, flags=0):
+        """ModelOutput.full_pose [B,72] = global_orient | body_pose (decoded from the embedding with F_VPOSER):
+        include/mvfit.h:mvfit_full_pose."""
+        x = self._dev(params, (self.B, D))
+        out = torch.empty(self.B, 72, device=self.device)
+        self._check(self._lib.mvfit_full_pose(self._ctx, x.data_ptr(), int(flags), out.data_ptr()))
+        return out
+
     def fit(self, params, stages, lr=1.0, max_iter=30, history=100, tolerance_grad=1e-5,
             tolerance_change=1e-9, maxiters=30, ftol=1e-9, gtol=1e-9, max_rounds=0):
         """Device-resident staged fit.  params [B,118] -> (params_out tensor, stats dict)."""

@@ -1,0 +1,46 @@
+"""CPU: the batch driver's folder parsing against what the reference's own FittingData / load_camera_para produced for
+its shipped demo (tests/golden/demo_fit_smpl.npz was written from the reference's parsers by oracle/make_golden_demo.py;
+tests/golden/demo_data holds the same input files)."""
+import os
+
+import numpy as np
+
+from mvsmplfitting_amd import batch
+from mvsmplfitting_amd import io_formats as iof
+from tests.helpers import GOLD
+
+DATA = os.path.join(GOLD, 'demo_data')
+
+
+def test_folder_inputs_equal_the_reference_demo():
+    g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
+    serials = batch.list_frames(os.path.join(DATA, 'keypoints'))
+    assert [(s, c, [f for f, _ in fr]) for s, c, fr in serials] == [('0000', ['Camera%02d' % v for v in range(6)], ['00001'])]
+    kp = batch.load_serial(serials[0][2], 6)
+    assert np.array_equal(kp[0], g['keypoints'].reshape(6, 17, 3))
+    extris, intris = iof.load_camera_para(os.path.join(DATA, '3DOH50K_Parameters.txt'))
+    assert np.array_equal(extris, g['extris']) and np.array_equal(intris, g['intris'])
+    # the problem tensors the driver hands to the engine = the reference's camera / target tensors of the demo
+    # (model_type 'smpllsp' -> pose_format 'lsp14' with use_hip: all 17 joint weights are 1, init.py:63-69)
+    assert np.array_equal(kp[0, :, :, :2], g['gt_xy'].reshape(6, 17, 2))
+    assert np.array_equal(kp[0, :, :, 2], g['conf'].reshape(6, 17))
+    assert np.allclose(extris[:, :3, :3], g['cam_R']) and np.allclose(extris[:, :3, 3], g['cam_t'])
+    assert np.allclose(intris[:, 0, 0], g['cam_f']) and np.allclose(intris[:, :2, 2], g['cam_c'])
+
+
+def test_missing_view_and_ragged_frames(tmp_path):
+    """A frame that one camera has no file for, and a camera folder with an extra frame."""
+    import shutil
+    root = tmp_path / 'keypoints' / 'seq'
+    src = os.path.join(DATA, 'keypoints', '0000')
+    for v in range(3):
+        (root / ('Camera%02d' % v)).mkdir(parents=True)
+        for fn in ('00001', '00002'):
+            if v == 1 and fn == '00002':
+                continue
+            shutil.copy(os.path.join(src, 'Camera%02d' % v, '00001_keypoints.json'), root / ('Camera%02d' % v) / (fn + '_keypoints.json'))
+    (serial, cams, frames), = batch.list_frames(str(tmp_path / 'keypoints'))
+    assert serial == 'seq' and len(cams) == 3 and [f for f, _ in frames] == ['00001', '00002']
+    assert frames[1][1][1] is None and frames[1][1][0] is not None
+    kp = batch.load_serial(frames, 3)
+    assert kp.shape == (2, 3, 17, 3) and np.all(kp[1, 1] == 0) and np.array_equal(kp[1, 0], kp[0, 0])

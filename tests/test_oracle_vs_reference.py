@@ -70,3 +70,20 @@ def test_triangulation_oracle_equals_reference_recompute3D():
             ref = recompute3D(list(extris), list(intris), [kps[b, v][None].copy() for v in range(V)])
             assert np.abs(tn.recompute3d(extris, intris, kps[b]) - ref).max() <= 1e-12
 
+
+
+def test_oracle_full_pose_against_reference_golden():
+    """The NumPy restatement's VPoser decode + full_pose against ModelOutput.full_pose recorded from the reference
+    (tests/golden/full_pose.npz; oracle/make_golden_full_pose.py)."""
+    import os
+    from mvsmplfitting_amd import synthetic as syn
+    from tests.helpers import GOLD, body_model, oracle_for
+    g = dict(np.load(os.path.join(GOLD, 'full_pose.npz')))
+    real = dict(np.load(os.path.join(GOLD, 'vposer_poser_epoch091_decoder.npz')))
+    real = {k: real[k] for k in ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'out_w', 'out_b')}
+    for name, vpw in (('real', real), ('wild', syn.make_vposer_decoder(seed=2, gain=1.0, identity_bias=False))):
+        orc = oracle_for(body_model(0, 4), vpw, None)
+        for x, ref in zip(g[name + '_x'], g[name + '_full_pose']):
+            out = orc.body(dict(betas=x[0:10], global_orient=x[10:13], transl=x[13:16], scale=x[16], pose_embedding=x[17:49]),
+                           want_cache=False)
+            assert np.abs(out['full_pose'] - ref).max() < 1e-12
