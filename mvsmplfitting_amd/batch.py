@@ -87,8 +87,8 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
     try:
         for serial, cams, frames in list_frames(keyp_root):
             V, F = len(cams), len(frames)
-            if F == 0 or V < 2:
-                continue                                            # the single-view depth guess is not mirrored
+            if F == 0 or V < 1:
+                continue
             kp = load_serial(frames, V)
             ex, it = np.asarray(extris[:V], np.float64), np.asarray(intris[:V], np.float64)
             rig = (ex[:, :3, :3].astype(np.float32), ex[:, :3, 3].astype(np.float32),

@@ -45,18 +45,46 @@ def rest_keypoints(engine: MvFit, scale: float = 1.0) -> torch.Tensor:
     return joints[0].to(torch.float64)
 
 
+def single_view_joints3d(rest, extri, intri, keypoints) -> torch.Tensor:
+    """The depth guess for single-view input (init_guess.py:54-72), batched over frames: the rest-pose keypoints pushed
+    along the camera's z axis by est_d = fx * (torso height in 3-D) / (torso height in the image), where the 3-D height
+    is the mean of the two shoulder-hip distances and the 2-D one - as the reference computes it (:65) - the LEFT
+    shoulder-hip distance taken twice, over the (u, v, confidence) rows.  rest [17,3] float64 tensor, extri [4,4], intri
+    [3,3], keypoints [B,17,3]
+    -> [B,17,3] float64 on rest's device."""
+    dev = rest.device
+    E = torch.as_tensor(np.asarray(extri, np.float64), dtype=torch.float64, device=dev)
+    fx = float(np.asarray(intri, np.float64)[0, 0])
+    kp = torch.as_tensor(np.asarray(keypoints, np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints,
+                         dtype=torch.float32, device=dev)
+    rest_h = torch.cat([rest.to(torch.float64), torch.ones(rest.shape[0], 1, dtype=torch.float64, device=dev)], 1)   # [17,4]
+    cam = E @ rest_h.T                                                          # [4,17] camera coordinates of the rest pose
+    t3 = cam[:3, list(TORSO)].T                                                 # [4,3]
+    h3 = 0.5 * ((t3[0] - t3[2]).norm() + (t3[1] - t3[3]).norm())
+    # rows (u, v, confidence) like :58 - the confidence difference is in the norm - and in float32 like the reference's
+    # keypoint arrays; the mean of the same distance twice (:65-66) is that distance
+    d2 = kp[:, TORSO[0], :] - kp[:, TORSO[2], :]
+    h2 = torch.sqrt(d2[:, 0] * d2[:, 0] + d2[:, 1] * d2[:, 1] + d2[:, 2] * d2[:, 2]).to(torch.float64)
+    est_d = fx * (h3 / h2)                                                      # [B]
+    camb = cam.unsqueeze(0).repeat(kp.shape[0], 1, 1)
+    camb[:, 2, :] += est_d[:, None]
+    return (torch.linalg.inv(E) @ camb).transpose(1, 2)[:, :, :3].contiguous()
+
+
 def init_guess_batch(engine: MvFit, extris, intris, keypoints, est_scale=True, fixed_scale=None, use_torso=True,
                      joints3d=None) -> dict:
     """init_guess (init_guess.py:18-106) for B frames: keypoints [B, V, 17, 3] (u, v, confidence), extris [V,4,4],
     intris [V,3,3] float64.  ``joints3d`` [B,17,3] replaces the triangulation (use_3d, :84-85).  Returns
     dict(global_orient [B,3], transl [B,3], scale [B], joints3d [B,17,3]) float64 tensors on the device."""
     kp = np.asarray(keypoints, np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints
-    if kp.shape[1] < 2 and joints3d is None:
-        raise NotImplementedError('single-view depth guess (init_guess.py:54-78) is not mirrored')
     s0 = 1.0 if fixed_scale is None else float(fixed_scale)                      # :24
     rest = rest_keypoints(engine, s0)
-    j3 = engine.triangulate(kp, intris, extris) if joints3d is None else \
-        torch.as_tensor(np.asarray(joints3d, np.float64), dtype=torch.float64, device=engine.device)
+    if joints3d is not None:
+        j3 = torch.as_tensor(np.asarray(joints3d, np.float64), dtype=torch.float64, device=engine.device)
+    elif kp.shape[1] == 1:
+        j3 = single_view_joints3d(rest, extris[0], intris[0], kp[:, 0])
+    else:
+        j3 = engine.triangulate(kp, intris, extris)
     idx = list(TORSO) if use_torso else list(range(17))
     out = engine.umeyama(rest[idx], j3[:, idx].contiguous(), estimate_scale=est_scale)
     scale = out['scale'] if est_scale else torch.full_like(out['scale'], s0)     # :98-101
@@ -80,4 +108,5 @@ def initial_params(guess: dict, use_vposer: bool, fixed_shape=None) -> torch.Ten
     return x
 
 
-__all__ = ['recompute3D', 'recompute3D_batch', 'rest_keypoints', 'init_guess_batch', 'initial_params', 'TORSO']
+__all__ = ['recompute3D', 'recompute3D_batch', 'rest_keypoints', 'single_view_joints3d', 'init_guess_batch', 'initial_params',
+           'TORSO']

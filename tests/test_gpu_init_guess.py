@@ -62,3 +62,29 @@ def test_batched_initial_guess_is_per_frame():
         for k in ('global_orient', 'transl', 'scale'):
             assert np.array_equal(one[k][0].cpu().numpy(), all_[k][b].cpu().numpy()), (b, k)
     eng.close()
+
+
+def test_single_view_guess_and_fit():
+    """One camera only (init_guess.py:54-72): the depth guess equals its restatement, and the staged single-view fit
+    started from it ends far below its start.  (parity of this branch is unpinned: the reference's init_guess cannot
+    run in the build container, oracle/init_guess_np.py.)"""
+    from mvsmplfitting_amd.engine import stage_weights
+    from oracle import init_guess_np as ign
+    g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
+    eng = make_engine(body_model())
+    kp6 = g['keypoints'].reshape(6, 17, 3).astype(np.float32)
+    kps = np.stack([kp6[0], kp6[3]])[:, None]                               # two "frames" seen by camera 0 only: [2, 1, 17, 3]
+    cams = tuple(g[k][:1].astype(np.float32) for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'))
+    eng.set_problems(cams, kps[..., :2], kps[..., 2])
+    out = ig.init_guess_batch(eng, g['extris'][:1], g['intris'][:1], kps, est_scale=True, use_torso=True)
+    rest = ig.rest_keypoints(eng).cpu().numpy()
+    for b in range(2):
+        ref = ign.single_view_joints3d(rest, g['extris'][0], g['intris'][0], kps[b, 0])
+        assert np.abs(out['joints3d'][b].cpu().numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+    x0 = ig.initial_params(out, use_vposer=False)
+    stages = stage_weights(1536.0, flags=0)
+    l0 = eng.closure(x0, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
+    xf, st = eng.fit(x0, stages)
+    final = st['final_loss'].cpu().numpy()
+    assert np.all(np.isfinite(final)) and np.all(final < 0.5 * l0), (final, l0)
+    eng.close()

@@ -75,3 +75,21 @@ def test_gpu_umeyama_equals_restatement_for_one_sign_pattern():
                 assert abs(np.linalg.det(rot[b]) - 1) < 1e-9
                 assert np.abs(rvec[b] - un.rotvec(rot[b])).max() < 1e-9
     eng.close()
+
+
+def test_single_view_depth_guess_equals_its_restatement():
+    """init_guess.single_view_joints3d (batched, torch) against the line-by-line NumPy restatement of
+    init_guess.py:54-72 on the demo's first camera and keypoints."""
+    import os
+    import torch
+    from mvsmplfitting_amd.init_guess import single_view_joints3d
+    from oracle import init_guess_np as ig
+    from tests.helpers import GOLD
+    g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
+    rest = g['init_joints_rest']
+    kp = g['keypoints'].reshape(6, 17, 3)
+    frames = np.stack([kp[0], kp[0] * np.array([0.9, 1.1, 1.0], np.float32), kp[2]])
+    out = single_view_joints3d(torch.as_tensor(rest, dtype=torch.float64), g['extris'][0], g['intris'][0], frames).numpy()
+    for b in range(3):
+        ref = ig.single_view_joints3d(rest, g['extris'][0], g['intris'][0], frames[b])
+        assert np.abs(out[b] - ref).max() < 1e-9 * np.abs(ref).max()
