@@ -63,9 +63,29 @@ def load_serial(frames, num_views, person=0):
     return kp
 
 
+def load_serial_joints3d(frames, person=0):
+    """use_3d annotation (data_parser.py:396-400): per frame the 'pose_keypoints_3d' of the FIRST camera that has a file,
+    [F, 17, 4] = (x, y, z, confidence) float32, and a mask of the frames that carry one."""
+    j3 = np.zeros((len(frames), 17, 4), np.float32)
+    has = np.zeros(len(frames), bool)
+    for f, (_, paths) in enumerate(frames):
+        for p in paths:
+            if p is None:
+                continue
+            try:
+                people = iof.read_joints3d(p)
+            except KeyError:                                   # no 3-D annotation in this file (the reference: None)
+                break
+            if len(people) > person:
+                j3[f] = people[person][:17]
+                has[f] = True
+            break
+    return j3, has
+
+
 def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, image_height=1536.0, is_seq=False,
-               pose_format='lsp14', use_hip=True, fix_scale=None, fix_shape=None, save_meshes=False, mesh_folder=None,
-               device=0, stages=None, engine: MvFit | None = None):
+               pose_format='lsp14', use_hip=True, use_3d=False, fix_scale=None, fix_shape=None, save_meshes=False,
+               mesh_folder=None, device=0, stages=None, engine: MvFit | None = None):
     """Fits every frame under keyp_root and writes the reference's result files.  Returns
     {serial: dict(frames, params [F,118], final_loss [F], n_closure [F], files [F], init [F,118], restarted [F]:
     frames fitted from their own initial guess - all of them unless is_seq)}."""
@@ -76,8 +96,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
         flags |= _lib.F_FIX_SCALE
     if fix_shape is not None:
         flags |= _lib.F_FIX_SHAPE
-    if stages is None:
-        stages = stage_weights(float(image_height), flags=flags)
+    user_stages = stages
     own = engine is None
     eng = engine if engine is not None else MvFit(model, vposer=vposer, device=device)
     jw = np.ones(17, np.float32)
@@ -96,10 +115,25 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
             gt_xy = kp[..., :2].copy()
             conf = kp[..., 2] * jw[None, None, :]
             eng.set_problems(rig, gt_xy, conf)
-            guess = init_guess_batch(eng, ex, it, kp, est_scale=fix_scale is None, fixed_scale=fix_scale)
+            j3 = t3 = None
+            if use_3d:
+                # 3-D joint targets (non_linear_solver.py:86-99) and the initial alignment to them instead of the
+                # triangulation (init_guess.py:84-85); a serial with a frame that has no annotation falls back to 2-D only
+                # (the reference decides per frame, :68-69; a batched fit has one objective)
+                ann, has = load_serial_joints3d(frames)
+                if has.all():
+                    c3 = ann[:, :, 3].copy()
+                    if not use_hip:
+                        c3[:, 11] = c3[:, 12] = 0.0
+                    eng.set_joints3d(ann[:, :, :3], c3)
+                    j3 = ann[:, :, :3].astype(np.float64)
+                    t3 = (ann[None, :, :, :3], c3[None])
+            guess = init_guess_batch(eng, ex, it, kp, est_scale=fix_scale is None, fixed_scale=fix_scale, joints3d=j3)
             x0 = initial_params(guess, use_vposer, fixed_shape=fix_shape)
+            stages = user_stages if user_stages is not None else \
+                stage_weights(float(image_height), flags=flags | (_lib.F_USE_3D if j3 is not None else 0))
             if is_seq:
-                xs, st = fit_sequences(eng, rig, gt_xy[None], conf[None], x0[None], stages)
+                xs, st = fit_sequences(eng, rig, gt_xy[None], conf[None], x0[None], stages, joints3d=t3)
                 xf, final, ncl = xs[0], st['final_loss'][0], st['n_closure'][0]
                 restarted = st['restarted'][0]
                 eng.set_problems(rig, gt_xy, conf)                  # back to the whole serial for the outputs below
@@ -107,7 +141,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                 xf, st = eng.fit(x0, stages)
                 final, ncl = st['final_loss'], st['n_closure']
                 restarted = np.ones(F, bool)
-            full = eng.full_pose(xf, flags=flags).cpu().numpy()
+            full = eng.full_pose(xf, flags=flags & ~_lib.F_USE_3D).cpu().numpy()
             xf_h, final_h = xf.cpu().numpy(), final.cpu().numpy()
             res = [iof.result_dict(xf_h[f], loss=final_h[f], body_pose_decoded=full[f, 3:] if use_vposer else None)
                    for f in range(F)]

@@ -30,9 +30,10 @@ def sequence_stages(stages):
     return out
 
 
-def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, **fit_kw):
+def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, joints3d=None, **fit_kw):
     """gt_xy [S, T, V, 17, 2], w_conf [S, T, V, 17]: S sequences of T frames of one rig (or per-sequence cameras
     [S, V, ...]); x_init [S, T, 118]: the full initial guess of every frame (used for frame 0 and after a restart).
+    joints3d = (gt3d [S, T, 17, 3], conf3d [S, T, 17]): the use_3d targets of every frame (stages carrying F_USE_3D).
     Returns (x [S, T, 118] tensor, dict(final_loss [S, T], n_closure [S, T], restarted [S, T] bool))."""
     gt = np.asarray(gt_xy, np.float32)
     wc = np.asarray(w_conf, np.float32)
@@ -57,6 +58,8 @@ def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, **fit_kw):
                 continue
             cam_sel = tuple(np.asarray(c)[sel] for c in cams) if np.ndim(cams[0]) == 4 else cams
             engine.set_problems(cam_sel, gt[sel, t], wc[sel, t])
+            if joints3d is not None:
+                engine.set_joints3d(np.asarray(joints3d[0], np.float32)[sel, t], np.asarray(joints3d[1], np.float32)[sel, t])
             idx = torch.as_tensor(sel, device=engine.device)
             if stg is stages:
                 x0 = xi[idx, t]

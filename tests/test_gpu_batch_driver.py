@@ -75,3 +75,53 @@ def test_sequence_folder(tmp_path):
     assert np.all(r['restarted'])
     assert np.array_equal(r['params'][1], r['params'][0]) and r['n_closure'][1] == r['n_closure'][0]
     assert not np.array_equal(r['params'][2], r['params'][0])
+
+
+def test_synthetic_folder_with_3d_annotation(tmp_path):
+    """A synthetic serial written in the reference's file formats (camera text file, keypoint json with
+    'pose_keypoints_2d' and 'pose_keypoints_3d'): 3 frames x 4 views, fitted with use_3d - the 3-D targets drive the
+    initial alignment (init_guess.py:84-85) and the D3 term - and as a sequence."""
+    import json
+    from mvsmplfitting_amd import synthetic as syn
+    from tests.gpu_helpers import make_engine
+    model = body_model()
+    V, F = 4, 3
+    cams = syn.make_camera_ring(V)
+    eng = make_engine(model)
+    fr = syn.make_frames(F, seed0=50)
+    xgt = np.zeros((F, 118), np.float32)
+    for k, (a, b) in dict(betas=(0, 10), global_orient=(10, 13), body_pose=(13, 82), transl=(82, 85), scale=(85, 86)).items():
+        xgt[:, a:b] = fr[k]
+    eng.set_problems(cams, np.zeros((F, V, 17, 2), np.float32), np.ones((F, V, 17), np.float32))
+    _, joints = eng.vertices(xgt)
+    joints = joints.cpu().numpy()
+    gt, conf = syn.make_observations(joints, cams, seed=5)
+    # the camera file: three 3-number rows of K and three 4-number rows of [R|t] per camera (utils.py:352-394)
+    cam_R, cam_t, cam_f, cam_c = (np.asarray(a, np.float64) for a in cams)
+    with open(tmp_path / 'cams.txt', 'w') as fh:
+        for v in range(V):
+            fh.write('%d\n' % v)
+            K = np.array([[cam_f[v], 0, cam_c[v, 0]], [0, cam_f[v], cam_c[v, 1]], [0, 0, 1]])
+            for r in K:
+                fh.write(' '.join('%.10f' % x for x in r) + '\n')
+            fh.write('0 0\n')
+            for r in np.hstack([cam_R[v], cam_t[v][:, None]]):
+                fh.write(' '.join('%.10f' % x for x in r) + '\n')
+    for v in range(V):
+        d = tmp_path / 'keypoints' / 's0' / ('Camera%02d' % v)
+        d.mkdir(parents=True)
+        for f in range(F):
+            k2 = np.concatenate([gt[f, v], conf[f, v][:, None]], 1).reshape(-1)
+            k3 = np.concatenate([joints[f], np.ones((17, 1), np.float32)], 1).reshape(-1)
+            with open(d / ('%05d_keypoints.json' % f), 'w') as fh:
+                json.dump(dict(version=1.0, people=[dict(pose_keypoints_2d=[float(x) for x in k2],
+                                                         pose_keypoints_3d=[float(x) for x in k3])]), fh)
+    for seq in (False, True):
+        out = batch.fit_folder(model, str(tmp_path / 'keypoints'), str(tmp_path / 'cams.txt'), str(tmp_path / ('res%d' % seq)),
+                               use_3d=True, is_seq=seq, engine=eng)['s0']
+        assert out['frames'] == ['%05d' % f for f in range(F)] and all(os.path.exists(p) for p in out['files'])
+        # with exact 3-D targets the alignment starts next to the truth and the fit recovers the root translation
+        assert np.abs(out['init'][:, 82:85] - xgt[:, 82:85]).max() < 0.25
+        assert np.abs(out['params'][:, 82:85] - xgt[:, 82:85]).max() < 0.05
+        assert np.all(np.isfinite(out['final_loss']))
+    eng.close()
