@@ -117,3 +117,43 @@ class StubMvFit:
                 ncl[b] += opt.func_evals
                 nit[b] += opt.n_iter
         return torch.tensor(x), dict(final_loss=torch.tensor(final), n_closure=torch.tensor(ncl), n_iter=torch.tensor(nit))
+
+    # ---- the rows either side of the path, answered by the oracle restatements (batch driver host-logic tests) ----
+    def _params(self, x118, flags):
+        x = np.asarray(x118.detach().cpu().numpy() if isinstance(x118, torch.Tensor) else x118, np.float64)
+        p = dict(betas=x[0:10], global_orient=x[10:13], body_pose=x[13:82], transl=x[82:85], scale=x[85])
+        if flags & _lib.F_VPOSER:
+            p['pose_embedding'] = x[86:118]
+        return p
+
+    def vertices(self, params, flags=0):
+        x = np.asarray(params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else params, np.float64)
+        outs = [self.orc.body(self._params(r, int(flags)), want_cache=False) for r in x]
+        return (torch.tensor(np.stack([o['vertices'] for o in outs]), dtype=torch.float32),
+                torch.tensor(np.stack([o['joints'] for o in outs]), dtype=torch.float32))
+
+    def full_pose(self, params, flags=0):
+        x = np.asarray(params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else params, np.float64)
+        return torch.tensor(np.stack([self.orc.body(self._params(r, int(flags)), want_cache=False)['full_pose'] for r in x]),
+                            dtype=torch.float32)
+
+    def triangulate(self, keypoints, intris, extris):
+        from oracle import triangulate_np as tn
+        kp = np.asarray(keypoints)
+        return torch.tensor(np.stack([tn.recompute3d(extris, intris, kp[b]) for b in range(kp.shape[0])]))
+
+    def umeyama(self, src, dst, estimate_scale=True):
+        from oracle import umeyama_np as un
+        src = np.asarray(src.cpu().numpy() if isinstance(src, torch.Tensor) else src, np.float64)
+        dst = np.asarray(dst.cpu().numpy() if isinstance(dst, torch.Tensor) else dst, np.float64)
+        rot, tr, sc = [], [], []
+        for b in range(dst.shape[0]):
+            r, t, s_, _ = un.umeyama(src, dst[b], estimate_scale)
+            rot.append(r); tr.append(t); sc.append(s_)
+        rot = np.stack(rot)
+        return dict(rot=torch.tensor(rot), rvec=torch.tensor(np.stack([un.rotvec(r) for r in rot])),
+                    trans=torch.tensor(np.stack(tr)), scale=torch.tensor(np.asarray(sc, np.float64)))
+
+    def close(self):
+        pass
+

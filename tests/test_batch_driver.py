@@ -44,3 +44,33 @@ def test_missing_view_and_ragged_frames(tmp_path):
     assert frames[1][1][1] is None and frames[1][1][0] is not None
     kp = batch.load_serial(frames, 3)
     assert kp.shape == (2, 3, 17, 3) and np.all(kp[1, 1] == 0) and np.array_equal(kp[1, 0], kp[0, 0])
+
+
+def test_fit_folder_host_logic_on_the_demo_folder(tmp_path):
+    """fit_folder end to end on CPU: the engine is the recording stub that answers with the float64 oracle (tests only; there
+    is no GPU in the build container), everything else - folder walk, initial guess plumbing, stage weights, result
+    dictionaries, the reference's file layout - is the shipped code.  The fitted parameters equal the reference-recorded
+    demo fit's quality (its float64 run ends at fit_final64)."""
+    import pickle
+    from tests.helpers import body_model
+    from tests.stub_engine import StubMvFit
+    g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
+    d = dict(np.load(os.path.join(GOLD, 'vposer_poser_epoch091_decoder.npz')))
+    vpw = {k: d[k] for k in ('fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'out_w', 'out_b')}
+    model = body_model()
+    eng = StubMvFit(model, vposer=vpw)
+    out = batch.fit_folder(model, os.path.join(DATA, 'keypoints'), os.path.join(DATA, '3DOH50K_Parameters.txt'),
+                           str(tmp_path / 'results'), vposer=vpw, image_height=1536.0, engine=eng)['0000']
+    # the initial guess equals the reference's own (same LAPACK behind the restatement and the reference): x0 of the golden
+    ref0 = g['x0']
+    x0 = out['init'][0]
+    assert np.abs(x0[10:13] - ref0[10:13]).max() < 1e-5 and np.abs(x0[82:85] - ref0[13:16]).max() < 1e-4
+    assert abs(x0[85] - ref0[16]) < 1e-5 * abs(ref0[16])
+    # float64 oracle optimiser from the same start on the same objective: the reference's float64 fit
+    assert abs(out['final_loss'][0] - float(g['fit_final64'])) <= 0.02 * float(g['fit_final64'])
+    with open(out['files'][0], 'rb') as f:
+        res = pickle.load(f)
+    assert out['files'][0] == str(tmp_path / 'results' / '0000' / '00001' / '000.pkl')
+    assert set(res) == {'betas', 'global_orient', 'transl', 'scale', 'loss', 'pose_embedding', 'body_pose', 'pose'}
+    bp = res['body_pose'][0]
+    assert np.all(bp[18:24] == 0) and np.all(bp[27:33] == 0) and np.all(bp[57:] == 0) and np.any(bp[:18] != 0)
