@@ -291,6 +291,7 @@ def main():
     finals = None
     gathered = None
     n_max = 0
+    counts = []
     passes = None
     busy = 0.0
     for _ in range(args.steps):
@@ -299,13 +300,15 @@ def main():
         busy += time.perf_counter() - tb
         if world > 1:
             gathered = gather_results(xf, total)   # the path's only collective (RCCL over xGMI), inside the step
-        n_closure += int(st['n_closure'].sum().item())      # tiny D2H per step, after the fit finished
-        n_iter += int(st['n_iter'].sum().item())
-        n_max = int(st['n_closure'].max().item())
+        counts.append((st['n_closure'], st['n_iter']))      # device tensors: read after the timed region
         finals = st['final_loss']
         passes = st.get('passes')
     barrier()
     dt = time.perf_counter() - t0
+    for ncl_t, nit_t in counts:
+        n_closure += int(ncl_t.sum().item())
+        n_iter += int(nit_t.sum().item())
+    n_max = int(counts[-1][0].max().item())
 
     # max-over-ranks time, totals, per-rank busy time
     tot_closure, tot_iter, tmax = n_closure, n_iter, dt
