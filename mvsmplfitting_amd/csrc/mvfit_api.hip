@@ -1371,8 +1371,8 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         if (*h_done >= B) break;
         if ((k + 1) * kPassBatch >= cap) break;
     }
-    HIP_OK(c, hipStreamSynchronize(c->stream));                        // the optimiser kernel (all problems, or the round cap)
-    // the ctx stream continues behind the last passes (nothing of the fit's result depends on them: ordering only)
+    // behind the optimiser kernel (all problems, or the round cap) the ctx stream continues behind the last passes
+    // (nothing of the fit's result depends on them: ordering only); one host wait for all of it below
     HIP_OK(c, hipStreamWaitEvent(c->stream, c->ev_batch[k & 3], 0));
     HIP_OK(c, hipMemcpyAsync(c->async_stats, R.stats, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipMemcpyAsync(c->h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
