@@ -108,6 +108,8 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
             V, F = len(cams), len(frames)
             if F == 0 or V < 1:
                 continue
+            if V > len(extris):
+                raise ValueError('serial %s has %d camera folders, the camera file %s holds %d cameras' % (serial, V, cam_file, len(extris)))
             kp = load_serial(frames, V)
             ex, it = np.asarray(extris[:V], np.float64), np.asarray(intris[:V], np.float64)
             rig = (ex[:, :3, :3].astype(np.float32), ex[:, :3, 3].astype(np.float32),

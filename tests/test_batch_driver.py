@@ -74,3 +74,18 @@ def test_fit_folder_host_logic_on_the_demo_folder(tmp_path):
     assert set(res) == {'betas', 'global_orient', 'transl', 'scale', 'loss', 'pose_embedding', 'body_pose', 'pose'}
     bp = res['body_pose'][0]
     assert np.all(bp[18:24] == 0) and np.all(bp[27:33] == 0) and np.all(bp[57:] == 0) and np.any(bp[:18] != 0)
+
+
+def test_more_camera_folders_than_cameras_is_an_error(tmp_path):
+    import shutil
+    import pytest
+    from tests.helpers import body_model
+    from tests.stub_engine import StubMvFit
+    root = tmp_path / 'keypoints' / 's'
+    for v in range(7):
+        (root / ('Camera%02d' % v)).mkdir(parents=True)
+        shutil.copy(os.path.join(DATA, 'keypoints', '0000', 'Camera00', '00001_keypoints.json'), root / ('Camera%02d' % v) / '00001_keypoints.json')
+    model = body_model()
+    with pytest.raises(ValueError):
+        batch.fit_folder(model, str(tmp_path / 'keypoints'), os.path.join(DATA, '3DOH50K_Parameters.txt'), str(tmp_path / 'r'),
+                         engine=StubMvFit(model))
