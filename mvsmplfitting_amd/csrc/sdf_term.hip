@@ -5,7 +5,9 @@
 //   phi = SDF(faces, (v-c)/s, G) (:361-369) and phi_v = grid_sample(phi, (v-c)/s) (:375-383)
 //                                      ->  sdf_sample_kernel    thread per (problem, vertex)
 //   adjoint of S = sum_v phi_v w.r.t. the pose operands of the vertex pass
-//                                      ->  sdf_adjoint_kernel   one workgroup per problem
+//                                      ->  sdf_entries_kernel   8 workgroups per problem: S, box-adjoint sums, entry lists
+//                                          sdf_pullback_kernel  8 workgroups per problem: entries through skinning / basis
+//                                          sdf_reduce_kernel    slice partials in slice order
 //
 // The reference voxelises G^3 = 2 M voxels per closure and then samples 6890 x 8 of them; phi is a pure
 // function of the voxel index, so the sample kernel evaluates exactly those <= 55 k voxels on the fly with the
@@ -223,51 +225,57 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
 struct SdfEntry { int v; float g[3]; };                                  // vertex, dS/dvertex
 static_assert(sizeof(SdfEntry) == 16, "entry layout");
 
-constexpr int SDF_NIT = 16;          // 64-vertex rows per wave: nv <= 8 * 16 * 64
+constexpr int SDF_NC = 8;            // vertex chunks per problem in the entry kernel (one workgroup each)
+constexpr int SDF_NIT = 2;           // 64-vertex rows per wave of a chunk: nv <= SDF_NC * 8 waves * SDF_NIT * 64 = 8192
 
-// per problem: entries in the list, S = sum_v phi_v
-struct SdfHead { int n; float S; int pad0, pad1; };
+// per (problem, vertex chunk): partial sums of S and of the box adjoint, entries written (at the chunk's own offset)
+struct SdfChunk { double S, gc0, gc1, gc2, gs; int cnt, pad; };
+static_assert(sizeof(SdfChunk) == 48, "chunk record");
 #ifndef SDF_NS_
 #define SDF_NS_ 8
 #endif
 constexpr int SDF_NS = SDF_NS_;      // workgroups (entry slices) per problem in the pull-back
 
-// Kernel 1 of the adjoint, one workgroup per problem: S, the box adjoint and the entry list.
+// Kernel 1 of the adjoint, grid (SDF_NC, B): a workgroup scans one eighth of a problem's vertices (the whole list
+// through one CU took 9 us): partial S and box-adjoint sums in float64, and the chunk's entries - the vertices that carry
+// gradient plus the box's arg-min / arg-max vertices - compacted in ascending order at the chunk's offset of the entry
+// buffer, with the gradient of the sampling only (the box adjoint needs the sums of ALL chunks: sdf_pullback_kernel
+// adds it when it loads an entry).
 __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const float* __restrict__ verts,
                                                                  const SdfBox* __restrict__ box, const float4* __restrict__ samp,
                                                                  const int* __restrict__ gate,
-                                                                 SdfEntry* __restrict__ entries, SdfHead* __restrict__ head) {
+                                                                 SdfEntry* __restrict__ entries, SdfChunk* __restrict__ chunks) {
     __shared__ double sh_d[8][5];
     __shared__ int sh_cnt[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
     const SdfBox bx = box[b];
     const float* vb = verts + (size_t)b * nv * 3;
     const float4* sb = samp + (size_t)b * nv;
-    SdfEntry* eb = entries + (size_t)b * nv;
-    // ---- pass A: every wave owns an ascending chunk of vertices, 64 per row; everything stays in registers ----
-    const int chunk = (nv + 7) / 8, c0 = wave * chunk, c1 = min(nv, c0 + chunk);
+    const int csz = (nv + SDF_NC - 1) / SDF_NC, k0 = y * csz, k1 = min(nv, k0 + csz);
+    SdfEntry* eb = entries + (size_t)b * nv + k0;
+    // ---- pass A: every wave owns an ascending run of the chunk, 64 vertices per row; everything stays in registers ----
+    const int wsz = (csz + 7) / 8, c0 = k0 + wave * wsz, c1 = min(k1, c0 + wsz);
     float4 q[SDF_NIT];
     double S = 0.0, gc0 = 0.0, gc1 = 0.0, gc2 = 0.0, gs = 0.0;
     unsigned actmask = 0;
     int cnt = 0;
+    {
+        float px[SDF_NIT], py[SDF_NIT], pz[SDF_NIT];
 #pragma unroll
-    for (int h = 0; h < SDF_NIT; h += 8) {             // 8 rows (32 loads) in flight at a time
-        float px[8], py[8], pz[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int v = c0 + (h + i) * 64 + lane;
+        for (int i = 0; i < SDF_NIT; ++i) {
+            const int v = c0 + i * 64 + lane;
             const bool in = v < c1;
-            const int vc = in ? v : c0;
-            q[h + i] = sb[vc];
+            const int vc = in ? v : k0;
+            q[i] = sb[vc];
             px[i] = vb[3 * vc]; py[i] = vb[3 * vc + 1]; pz[i] = vb[3 * vc + 2];
-            if (!in) q[h + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int v = c0 + (h + i) * 64 + lane;
+        for (int i = 0; i < SDF_NIT; ++i) {
+            const int v = c0 + i * 64 + lane;
             const bool in = v < c1;
-            const float4 qq = q[h + i];
+            const float4 qq = q[i];
             S += (double)qq.x;
             bool act = (qq.y != 0.f) | (qq.z != 0.f) | (qq.w != 0.f);
             if (act) {                                  // rare: only vertices next to a non-zero voxel
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
             }
             act |= (v == bx.imin[0]) | (v == bx.imin[1]) | (v == bx.imin[2]) | (v == bx.imax[0]) | (v == bx.imax[1]) | (v == bx.imax[2]);
             act &= in;
-            if (act) actmask |= 1u << (h + i);
+            if (act) actmask |= 1u << i;
             cnt += __popcll(__ballot(act));
         }
     }
@@ -291,35 +299,34 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
         if (w < wave) base += sh_cnt[w];
         n += sh_cnt[w];
     }
-    // ---- pass B: dS/dvertex of the active vertices -> entry list (ballot compaction, ascending order) ----
-    const float gcf[3] = {(float)gc0, (float)gc1, (float)gc2};
-    const float gsf = (float)gs * (float)((1 + 0.2) * 0.5);
+    // ---- pass B: the chunk's entries (ballot compaction, ascending order) ----
 #pragma unroll
     for (int i = 0; i < SDF_NIT; ++i) {
         const int v = c0 + i * 64 + lane;
         const bool act = (actmask >> i) & 1u;
         const unsigned long long bal = __ballot(act);
         if (act) {
-            float g[3] = {q[i].y / bx.s, q[i].z / bx.s, q[i].w / bx.s};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (v == bx.imin[a]) { g[a] += gcf[a] / 2.f; if (a == bx.amax) g[a] -= gsf; }
-                if (v == bx.imax[a]) { g[a] += gcf[a] / 2.f; if (a == bx.amax) g[a] += gsf; }
-            }
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            *reinterpret_cast<float4*>(&eb[pos]) = make_float4(__builtin_bit_cast(float, v), g[0], g[1], g[2]);
+            *reinterpret_cast<float4*>(&eb[pos]) = make_float4(__builtin_bit_cast(float, v), q[i].y / bx.s, q[i].z / bx.s, q[i].w / bx.s);
         }
         base += __popcll(bal);
     }
-    if (tid == 0) { SdfHead h; h.n = n; h.S = (float)S; h.pad0 = h.pad1 = 0; head[b] = h; }
+    if (tid == 0) {
+        SdfChunk c;
+        c.S = S; c.gc0 = gc0; c.gc1 = gc1; c.gc2 = gc2; c.gs = gs; c.cnt = n; c.pad = 0;
+        chunks[(size_t)b * SDF_NC + y] = c;
+    }
 }
 
 // Kernel 2: pull-back of the entries through skinning and the blendshape basis (~5.4 KB of basis rows and weights per
 // entry: one CU ingests ~10 B/clk, so a problem's list is cut into SDF_NS contiguous slices, one workgroup each; the
 // slice partials are added in slice order by kernel 3 - deterministic).  Grid (SDF_NS, B).
 __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, DevPose P, const int* __restrict__ gate,
+                                                                  const SdfBox* __restrict__ box,
                                                                   const SdfEntry* __restrict__ entries,
-                                                                  const SdfHead* __restrict__ head, SdfAdj* __restrict__ part) {
+                                                                  const SdfChunk* __restrict__ chunks, SdfAdj* __restrict__ part) {
+    __shared__ int sh_pref[SDF_NC + 1];
+    __shared__ float sh_box[4];                                      // box adjoint: d S / d centre (3), d S / d scale
     __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
     __shared__ float sh_A[NJ * 12];
     __shared__ __attribute__((aligned(16))) SdfEntry sh_e[SDF_EB];
@@ -329,8 +336,23 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
     __shared__ float sh_gvp[SDF_EB][3];
     const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x;
     if (gate && !gate[b]) return;
-    const int ntot = head[b].n;
+    if (tid == 0) {                                                  // chunk records -> prefix of the entry counts, box adjoint
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, gs = 0.0;
+        int acc = 0;
+        for (int c = 0; c < SDF_NC; ++c) {
+            const SdfChunk ch = chunks[(size_t)b * SDF_NC + c];
+            sh_pref[c] = acc; acc += ch.cnt;
+            g0 += ch.gc0; g1 += ch.gc1; g2 += ch.gc2; gs += ch.gs;
+        }
+        sh_pref[SDF_NC] = acc;
+        sh_box[0] = (float)g0; sh_box[1] = (float)g1; sh_box[2] = (float)g2;
+        sh_box[3] = (float)gs * (float)((1 + 0.2) * 0.5);
+    }
+    __syncthreads();
+    const SdfBox bx = box[b];
+    const int ntot = sh_pref[SDF_NC];
     const int lo = (int)((long long)ntot * y / SDF_NS), n = (int)((long long)ntot * (y + 1) / SDF_NS);
+    const int csz = (M.nv + SDF_NC - 1) / SDF_NC;
     const SdfEntry* eb = entries + (size_t)b * M.nv;
     if (lo < n) {                                                    // (uniform) an empty slice writes zeros
         if (tid < KROWS) sh_coef[tid] = P.coefT[(size_t)(b >> 5) * KROWS * 32 + (size_t)tid * 32 + (b & 31)];
@@ -342,7 +364,23 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
     for (int e0 = lo; e0 < n; e0 += SDF_EB) {
         const int ne = min(SDF_EB, n - e0);
         __syncthreads();
-        if (tid < ne) reinterpret_cast<float4*>(sh_e)[tid] = reinterpret_cast<const float4*>(eb + e0)[tid];
+        if (tid < ne) {
+            // entry e0 + tid of the problem = entry (e0 + tid - prefix[c]) of chunk c; the box adjoint reaches the vertices
+            // that define the box: half of d S / d centre each, -+ d S / d scale on the largest axis (fitting.py:282-288,356-359)
+            const int idx = e0 + tid;
+            int c = 0;
+#pragma unroll
+            for (int k = 1; k < SDF_NC; ++k) c += idx >= sh_pref[k] ? 1 : 0;
+            const float4 raw = reinterpret_cast<const float4*>(eb + (size_t)c * csz)[idx - sh_pref[c]];
+            const int v = __builtin_bit_cast(int, raw.x);
+            float g[3] = {raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (v == bx.imin[a]) { g[a] += sh_box[a] / 2.f; if (a == bx.amax) g[a] -= sh_box[3]; }
+                if (v == bx.imax[a]) { g[a] += sh_box[a] / 2.f; if (a == bx.amax) g[a] += sh_box[3]; }
+            }
+            reinterpret_cast<float4*>(sh_e)[tid] = make_float4(raw.x, g[0], g[1], g[2]);
+        }
         __syncthreads();
         // v_posed = v_template + coef . basis  (lbs.py:179,203): thread per (entry, coordinate, quarter row),
         // 14 independent 16-byte loads in flight per thread
@@ -401,7 +439,7 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
 }
 
 // Kernel 3: slice partials -> the problem's adjoint, in slice order.
-__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_reduce_kernel(const int* __restrict__ gate, const SdfHead* __restrict__ head,
+__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_reduce_kernel(const int* __restrict__ gate, const SdfChunk* __restrict__ chunks,
                                                                 const SdfAdj* __restrict__ part, SdfAdj* __restrict__ out) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (gate && !gate[b]) return;
@@ -415,28 +453,33 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_reduce_kernel(const int* __res
     SdfAdj& O = out[b];
     if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
     if (tid < 3) O.gtau[tid] = gtv;
-    if (tid == 0) O.S = head[b].S;
+    if (tid == 0) {
+        double S = 0.0;
+        for (int c = 0; c < SDF_NC; ++c) S += chunks[(size_t)b * SDF_NC + c].S;
+        O.S = (float)S;
+    }
 }
 
-// work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B] SdfHead
+// work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B][SDF_NC] SdfChunk
 static size_t sdf_part_offset(int B, int nv) { return ((size_t)B * nv * sizeof(SdfEntry) + 255) & ~(size_t)255; }
-static size_t sdf_head_offset(int B, int nv) { return sdf_part_offset(B, nv) + (size_t)B * SDF_NS * sizeof(SdfAdj); }
-size_t sdf_work_bytes(int B, int nv) { return sdf_head_offset(B, nv) + (size_t)B * sizeof(SdfHead); }
+static size_t sdf_chunk_offset(int B, int nv) { return sdf_part_offset(B, nv) + (size_t)B * SDF_NS * sizeof(SdfAdj); }
+size_t sdf_work_bytes(int B, int nv) { return sdf_chunk_offset(B, nv) + (size_t)B * SDF_NC * sizeof(SdfChunk); }
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream) {
     static_assert(SDF_ADJ_NT == KROWS + NJ * 12, "thread per output of the pull-back");
     unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
     SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
-    SdfHead* head = reinterpret_cast<SdfHead*>(wk + sdf_head_offset(B, M.nv));
+    SdfChunk* chunks = reinterpret_cast<SdfChunk*>(wk + sdf_chunk_offset(B, M.nv));
+    if (M.nv > SDF_NC * 8 * SDF_NIT * 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box);
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
                        (const SdfBox*)box, faces, num_faces, G, gate, samp);
-    hipLaunchKernelGGL(sdf_entries_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
-                       (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), head);
-    hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate,
-                       reinterpret_cast<const SdfEntry*>(entries), (const SdfHead*)head, part);
-    hipLaunchKernelGGL(sdf_reduce_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, gate, (const SdfHead*)head, (const SdfAdj*)part, adj);
+    hipLaunchKernelGGL(sdf_entries_kernel, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
+                       (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), chunks);
+    hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
+                       reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part);
+    hipLaunchKernelGGL(sdf_reduce_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, gate, (const SdfChunk*)chunks, (const SdfAdj*)part, adj);
     return hipGetLastError();
 }
 
