@@ -232,7 +232,7 @@ constexpr int SDF_NIT = 2;           // 64-vertex rows per wave of a chunk: nv <
 struct SdfChunk { double S, gc0, gc1, gc2, gs; int cnt, pad; };
 static_assert(sizeof(SdfChunk) == 48, "chunk record");
 #ifndef SDF_NS_
-#define SDF_NS_ 8
+#define SDF_NS_ 8                   // (-DSDF_NS_=1 reproduces the single-chain summation order bit for bit: the control experiment)
 #endif
 constexpr int SDF_NS = SDF_NS_;      // workgroups (entry slices) per problem in the pull-back
 
