@@ -94,7 +94,7 @@ class RefProblem:
 
     def __init__(self, model: dict, cams, gt_xy, conf, dtype='float64', use_vposer=False,
                  vposer_weights=None, prior='l2', gmm=None, fix_shape=False, rho=100.0,
-                 joint_weights=None, joints3d=None):
+                 joint_weights=None, joints3d=None, interpenetration=False):
         import torch
         ref = load()
         self.ref = ref
@@ -159,7 +159,7 @@ class RefProblem:
         angle_prior = ref.prior.create_prior('angle', dtype=dt)
         self.loss = ref.fitting.create_loss(
             loss_type='smplify', rho=rho, use_joints_conf=True, body_pose_prior=body_prior,
-            shape_prior=shape_prior, angle_prior=angle_prior, interpenetration=False,
+            shape_prior=shape_prior, angle_prior=angle_prior, interpenetration=interpenetration,
             dtype=dt, use_3d=joints3d is not None, fix_shape=fix_shape)
         self.use_3d = joints3d is not None
         self.gt_joints3d = self.joints3d_conf = None

@@ -1,6 +1,10 @@
 """GPU parity: the interpenetration term of the loss (fitting.py:352-393) through the C ABI against the
 oracle (oracle/sdf_term_np.py on top of oracle/closure_np.py).  Tolerances as for the closure: loss 1e-5
-relative, gradient 2e-4 of its max.  The oracle's SDF op is "parity unpinned" (CUDA-only reference op).
+relative, gradient 2e-4 of its max.  Pins: the voxel function is bit-exact against the reference's own kernel source
+(oracle/_ref, tests/test_sdf_ref.py, tests/test_gpu_sdf.py); the whole term - boxes, op call as wired, grid_sample, the
+square, autograd - against the reference's own SMPLifyLoss.forward recorded in tests/golden/sdf_term_ref.npz
+(oracle/make_golden_sdf_term.py): tests/test_sdf_term_ref.py for the oracle and
+test_closure_with_sdf_term_matches_the_references_own_forward below for the device.
 
 The term is only piecewise smooth in the vertices (trilinear cells; phi jumps at the mesh boundary), so the
 oracle's term is evaluated at the vertices the device produced (themselves checked to 1e-4 in
@@ -70,6 +74,38 @@ def test_closure_with_sdf_term_matches_oracle(num_faces, G, coll_w):
         assert abs(r['L'] - r['Lr']) <= 1e-5 * abs(r['Lr']), (r['L'], r['Lr'])
         assert abs(r['pen'] - r['pen_r']) <= 1e-4 * max(r['pen_r'], 1e-3 * abs(r['Lr'])), (r['pen'], r['pen_r'])
         assert np.abs(r['g'] - r['gr']).max() <= 2e-4 * np.abs(r['gr']).max(), (np.abs(r['g'] - r['gr']).max(), np.abs(r['gr']).max())
+
+
+@pytest.mark.parametrize('name', ['l2_s3_v6', 'l2_top4_v8', 'vp_s0_v8'])
+def test_closure_with_sdf_term_matches_the_references_own_forward(name):
+    """mvfit_closure with the term as wired (first triangle, grid 128) against the reference's SMPLifyLoss.forward +
+    autograd in float32 (tests/golden/sdf_term_ref.npz): at a hand-picked weight and at the yaml's stage-3 / stage-4
+    weights.  Tolerances of tests/test_sdf_term_ref.py (float32 on both sides here)."""
+    from tests.test_sdf_term_ref import load_term_case
+    from oracle.make_golden import stage_weights
+    cfg, c, model, vpw, cams = load_term_case(name)
+    use_vp = cfg['use_vposer']
+    eng = make_engine(model, vpw, None)
+    eng.set_problems(cams, c['gt_xy'][None], c['conf'][None])
+    eng.set_sdf(model['faces'], num_faces=1, grid_size=128)
+    x = to118(c['x'], use_vp)[None].astype(np.float32)
+    for i in range(len(c['stage'])):
+        w = dict(stage_weights(int(c['stage'][i])), coll_loss_weight=float(c['coll_w'][i]), flags=_lib.F_VPOSER if use_vp else 0)
+        o1 = eng.closure(x, w, want_grad=True, want_verts=True)
+        o0 = eng.closure(x, dict(w, coll_loss_weight=0.0), want_grad=True)
+        L1, L0 = float(o1['loss'][0]), float(o0['loss'][0])
+        pick = (lambda g: np.concatenate([g[0:13], g[82:86], g[86:118]])) if use_vp else (lambda g: g[:86])
+        g1, g0 = pick(o1['grad'][0].cpu().numpy().astype(np.float64)), pick(o0['grad'][0].cpu().numpy().astype(np.float64))
+        pen_ref = c['loss_with'][i] - c['loss_without'][i]
+        assert np.abs(o1['verts'][0].cpu().numpy()[::10] - c['verts32']).max() < 1e-5
+        assert abs(L0 - c['loss_without'][i]) <= 1e-5 * abs(c['loss_without'][i])
+        assert abs(L1 - c['loss_with'][i]) <= 1e-5 * abs(c['loss_without'][i]) + 1e-4 * pen_ref, (L1, c['loss_with'][i])
+        assert abs((L1 - L0) - pen_ref) <= 1e-4 * pen_ref + 4.8e-7 * abs(c['loss_with'][i]), (L1 - L0, pen_ref)
+        gp, gp_ref = g1 - g0, c['grad_with'][i] - c['grad_without'][i]
+        assert np.abs(gp - gp_ref).max() <= 2e-3 * np.abs(gp_ref).max(), (np.abs(gp - gp_ref).max(), np.abs(gp_ref).max())
+        assert np.abs(g0 - c['grad_without'][i]).max() <= 2e-4 * np.abs(c['grad_without'][i]).max()
+        assert np.abs(g1 - c['grad_with'][i]).max() <= 2e-4 * np.abs(c['grad_without'][i]).max() + 2e-3 * np.abs(gp_ref).max()
+    eng.close()
 
 
 def test_closure_with_sdf_term_and_vposer():
