@@ -40,11 +40,11 @@ def stage_weights(image_height: float, flags: int = 0, rho: float = 100.0,
                   pose_w=YAML_POSE_W, shape_w=YAML_SHAPE_W, coll_w=None):
     """Per-stage weights exactly as non_linear_solver builds them (reference
     code/utils/non_linear_solver.py:109-124,148-150,177-180): data_weight = 500/H,
-    bending = 3.17 * body_pose_weight."""
+    bending = 3.17 * body_pose_weight - the product rounded to float32 like the reference's float32 weight tensor."""
     out = []
     for s in range(len(pose_w)):
         out.append(dict(data_weight=500.0 / image_height, body_pose_weight=pose_w[s],
-                        shape_weight=shape_w[s], bending_prior_weight=3.17 * pose_w[s],
+                        shape_weight=shape_w[s], bending_prior_weight=float(np.float32(3.17) * np.float32(pose_w[s])),
                         coll_loss_weight=0.0 if coll_w is None else coll_w[s], rho=rho, flags=flags))
     return out
 

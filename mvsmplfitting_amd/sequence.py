@@ -22,12 +22,37 @@ SEQ_POSE_FACTOR = 0.15         # non_linear_solver.py:162
 
 def sequence_stages(stages):
     """The stage list of a warm-started frame: stages 0 and 1 skipped, stage 2 with body_pose_weight * 0.15 - and the
-    bending weight that non_linear_solver derives from it afterwards (:177-179)."""
+    bending weight that non_linear_solver derives from it afterwards (:177-179).  The reference holds the weights as
+    float32 tensors (non_linear_solver.py:118-124 with float_dtype float32), so `*= 0.15` and `3.17 *` round to float32
+    after every operation; the same here, so that the device sees the reference's weights bit for bit
+    (tests/test_sequence_ref.py against the weights recorded from the reference)."""
     out = [dict(s) for s in stages[2:]]
     if out:
-        out[0]['body_pose_weight'] = out[0]['body_pose_weight'] * SEQ_POSE_FACTOR
-        out[0]['bending_prior_weight'] = 3.17 * out[0]['body_pose_weight']
+        w = np.float32(out[0]['body_pose_weight']) * np.float32(SEQ_POSE_FACTOR)
+        out[0]['body_pose_weight'] = float(w)
+        out[0]['bending_prior_weight'] = float(np.float32(3.17) * w)
     return out
+
+
+def carry_over(prev_x, prev_loss, x_init_t, use_vposer):
+    """The start vector of frame t of every sequence and whether it is a cold start, from frame t - 1's result - the
+    reference's load_init + fix_params (code/utils/init_guess.py:137-166,190-215; main.py:76-82):
+      * previous loss > 5000 (or no loss returned): init_guess again -> the frame's own full initial guess, all four
+        stages (`seq_start = True`, :141-145);
+      * otherwise betas, global_orient, transl, scale and - with VPoser - the embedding are the previous frame's result
+        (:147-166); the body pose is NOT carried over: reset_params zeroes what it is not given (body_models_scale.py:311-316)
+        and fix_params then writes its own start value (:199-203, the six leading ones), which x_init_t holds.
+    prev_x [S,118], prev_loss [S], x_init_t [S,118] (NumPy arrays or tensors of one kind) -> (x0 [S,118], cold [S] bool)."""
+    is_t = isinstance(prev_x, torch.Tensor)
+    pl = prev_loss.detach().cpu().numpy() if is_t else np.asarray(prev_loss)
+    cold = ~(pl <= RESTART_LOSS)                     # NaN (no loss returned) restarts too
+    x0 = prev_x.clone() if is_t else np.array(prev_x, copy=True)
+    if not use_vposer:
+        x0[:, 13:82] = x_init_t[:, 13:82]
+    if cold.any():
+        idx = torch.as_tensor(np.flatnonzero(cold), device=prev_x.device) if is_t else np.flatnonzero(cold)
+        x0[idx] = x_init_t[idx]
+    return x0, cold
 
 
 def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, joints3d=None, **fit_kw):
@@ -45,13 +70,13 @@ def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, joints3d=N
     final = torch.empty(S, T, device=engine.device)
     ncl = torch.zeros(S, T, dtype=torch.int32, device=engine.device)
     restarted = np.zeros((S, T), bool)
+    use_vposer = bool(int(stages[0].get('flags', 0)) & 1)
     prev_x, prev_loss = None, None
     for t in range(T):
         if t == 0:
-            cold = np.ones(S, bool)
+            x_start, cold = xi[:, t], np.ones(S, bool)
         else:
-            pl = prev_loss.cpu().numpy()
-            cold = ~(pl <= RESTART_LOSS)                 # NaN (no loss returned) restarts too
+            x_start, cold = carry_over(prev_x, prev_loss, xi[:, t], use_vposer)
         restarted[:, t] = cold
         for sel, stg in ((np.flatnonzero(cold), stages), (np.flatnonzero(~cold), warm)):
             if sel.size == 0:
@@ -61,15 +86,7 @@ def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, joints3d=N
             if joints3d is not None:
                 engine.set_joints3d(np.asarray(joints3d[0], np.float32)[sel, t], np.asarray(joints3d[1], np.float32)[sel, t])
             idx = torch.as_tensor(sel, device=engine.device)
-            if stg is stages:
-                x0 = xi[idx, t]
-            else:
-                # load_init (init_guess.py:147-166): shape, orientation, translation, scale and the VPoser embedding come
-                # from the previous frame; without VPoser the body pose restarts from fix_params' value (:199-203)
-                x0 = prev_x[idx].clone()
-                if not (int(stg[0].get('flags', 0)) & 1):
-                    x0[:, 13:82] = xi[idx, t, 13:82]
-            xf, st = engine.fit(x0, stg, **fit_kw)
+            xf, st = engine.fit(x_start[idx], stg, **fit_kw)
             xs[idx, t] = xf
             final[idx, t] = st['final_loss']
             ncl[idx, t] = st['n_closure']
@@ -77,4 +94,4 @@ def fit_sequences(engine: MvFit, cams, gt_xy, w_conf, x_init, stages, joints3d=N
     return xs, dict(final_loss=final, n_closure=ncl, restarted=restarted)
 
 
-__all__ = ['fit_sequences', 'sequence_stages', 'RESTART_LOSS', 'SEQ_POSE_FACTOR']
+__all__ = ['fit_sequences', 'sequence_stages', 'carry_over', 'RESTART_LOSS', 'SEQ_POSE_FACTOR']
