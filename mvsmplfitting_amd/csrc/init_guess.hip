@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lapack_svd3.h"
+
 namespace mvfit {
 
 __device__ __forceinline__ void inv3(const double* K, double* Ki) {          // np.linalg.inv of a 3x3
@@ -80,62 +82,17 @@ hipError_t launch_triangulate(const float* kps, const double* intris, const doub
 // to the triangulated ones - the reference's umeyama (code/utils/umeyama.py:16-109) with its two local changes kept
 // as they are (full-rank branch U diag(d) Vh^T, :73; two candidates with the first two rotation columns negated in
 // place and the translation taken from the second one, :84-104) - and cv2.Rodrigues of the chosen rotation.
-// One thread per frame, float64 like the reference's NumPy.  The 3x3 SVD is a one-sided (Hestenes) Jacobi; the SIGNS of
-// the singular-vector pairs are whatever it produces - the reference's are whatever LAPACK produced, its full-rank
-// formula is not invariant under that freedom (tests/test_umeyama.py accepts any of the four patterns).
+// One thread per frame, float64 like the reference's NumPy.  The reference's full-rank formula is not invariant under
+// the sign freedom of the SVD ((u_k, v_k) -> (-u_k, -v_k)): its value is "what LAPACK returned".  The 3x3 SVD here
+// therefore walks LAPACK's own path for a matrix of this size (lapack_svd3.h: dgebd2 + dbdsqr + dormbr) and returns
+// np.linalg.svd's pairs - rotation and translation equal the reference's (tests/test_umeyama.py, test_gpu_init_guess.py).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double det3(const double* M) {
     return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
-// A (row-major 3x3) = U diag(S) Vh, S descending
-__device__ void svd3(const double* A, double* U, double* S, double* Vh) {
-    double W[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) W[i] = A[i];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int r = 0; r < 3; ++r) { al += W[3 * r + p] * W[3 * r + p]; be += W[3 * r + q] * W[3 * r + q]; ga += W[3 * r + p] * W[3 * r + q]; }
-                off = fmax(off, fabs(ga) / (sqrt(al * be) + 1e-300));
-                if (fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                for (int r = 0; r < 3; ++r) {
-                    const double wp = W[3 * r + p], wq = W[3 * r + q];
-                    W[3 * r + p] = c * wp - sn * wq; W[3 * r + q] = sn * wp + c * wq;
-                    const double vp = V[3 * r + p], vq = V[3 * r + q];
-                    V[3 * r + p] = c * vp - sn * vq; V[3 * r + q] = sn * vp + c * vq;
-                }
-            }
-        if (off < 1e-15) break;
-    }
-    double nrm[3];
-    int ord[3] = {0, 1, 2};
-    for (int k = 0; k < 3; ++k) nrm[k] = sqrt(W[k] * W[k] + W[3 + k] * W[3 + k] + W[6 + k] * W[6 + k]);
-    for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (nrm[ord[j]] > nrm[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
-    for (int k = 0; k < 3; ++k) {
-        const int c = ord[k];
-        S[k] = nrm[c];
-        for (int r = 0; r < 3; ++r) { U[3 * r + k] = nrm[c] > 0 ? W[3 * r + c] / nrm[c] : 0.0; Vh[3 * k + r] = V[3 * r + c]; }
-    }
-    // a vanishing singular value leaves its left vector undefined: complete the basis (right-handed)
-    if (S[2] <= S[0] * 1e-14) {
-        if (S[1] <= S[0] * 1e-14) {            // rank <= 1: any unit vector orthogonal to u0
-            const int m = fabs(U[0]) < fabs(U[3]) ? (fabs(U[0]) < fabs(U[6]) ? 0 : 2) : (fabs(U[3]) < fabs(U[6]) ? 1 : 2);
-            double e[3] = {0, 0, 0}; e[m] = 1.0;
-            const double dp = U[0] * e[0] + U[3] * e[1] + U[6] * e[2];
-            double v[3] = {e[0] - dp * U[0], e[1] - dp * U[3], e[2] - dp * U[6]};
-            const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-            U[1] = v[0] / nv; U[4] = v[1] / nv; U[7] = v[2] / nv;
-        }
-        U[2] = U[3] * U[7] - U[6] * U[4];
-        U[5] = U[6] * U[1] - U[0] * U[7];
-        U[8] = U[0] * U[4] - U[3] * U[1];
-    }
-}
+// A (row-major 3x3) = U diag(S) Vh, S descending, with the singular-vector signs of np.linalg.svd: lapack_svd3.h
+__device__ __forceinline__ void svd3(const double* A, double* U, double* S, double* Vh) { lapack3::svd3(A, U, S, Vh); }
 
 // cv2.Rodrigues, matrix -> rotation vector
 __device__ void rotvec3(const double* R, double* rv) {

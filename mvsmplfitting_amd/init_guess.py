@@ -7,15 +7,13 @@
   rest-pose keypoints of the model            init_guess.py:38-52                -> mvfit_vertices at zero parameters
 
 ``recompute3D`` keeps the reference's argument meaning (``keypoints`` a list over views of [1, 17, 3] arrays
-(u, v, confidence)); ``init_guess_batch`` takes [B, V, 17, 3].  The single-view depth guess (init_guess.py:54-78) is
-not mirrored (the path is multi-view).
+(u, v, confidence)); ``init_guess_batch`` takes [B, V, 17, 3]; one view selects the single-view depth guess
+(init_guess.py:54-78, ``single_view_joints3d``).
 
 About the rotation: the reference's umeyama evaluates ``U diag(d) Vh^T`` in its full-rank branch (umeyama.py:73), which
-depends on the signs LAPACK happened to give the singular-vector pairs; libmvfit uses the signs of its own Jacobi SVD,
-then - like the reference - keeps the better of the two candidates (columns 0, 1 negated) by alignment residual.  The result
-is the reference's formula evaluated on a valid SVD (tests/test_umeyama.py checks it against the restatement for the four
-possible sign patterns); it equals the reference's own numbers only where LAPACK's signs coincide with the Jacobi SVD's
-(the scale always does).  The fit that follows starts from an equally (un)reasonable guess either way."""
+depends on the signs LAPACK gave the singular-vector pairs.  mvfit_umeyama's 3 x 3 SVD walks LAPACK's own dgesdd path
+(csrc/lapack_svd3.h) and returns np.linalg.svd's pairs, so rotation, translation and scale are the reference's
+(tests/test_init_guess_ref.py: the reference's own init_guess on the demo frame, several views and single view)."""
 from __future__ import annotations
 
 import numpy as np

@@ -1,9 +1,9 @@
 """TEST INFRASTRUCTURE - NumPy restatement of the single-view branch of the reference's per-frame initial guess
-(code/utils/init_guess.py:54-72), line by line, for ONE frame.  parity unpinned: the reference's init_guess itself
-cannot run in this container (hard-coded `.cuda()`, init_guess.py:38) and holds no fixtures; the restatement follows the
-source text, including its use of the LEFT shoulder-hip pair twice in the 2-D height (:65) and the confidence column
-that `keypoints[0][0][[5, 6, 11, 12]]` (:58) carries into that height.  Never imported by the
-package."""
+(code/utils/init_guess.py:54-72), line by line, for ONE frame - including its use of the LEFT shoulder-hip pair twice
+in the 2-D height (:65) and the confidence column that `keypoints[0][0][[5, 6, 11, 12]]` (:58) carries into that height.
+Pinned: tests/test_init_guess_ref.py checks it (with oracle/umeyama_np.py behind it) against the reference's own
+init_guess run on the demo's cameras / keypoints (tests/golden/init_guess_ref.npz, oracle/make_golden_init_guess.py).
+Never imported by the package."""
 from __future__ import annotations
 
 import numpy as np

@@ -26,17 +26,17 @@ def test_demo_initial_guess_equals_the_reference():
     assert np.abs(j3 - g['init_joints3d']).max() < 1e-6 * np.abs(g['init_joints3d']).max()
     rest = ig.rest_keypoints(eng).cpu().numpy()
     assert np.abs(rest - g['init_joints_rest']).max() < 1e-5               # float32 forward vs the reference's float64
-    # the guess, against the restatement evaluated on the device's own inputs, for one singular-vector sign pattern
+    # the guess, against the restatement evaluated on the device's own inputs (numpy's singular-vector signs: the
+    # device SVD walks LAPACK's path, csrc/lapack_svd3.h)
     rot, trans, scale = out['rot'][0].cpu().numpy(), out['transl'][0].cpu().numpy(), float(out['scale'][0])
     t = list(ig.TORSO)
-    hits = [sg for sg in un.SIGN_PATTERNS
-            if np.abs(un.umeyama(rest[t], j3[t], True, signs=sg)[0] - rot).max() < 1e-7]
-    assert hits, 'rotation equals the reference formula for none of the sign patterns'
-    r_ref, t_ref, s_ref, _ = un.umeyama(rest[t], j3[t], True, signs=hits[0])
-    assert np.abs(trans - t_ref).max() < 1e-7 and abs(scale - s_ref) < 1e-9
-    # the scale does not depend on the sign pattern: it is the reference's (x0 of the golden fit); rotation and
-    # translation are the reference's only if LAPACK's signs happen to be the Jacobi SVD's (not on this frame)
+    r_ref, t_ref, s_ref, _ = un.umeyama(rest[t], j3[t], True)
+    assert np.abs(rot - r_ref).max() < 1e-7 and np.abs(trans - t_ref).max() < 1e-7 and abs(scale - s_ref) < 1e-9
+    # ... and against what the REFERENCE computed on this frame (x0 of the golden fit: the reference's own recompute3D +
+    # umeyama + rotation vector): global_orient, transl, scale (float32 rest keypoints here, float64 there)
     x0 = g['x0']
+    assert np.abs(out['global_orient'][0].cpu().numpy() - x0[10:13]).max() < 1e-4, (out['global_orient'][0], x0[10:13])
+    assert np.abs(trans - x0[13:16]).max() < 1e-4 * max(1.0, np.abs(x0[13:16]).max())
     assert abs(scale - x0[16]) < 1e-4 * x0[16]
     # fix_params: the flat start of the fit
     x = ig.initial_params(out, use_vposer=True).cpu().numpy()
@@ -66,8 +66,8 @@ def test_batched_initial_guess_is_per_frame():
 
 def test_single_view_guess_and_fit():
     """One camera only (init_guess.py:54-72): the depth guess equals its restatement, and the staged single-view fit
-    started from it ends far below its start.  (parity of this branch is unpinned: the reference's init_guess cannot
-    run in the build container, oracle/init_guess_np.py.)"""
+    started from it ends far below its start.  (The branch is pinned to the reference's own init_guess in
+    tests/test_init_guess_ref.py.)"""
     from mvsmplfitting_amd.engine import stage_weights
     from oracle import init_guess_np as ign
     g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))

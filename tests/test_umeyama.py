@@ -1,9 +1,16 @@
 """Similarity alignment of the per-frame initial guess (reference code/utils/umeyama.py:16-109,
-init_guess.py:95-106).  CPU: the restatement against the reference function itself (numpy's singular-vector signs =
-pattern (1,1,1)) and the rotation-vector conversion against scipy (cv2 is absent).  GPU: mvfit_umeyama must equal the
-restatement for ONE of the four singular-vector sign patterns - the reference's full-rank formula U diag(d) Vh^T is
-not invariant under the SVD's sign freedom, so "what LAPACK returned" is the only thing it can be equal to - and its
-scale, candidate choice (smaller residual) and translation-from-the-second-candidate quirk must hold."""
+init_guess.py:95-106).  CPU: the restatement against the reference function itself and the rotation-vector conversion
+against scipy (cv2 is absent).  The reference's full-rank formula U diag(d) Vh^T is not invariant under the SVD's sign
+freedom - "what LAPACK returned" is the only thing it can be equal to - so the device's 3 x 3 SVD walks LAPACK's own
+dgesdd path (csrc/lapack_svd3.h): the shipped header is compiled for the host here and checked against np.linalg.svd
+(signs exact), together with its Python twin oracle/lapack_svd3_np.py.  GPU: mvfit_umeyama must equal the restatement
+with numpy's own singular-vector signs - rotation, translation (from the second candidate, the reference's quirk) and
+scale."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -51,8 +58,58 @@ def test_rotvec_equals_scipy():
     assert np.array_equal(un.rotvec(np.eye(3)), np.zeros(3))
 
 
+def _svd_test_matrices(n, seed):
+    rng = np.random.default_rng(seed)
+    mats = []
+    for k in range(n):
+        kind = k % 6
+        A = rng.normal(size=(3, 3))
+        if kind == 1:
+            A = A * np.array([1, 1e-3, 1e-6])                      # graded columns
+        elif kind == 2:                                            # what umeyama factorises: dst^T src / num of 4 points
+            s_ = rng.normal(size=(4, 3))
+            R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+            d_ = s_ @ R.T * rng.uniform(0.5, 2) + rng.normal(0, 0.01, (4, 3))
+            A = (d_ - d_.mean(0)).T @ (s_ - s_.mean(0)) / 4
+        elif kind == 3:
+            A = np.diag(rng.normal(size=3)) @ np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        elif kind == 4:
+            A = np.triu(A)
+        elif kind == 5:
+            A = rng.normal(size=(3, 2)) @ rng.normal(size=(2, 3))  # rank 2
+        mats.append(A)
+    return np.ascontiguousarray(np.stack(mats))
+
+
+def test_device_svd_header_returns_numpys_singular_vector_pairs():
+    """csrc/lapack_svd3.h (the code mvfit_umeyama runs per frame) built for the host with g++, no FMA contraction."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tempfile.mkdtemp(), 'libsvd3_host.so')
+    subprocess.run(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', os.path.join(root, 'tests', 'svd3_host_shim.cpp'), '-o', so],
+                   check=True)
+    lib = C.CDLL(so)
+    A = _svd_test_matrices(12000, seed=1)
+    n = A.shape[0]
+    U, S, Vh = np.zeros((n, 3, 3)), np.zeros((n, 3)), np.zeros((n, 3, 3))
+    lib.svd3_batch(*(a.ctypes.data_as(C.c_void_p) for a in (A, U, S, Vh)), n)
+    Un, Sn, Vn = np.linalg.svd(A)
+    assert np.abs(S - Sn).max() <= 1e-13 * max(1.0, Sn.max())
+    full = Sn[:, 2] > 1e-9 * Sn[:, 0]
+    assert np.abs(U[full] - Un[full]).max() < 1e-10 and np.abs(Vh[full] - Vn[full]).max() < 1e-10
+    # rank 2: the pair of the vanishing singular value is rounding noise (its sign too); the other two are numpy's,
+    # and umeyama's rank-2 branch (:60-68) does not depend on that sign
+    assert np.abs(U[~full][:, :, :2] - Un[~full][:, :, :2]).max() < 1e-7
+    assert np.abs(Vh[~full][:, :2] - Vn[~full][:, :2]).max() < 1e-7
+    assert np.abs(np.einsum('nij,nj,njk->nik', U, S, Vh) - A).max() < 1e-12
+    # the Python twin (oracle/lapack_svd3_np.py) is the same arithmetic
+    from oracle import lapack_svd3_np as L
+    for i in range(0, 600):
+        u, s_, vh = L.svd3(A[i])
+        assert np.abs(np.asarray(u) - U[i]).max() < 1e-14 and np.abs(np.asarray(vh) - Vh[i]).max() < 1e-14
+
+
 @pytest.mark.gpu
-def test_gpu_umeyama_equals_restatement_for_one_sign_pattern():
+def test_gpu_umeyama_equals_the_restatement_with_numpys_signs():
     import torch
     from tests.gpu_helpers import make_engine
     from tests.helpers import body_model
@@ -66,13 +123,10 @@ def test_gpu_umeyama_equals_restatement_for_one_sign_pattern():
             out = eng.umeyama(src, dst, estimate_scale=est)
             rot, rvec, trans, scale = (out[k].cpu().numpy() for k in ('rot', 'rvec', 'trans', 'scale'))
             for b in range(dst.shape[0]):
-                hits = []
-                for sg in un.SIGN_PATTERNS:
-                    r1, t1, s1, losses = un.umeyama(src, dst[b], est, signs=sg)
-                    hits.append(np.abs(rot[b] - r1).max() < 1e-9 and np.abs(trans[b] - t1).max() < 1e-8)
-                    assert abs(scale[b] - s1) < 1e-10 * max(1.0, abs(s1))              # the scale does not depend on the signs
-                assert any(hits), (est, npts, b)
-                assert abs(np.linalg.det(rot[b]) - 1) < 1e-9
+                r1, t1, s1, losses = un.umeyama(src, dst[b], est)                       # numpy's own signs = the reference's
+                assert np.abs(rot[b] - r1).max() < 1e-9 and np.abs(trans[b] - t1).max() < 1e-8, (est, npts, b)
+                assert abs(scale[b] - s1) < 1e-10 * max(1.0, abs(s1))
+                assert abs(abs(np.linalg.det(rot[b])) - 1) < 1e-9
                 assert np.abs(rvec[b] - un.rotvec(rot[b])).max() < 1e-9
     eng.close()
 
