@@ -10,8 +10,10 @@
  *   - every function returns 0 on success, a negative MVFIT_E_* code on failure, never throws;
  *     mvfit_last_error(ctx) returns a NUL-terminated message owned by the ctx.
  *   - a ctx is bound to one HIP device and one hipStream_t, is not thread-safe; different
- *     ctxs are independent.  All calls are asynchronous on the ctx stream except
- *     mvfit_create / mvfit_sync / mvfit_destroy and the host-copy getters.
+ *     ctxs are independent.  Calls enqueue their work on the ctx stream and return; the ones that
+ *     block until the device has finished are mvfit_create, mvfit_set_problems, mvfit_set_sdf,
+ *     mvfit_sync, mvfit_destroy, the profiling readers and mvfit_fit (it watches the problems'
+ *     completion to stop queueing rounds; its outputs are complete when it returns).
  *   - "dev|host" pointers may be either (copied with hipMemcpyDefault); "dev" pointers must be
  *     device memory (e.g. a torch CUDA tensor's data_ptr()); all arrays row-major float32
  *     unless noted.  Caller-owned; nothing is retained beyond the call except by
@@ -166,7 +168,11 @@ int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint
  * every problem advancing its own state machine, no host synchronisation per closure.
  *   params[B,MVFIT_D] dev, in/out ; stage_weights[num_stages] host ;
  *   final_loss[B] dev (run_fitting's return of the last stage; NaN where the reference returns None)
- *   n_closure[B], n_iter[B] dev int32 (closure evaluations / L-BFGS iterations spent), may be NULL. */
+ *   n_closure[B], n_iter[B] dev int32 (closure evaluations / L-BFGS iterations spent), may be NULL.
+ * The vertices of the trial points (the reference's return_verts=True) are computed per closure round into an internal
+ * buffer and are NOT an output of this call - mvfit_vertices(params) gives the vertices of the result.  In the
+ * asynchronous mode (default without the SDF term) those per-round passes run beside the optimiser and nothing of the
+ * result depends on them; mvfit_fit_stats reports how many ran and whether any was lost (expected: none). */
 int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
 
@@ -178,14 +184,16 @@ int mvfit_fit_stats(mvfit_ctx* ctx, uint32_t* out4);
 /* Test hook for the asynchronous fit: the vertex pass that belongs to closure round `round` (0-based, of every
  * problem) writes its vertices to verts[B,Nv,3] (dev) instead of the internal buffer; together with mvfit_fit_trace
  * (the trial points) this lets a test check that the pass of round r really computed the trial point of round r.
- * verts = NULL switches it off. */
+ * verts = NULL switches it off.  The buffer is sized for the CURRENT batch: mvfit_set_problems with another B (or V)
+ * switches the hook off. */
 int mvfit_debug_capture_pass(mvfit_ctx* ctx, int round, float* verts);
 
 /* Optional closure trace of the NEXT mvfit_fit calls (test / debugging hook; the reference equivalent is printing
  * inside fitting_func): for every problem the first max_closures closure evaluations are recorded as
  *   trace[b][k][0:MVFIT_D] = the trial point the closure was evaluated at, trace[b][k][MVFIT_D] = its loss.
  * trace[B, max_closures, MVFIT_D + 1] dev, caller-owned, must stay valid until tracing is switched off with
- * mvfit_fit_trace(ctx, NULL, 0) (or the ctx is destroyed).  Rows beyond a problem's closure count are not written. */
+ * mvfit_fit_trace(ctx, NULL, 0) (or the ctx is destroyed).  Rows beyond a problem's closure count are not written.
+ * The buffer is sized for the CURRENT batch: mvfit_set_problems with another B (or V) switches tracing off. */
 int mvfit_fit_trace(mvfit_ctx* ctx, float* trace, int max_closures);
 
 /* The SDF voxelisation op (reference sdf/sdf/sdf.py:21-26 -> sdf_cuda.cpp:14-28 -> sdf_cuda_kernel.cu:242-335):

@@ -3,7 +3,8 @@ frame of a serial fitted in ONE batched device fit (the refer
 
     keypoint files  <keyp_root>/<serial>/<camera>/<frame>_keypoints.json   (data_parser.py:375-411: cameras and frames
                     in sorted order, view v = the v-th camera of the camera file; a view without a file does not take
-                    part in that frame - here: zero confidence)
+                    part in that frame (main.py:44-66) - here: zero confidence in the fit, and left out of that frame's
+                    initial guess: triangulation over the frame's own views, the single-view depth guess when it has one)
     camera file     io_formats.load_camera_para  (utils.py:352-394)
       -> joint weights: hips 11, 12 ignored unless pose_format == 'lsp14' and use_hip (data_parser.py:340-357;
          model_type 'smpllsp' -> 'lsp14', init.py:63-69, and fit_smpl.yaml has use_hip: true: the default here)
@@ -20,6 +21,7 @@ the image height the data weight 500 / H refers to (non_linear_solver.py:150,177
 from __future__ import annotations
 
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -50,9 +52,11 @@ def list_frames(keyp_root):
     return out
 
 
-def load_serial(frames, num_views, person=0):
-    """Keypoints [F, V, 17, 3] float32 of one serial (missing view / person: zeros, i.e. zero confidence)."""
+def load_serial(frames, num_views, person=0, return_mask=False):
+    """Keypoints [F, V, 17, 3] float32 of one serial (missing view / person: zeros, i.e. zero confidence) and, with
+    return_mask, which (frame, view) pairs exist - the reference drops the others from the frame (main.py:44-66)."""
     kp = np.zeros((len(frames), num_views, 17, 3), np.float32)
+    mask = np.zeros((len(frames), num_views), bool)
     for f, (_, paths) in enumerate(frames):
         for v, p in enumerate(paths[:num_views]):
             if p is None:
@@ -60,7 +64,8 @@ def load_serial(frames, num_views, person=0):
             people = iof.read_keypoints(p)
             if len(people) > person:
                 kp[f, v] = people[person]
-    return kp
+                mask[f, v] = True
+    return (kp, mask) if return_mask else kp
 
 
 def load_serial_joints3d(frames, person=0):
@@ -88,7 +93,8 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                mesh_folder=None, device=0, stages=None, engine: MvFit | None = None):
     """Fits every frame under keyp_root and writes the reference's result files.  Returns
     {serial: dict(frames, params [F,118], final_loss [F], n_closure [F], files [F], init [F,118], restarted [F]:
-    frames fitted from their own initial guess - all of them unless is_seq)}."""
+    frames fitted from their own initial guess - all of them unless is_seq, used_3d [F]: frames fitted with the 3-D joint
+    term, views_per_frame [F])}."""
     extris, intris = iof.load_camera_para(cam_file)
     use_vposer = vposer is not None
     flags = _lib.F_VPOSER if use_vposer else 0
@@ -110,38 +116,71 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                 continue
             if V > len(extris):
                 raise ValueError('serial %s has %d camera folders, the camera file %s holds %d cameras' % (serial, V, cam_file, len(extris)))
-            kp = load_serial(frames, V)
+            kp, vmask = load_serial(frames, V, return_mask=True)
+            if not vmask.any(1).all():
+                raise ValueError('serial %s: frames %s have no keypoint file in any camera folder'
+                                 % (serial, [frames[f][0] for f in np.flatnonzero(~vmask.any(1))]))
             ex, it = np.asarray(extris[:V], np.float64), np.asarray(intris[:V], np.float64)
             rig = (ex[:, :3, :3].astype(np.float32), ex[:, :3, 3].astype(np.float32),
                    it[:, 0, 0].astype(np.float32), it[:, :2, 2].astype(np.float32))
             gt_xy = kp[..., :2].copy()
             conf = kp[..., 2] * jw[None, None, :]
             eng.set_problems(rig, gt_xy, conf)
-            j3 = t3 = None
-            if use_3d:
-                # 3-D joint targets (non_linear_solver.py:86-99) and the initial alignment to them instead of the
-                # triangulation (init_guess.py:84-85); a serial with a frame that has no annotation falls back to 2-D only
-                # (the reference decides per frame, :68-69; a batched fit has one objective)
-                ann, has = load_serial_joints3d(frames)
-                if has.all():
-                    c3 = ann[:, :, 3].copy()
-                    if not use_hip:
-                        c3[:, 11] = c3[:, 12] = 0.0
-                    eng.set_joints3d(ann[:, :, :3], c3)
-                    j3 = ann[:, :, :3].astype(np.float64)
-                    t3 = (ann[None, :, :, :3], c3[None])
-            guess = init_guess_batch(eng, ex, it, kp, est_scale=fix_scale is None, fixed_scale=fix_scale, joints3d=j3)
+            # 3-D joint targets (non_linear_solver.py:86-99) and the initial alignment to them instead of the triangulation
+            # (init_guess.py:84-85) - decided PER FRAME like the reference (:68-69): frames with an annotation are fitted with
+            # the 3-D term, the others without it (two batched fits when a serial mixes both)
+            ann, has = (load_serial_joints3d(frames) if use_3d else (None, np.zeros(F, bool)))
+            if is_seq and has.any() and not has.all():
+                warnings.warn('serial %s: %d of %d frames carry no 3-D annotation; the is_seq chain runs on one objective - '
+                              'fitting the whole serial from the 2-D keypoints only' % (serial, int((~has).sum()), F))
+                has[:] = False
+            c3 = None
+            if has.any():
+                c3 = ann[:, :, 3].copy()
+                if not use_hip:
+                    c3[:, 11] = c3[:, 12] = 0.0
+            j3_all = ann[:, :, :3].astype(np.float64) if has.all() else None
+            guess = init_guess_batch(eng, ex, it, kp, est_scale=fix_scale is None, fixed_scale=fix_scale, joints3d=j3_all,
+                                     view_mask=vmask)
+            if has.any() and not has.all():
+                # annotated frames: aligned to their 3-D joints; the rest keep the triangulation / depth guess
+                sel = np.flatnonzero(has)
+                eng.set_problems(rig, gt_xy[sel], conf[sel])
+                g3 = init_guess_batch(eng, ex, it, kp[sel], est_scale=fix_scale is None, fixed_scale=fix_scale,
+                                      joints3d=ann[sel][:, :, :3].astype(np.float64))
+                idx = torch.as_tensor(sel, device=eng.device)
+                for k in ('global_orient', 'transl', 'scale', 'joints3d', 'rot'):
+                    guess[k][idx] = g3[k]
+                eng.set_problems(rig, gt_xy, conf)
             x0 = initial_params(guess, use_vposer, fixed_shape=fix_shape)
-            stages = user_stages if user_stages is not None else \
-                stage_weights(float(image_height), flags=flags | (_lib.F_USE_3D if j3 is not None else 0))
+
+            def stages_for(with_3d):
+                return user_stages if user_stages is not None else \
+                    stage_weights(float(image_height), flags=flags | (_lib.F_USE_3D if with_3d else 0))
             if is_seq:
-                xs, st = fit_sequences(eng, rig, gt_xy[None], conf[None], x0[None], stages, joints3d=t3)
+                if has.all():
+                    eng.set_joints3d(ann[:, :, :3], c3)
+                t3 = (ann[None, :, :, :3], c3[None]) if has.all() else None
+                xs, st = fit_sequences(eng, rig, gt_xy[None], conf[None], x0[None], stages_for(has.all()), joints3d=t3)
                 xf, final, ncl = xs[0], st['final_loss'][0], st['n_closure'][0]
                 restarted = st['restarted'][0]
                 eng.set_problems(rig, gt_xy, conf)                  # back to the whole serial for the outputs below
             else:
-                xf, st = eng.fit(x0, stages)
-                final, ncl = st['final_loss'], st['n_closure']
+                xf = torch.empty_like(x0)
+                final = torch.empty(F, device=eng.device)
+                ncl = torch.zeros(F, dtype=torch.int32, device=eng.device)
+                for sel, with_3d in ((np.flatnonzero(has), True), (np.flatnonzero(~has), False)):
+                    if sel.size == 0:
+                        continue
+                    if sel.size < F:
+                        eng.set_problems(rig, gt_xy[sel], conf[sel])
+                    if with_3d:
+                        eng.set_joints3d(ann[sel][:, :, :3], c3[sel])
+                    idx = torch.as_tensor(sel, device=eng.device)
+                    xs_, st = eng.fit(x0[idx], stages_for(with_3d))
+                    xf[idx], final[idx], ncl[idx] = xs_.to(xf.dtype), st['final_loss'].to(final.dtype), st['n_closure'].to(ncl.dtype)
+                if has.any() and not has.all():
+                    eng.set_problems(rig, gt_xy, conf)
                 restarted = np.ones(F, bool)
             full = eng.full_pose(xf, flags=flags & ~_lib.F_USE_3D).cpu().numpy()
             xf_h, final_h = xf.cpu().numpy(), final.cpu().numpy()
@@ -159,7 +198,8 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                     os.makedirs(d, exist_ok=True)
                     iof.save_obj(os.path.join(d, '000.obj'), verts[f], model['faces'])
             results[serial] = dict(frames=[fr[0] for fr in frames], params=xf_h, final_loss=final_h,
-                                   n_closure=ncl.cpu().numpy(), files=files, init=x0.cpu().numpy(), restarted=restarted)
+                                   n_closure=ncl.cpu().numpy(), files=files, init=x0.cpu().numpy(), restarted=restarted,
+                                   used_3d=has.copy(), views_per_frame=vmask.sum(1))
     finally:
         if own:
             eng.close()

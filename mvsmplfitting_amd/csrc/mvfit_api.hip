@@ -998,6 +998,9 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
     HIP_OK(c, hipStreamSynchronize(c->stream));
     if (B != c->B || V != c->V || (cam_batched != 0) != (c->Q.cam_batched != 0)) {
         free_problem_buffers(c);
+        // caller-owned hook buffers were sized for the old batch (include/mvfit.h): switch both hooks off
+        c->trace = nullptr; c->trace_cap = 0;
+        c->capture_verts = nullptr; c->capture_round = -1;
         const size_t nc = cam_batched ? (size_t)B * V : (size_t)V;
         const int Bpad = (B + 31) / 32 * 32;
         HIP_OK(c, hipMalloc(&c->d_camR, nc * 9 * 4)); HIP_OK(c, hipMalloc(&c->d_camt, nc * 3 * 4));

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
         for (int i = 0; i < SDF_NIT; ++i) {
             const int v = c0 + i * 64 + lane;
             const bool in = v < c1;
-            const int vc = in ? v : k0;
+            const int vc = in ? v : min(k0, nv - 1);      // padding lanes re-read a vertex that exists (small / odd nv: k0 may be >= nv)
             q[i] = sb[vc];
             px[i] = vb[3 * vc]; py[i] = vb[3 * vc + 1]; pz[i] = vb[3 * vc + 2];
             if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -150,8 +150,11 @@ class MvFit:
         gt = self._dev(gt_xy)
         B, V = int(gt.shape[0]), int(gt.shape[1])
         wc = self._dev(w_conf, (B, V, 17))
-        if B != self.B and getattr(self, '_trace', None) is not None:
-            self.fit_trace(0)                    # the trace buffer was sized for the old batch
+        if B != self.B or V != self.V:           # hook buffers were sized for the old batch (the C side drops them too)
+            if getattr(self, '_trace', None) is not None:
+                self.fit_trace(0)
+            if getattr(self, '_capture', None) is not None:
+                self.capture_pass(None)
         batched = 1 if np.ndim(cam_R) == 4 else 0
         R, t, f, c = self._dev(cam_R), self._dev(cam_t), self._dev(cam_f), self._dev(cam_c)
         self._check(self._lib.mvfit_set_problems(

@@ -70,19 +70,37 @@ def single_view_joints3d(rest, extri, intri, keypoints) -> torch.Tensor:
 
 
 def init_guess_batch(engine: MvFit, extris, intris, keypoints, est_scale=True, fixed_scale=None, use_torso=True,
-                     joints3d=None) -> dict:
+                     joints3d=None, view_mask=None) -> dict:
     """init_guess (init_guess.py:18-106) for B frames: keypoints [B, V, 17, 3] (u, v, confidence), extris [V,4,4],
-    intris [V,3,3] float64.  ``joints3d`` [B,17,3] replaces the triangulation (use_3d, :84-85).  Returns
-    dict(global_orient [B,3], transl [B,3], scale [B], joints3d [B,17,3]) float64 tensors on the device."""
+    intris [V,3,3] float64.  ``joints3d`` [B,17,3] replaces the triangulation (use_3d, :84-85).
+    ``view_mask`` [B, V] bool: the views that exist for a frame.  The reference drops the views without annotation BEFORE
+    the initial guess (main.py:44-66), so a frame is triangulated from its own views only (recompute3D would otherwise
+    weigh an absent view with its 1e-6, recompute3D.py:47-51) and a frame with exactly one view takes the single-view
+    depth guess with that view's camera (:54-78) - whatever the rig's camera count.  Frames are grouped by their view
+    pattern, one device call per pattern.
+    Returns dict(global_orient [B,3], transl [B,3], scale [B], joints3d [B,17,3]) float64 tensors on the device."""
     kp = np.asarray(keypoints, np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints
+    extris, intris = np.asarray(extris, np.float64), np.asarray(intris, np.float64)
+    B, V = int(kp.shape[0]), int(kp.shape[1])
     s0 = 1.0 if fixed_scale is None else float(fixed_scale)                      # :24
     rest = rest_keypoints(engine, s0)
     if joints3d is not None:
         j3 = torch.as_tensor(np.asarray(joints3d, np.float64), dtype=torch.float64, device=engine.device)
-    elif kp.shape[1] == 1:
-        j3 = single_view_joints3d(rest, extris[0], intris[0], kp[:, 0])
     else:
-        j3 = engine.triangulate(kp, intris, extris)
+        mask = np.ones((B, V), bool) if view_mask is None else np.asarray(view_mask, bool).reshape(B, V)
+        j3 = torch.empty(B, 17, 3, dtype=torch.float64, device=engine.device)
+        kp_t = torch.as_tensor(kp, dtype=torch.float32)
+        for pat in np.unique(mask, axis=0):
+            sel = np.flatnonzero((mask == pat[None]).all(1))
+            vs = np.flatnonzero(pat)
+            if vs.size == 0:
+                raise ValueError('frames %s have no view with keypoints' % sel.tolist())
+            idx = torch.as_tensor(sel, device=engine.device)
+            sub = kp_t[torch.as_tensor(sel)][:, torch.as_tensor(vs)]
+            if vs.size == 1:
+                j3[idx] = single_view_joints3d(rest, extris[vs[0]], intris[vs[0]], sub[:, 0])
+            else:
+                j3[idx] = engine.triangulate(sub.contiguous(), intris[vs], extris[vs])
     idx = list(TORSO) if use_torso else list(range(17))
     out = engine.umeyama(rest[idx], j3[:, idx].contiguous(), estimate_scale=est_scale)
     scale = out['scale'] if est_scale else torch.full_like(out['scale'], s0)     # :98-101

@@ -75,6 +75,7 @@ def result_dict(x118, loss=None, body_pose_decoded=None):
         res['pose_embedding'] = x[86:118][None].copy()
     else:
         bp = x[13:82][None].copy()
+        res['pose_embedding'] = None      # the reference stores the key in both branches (non_linear_solver.py:286: None without VPoser)
     bp[:, 18:24] = 0.          # feet and hands are zeroed in both branches (utils/utils.py:750-753 and :761-764)
     bp[:, 27:33] = 0.
     bp[:, 57:] = 0.

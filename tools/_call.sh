@@ -1,7 +1,5 @@
 set -u
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3a
-timeout 600 python -m pytest tests/test_gpu_large_batch.py -q -x > gpurun_out/r3a/large_batch.log 2>&1; echo "rc=$?" >> gpurun_out/r3a/large_batch.log
-timeout 300 python tests/quick_timing.py 32 > gpurun_out/r3a/quick32.log 2>&1
-timeout 300 python tests/phase_timing.py > gpurun_out/r3a/phase.log 2>&1
-tail -5 gpurun_out/r3a/large_batch.log; cat gpurun_out/r3a/quick32.log | tail -12; tail -30 gpurun_out/r3a/phase.log
+mkdir -p gpurun_out/r3b
+timeout 900 python -m pytest tests/test_umeyama.py tests/test_gpu_init_guess.py tests/test_init_guess_ref.py tests/test_gpu_sequence.py tests/test_gpu_sdf_term.py tests/test_gpu_large_batch.py -q -m gpu > gpurun_out/r3b/new_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r3b/new_tests.log
+tail -40 gpurun_out/r3b/new_tests.log
