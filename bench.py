@@ -7,19 +7,30 @@ vertex pass as a fraction of the HBM roofline.
 
 A "step" = ONE complete 4-stage fit (reference cfg_files/fit_smpl.yaml weights, L-BFGS lr=1,
 max_iter=30, history=100, strong-Wolfe; outer maxiters=30, ftol=gtol=1e-9) of this rank's batch of
-32 synthetic frames x 8 views x 1 person (BASELINE configs[1]), every closure with its full
-6890-vertex LBS pass like the reference's return_verts=True.  Inputs are resident in HBM before the
-timed region.  Ranks fit disjoint frames (weak scaling: 32 frames per GPU; --strong: the 32 frames
-split over the ranks); the only collective is the final all_gather of the fitted parameters (RCCL).
+synthetic problems, every closure with its full 6890-vertex LBS pass like the reference's
+return_verts=True.  Inputs are resident in HBM before the timed region.  Ranks fit disjoint frames
+(weak scaling: the per-GPU share is fixed; --strong: a fixed total split over the ranks); the only
+collective is the final all_gather of the fitted parameters (RCCL).
+
+Named workloads (BASELINE.json configs):
+  --config configs1   (default) 1 person x 8 views x 32 frames per GPU, GMoF + pose prior, no SDF
+  --config demo       configs[0]: the reference's shipped demo inputs (1 frame, 6 real views, VPoser checkpoint)
+  --config configs2   configs[1] + the SDF interpenetration term (--sdf-faces wired | all)
+  --config configs3   4 persons x 8 views x 256 frames frame-sharded over 8 GPUs = 4 x 32 frames (128 problems) per GPU
+  --config configs4   16-view rig x 1024 frames over 8 GPUs = 128 frames per GPU, half-width blendshape operands
 
   python bench.py --gpus 1 --steps 5 --warmup 1
+  python bench.py --gpus 8                       # starts 8 ranks itself (torch.distributed.run, 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-  python bench.py --config demo        # BASELINE configs[0]: the reference's shipped demo inputs (1 frame, 6 views, VPoser)
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,33 +39,46 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mvsmplfitting_amd import _lib                      # noqa: E402
-from mvsmplfitting_amd import synthetic as syn          # noqa: E402
-from mvsmplfitting_amd.engine import MvFit, stage_weights   # noqa: E402
-from mvsmplfitting_amd.sharding import gather_results, shard_range   # noqa: E402
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 CONST_BYTES = 82680 + 826800 + 17114760 + 661440      # v_template + shapedirs + posedirs + lbs_weights
 PER_PROBLEM_BYTES = 2032 + 82680                      # (betas, pose_feature, A, transl) in + vertices out
-PMC_JSON = os.path.join(ROOT, 'profiles', 'r2_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
+PMC_JSON = os.path.join(ROOT, 'profiles', 'r3_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
 # the imported reference itself (PyTorch CPU, create_fitting_closure + LBFGSLs + run_fitting) timed in the survey's
 # build container (it cannot travel to the GPU box): closures/s inside L-BFGS, 8 vCPUs
 SURVEY_REFERENCE_CLOSURES_PER_S = (74.0, 125.0)
 
+PRESETS = {
+    'configs1': dict(frames=32, views=8, persons=1),
+    'configs2': dict(frames=32, views=8, persons=1, sdf=True),
+    'configs3': dict(frames=32, views=8, persons=4),
+    'configs4': dict(frames=128, views=16, persons=1, half_basis=True),
+}
 
-def bytes_fwd(B, skin_topk=0):
+
+def bytes_fwd(B, skin_topk=0, half_basis=False):
     """Algorithmic bytes of one LBS vertex pass over B problems; with
-    k-sparse skinning weights the weight matrix is k (weight, joint) pairs per vertex instead of 24 floats."""
+    k-sparse skinning weights the weight matrix is k (weight, joint) pairs per vertex instead of 24 floats; the
+    half-width basis (configs[4]) is 2 bytes per posedirs / shapedirs element."""
     const = CONST_BYTES if not skin_topk else CONST_BYTES - 661440 + 6890 * skin_topk * 8
+    if half_basis:
+        const -= 8557380 + 413400
     return const + PER_PROBLEM_BYTES * B
 
 
-def pmc_value(key, kernel_substr, field='traffic_bytes'):
-    """A per-launch figure of the committed PMC summary (profiles/r2_pmc.json), or None."""
+def pmc_file():
+    for fn in (PMC_JSON, os.path.join(ROOT, 'profiles', 'r2_pmc.json')):
+        if os.path.isfile(fn):
+            return fn
+    return None
+
+
+def pmc_value(key, kernel_substr, field='traffic_bytes', table=None):
+    """A per-launch figure of a PMC summary (measured in this run, or the committed profiles/*_pmc.json), or None."""
     try:
-        with open(PMC_JSON) as f:
-            d = json.load(f)
-        for k, e in d.get(key, {}).items():
+        if table is None:
+            with open(pmc_file()) as f:
+                table = json.load(f)
+        for k, e in table.get(key, {}).items():
             if kernel_substr in k and field in e:
                 return round(e[field])
     except Exception:
@@ -62,37 +86,65 @@ def pmc_value(key, kernel_substr, field='traffic_bytes'):
     return None
 
 
-def pmc_traffic(key, kernel_substr):
-    """Measured HBM-side bytes per launch, or None."""
-    return pmc_value(key, kernel_substr, 'traffic_bytes')
+def measure_pmc(B, launches=40, timeout_s=150):
+    """HBM-side traffic and matrix-pipe busy cycles of the vertex pass at B problems, measured NOW with rocprofv3 PMC
+    counters on this GPU: separate passes for FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES (the guide's
+    recipe: the two size counters do not fit one pass), `--kernel-trace` only, on tools/pmc_vertex_pass.py's driver.
+    Returns the parsed table ({'B<n>': {kernel: {...}}}) or None when rocprofv3 is absent or a pass fails."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    from tools import pmc_vertex_pass as pv
+    out = tempfile.mkdtemp(prefix='mvfit_pmc_')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    specs = []
+    try:
+        for cn in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
+            d = os.path.join(out, cn)
+            cmd = [exe, '--pmc', cn, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable,
+                   os.path.join(ROOT, 'tools', 'pmc_vertex_pass.py'), 'drive', str(B), str(launches)]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            specs.append('B%d=%s' % (B, d))
+        return pv.parse(None, specs)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
-def mfma_util(key, kernel_substr, launch_us):
+def mfma_util(busy_cycles, launch_us):
     """Matrix-pipe utilisation of a launch: SQ_VALU_MFMA_BUSY_CYCLES (PMC, summed over the chip's SIMDs) over launch
     duration x 2.4 GHz x 1024 SIMDs.  Small by design: the contraction is the only MFMA work of the path (north_star)."""
-    busy = pmc_value(key, kernel_substr, 'mfma_busy_cycles_per_launch')
-    return None if busy is None else round(busy / (launch_us * 1e-6 * 2.4e9 * 1024), 4)
+    return None if busy_cycles is None else round(busy_cycles / (launch_us * 1e-6 * 2.4e9 * 1024), 4)
 
 
-def build_inputs(eng, frames, views, seed0):
-    """Synthetic config-2 inputs: GT parameter draws -> keypoints (by the GPU forward) -> noisy 2-D
-    observations + confidences; initial parameters = zeros, scale 1."""
+def build_inputs(eng, syn, frame_lo, frame_hi, persons, views, seed_base=1000):
+    """Synthetic inputs of this rank: for every person (own fixed shape) the frames [frame_lo, frame_hi) - GT parameter
+    draws (seeded by person and GLOBAL frame index) -> keypoints (by the GPU forward) -> noisy 2-D observations +
+    confidences; initial parameters = zeros, scale 1.  Problem order: person-major."""
     cams = syn.make_camera_ring(views)
-    fr = syn.make_frames(frames, seed0=seed0)
-    xgt = np.zeros((frames, 118), np.float32)
-    for k, (a, b) in dict(betas=(0, 10), global_orient=(10, 13), body_pose=(13, 82), transl=(82, 85),
-                          scale=(85, 86)).items():
-        xgt[:, a:b] = fr[k]
-    eng.set_problems(cams, np.zeros((frames, views, 17, 2), np.float32), np.ones((frames, views, 17), np.float32))
+    nf = frame_hi - frame_lo
+    B = persons * nf
+    xgt = np.zeros((B, 118), np.float32)
+    for p in range(persons):
+        betas = None if persons == 1 else np.random.default_rng(9000 + p).normal(0, 0.5, 10)
+        fr = syn.make_frames(nf, seed0=seed_base + 100000 * p + frame_lo, betas=betas)
+        for k, (a, b) in dict(betas=(0, 10), global_orient=(10, 13), body_pose=(13, 82), transl=(82, 85), scale=(85, 86)).items():
+            xgt[p * nf:(p + 1) * nf, a:b] = fr[k]
+    eng.set_problems(cams, np.zeros((B, views, 17, 2), np.float32), np.ones((B, views, 17), np.float32))
     _, joints = eng.vertices(xgt)
-    gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=seed0 + 7)
+    gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=seed_base + frame_lo + 7)
     eng.set_problems(cams, gt, conf)
-    x0 = np.zeros((frames, 118), np.float32)
+    x0 = np.zeros((B, 118), np.float32)
     x0[:, 85] = 1.0
     return cams, gt, conf, x0
 
 
-def demo_inputs():
+def demo_inputs(syn):
     """BASELINE configs[0]: the reference's shipped demo - real cameras, keypoints, VPoser checkpoint and the
     reference's own initial guess, from the committed golden files (oracle/make_golden_demo.py)."""
     gd = os.path.join(ROOT, 'tests', 'golden')
@@ -153,23 +205,27 @@ def cpu_baseline(model, cams, gt, conf, stages, use_vposer, vpw, budget_s=15.0):
     return out
 
 
-def vertex_pass_variants(model, views, skin_topk):
+def with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
     """Roofline of the vertex pass in its other instantiations, each on its own engine: the exact-fp32 contraction
     at 32 problems and the chunk-loop kernel at 128 problems (64 back-to-back launches inside one hipEvent pair)."""
     out = {}
     cams = syn.make_camera_ring(views)
 
     def measure(B, env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            eng = MvFit(model)
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        eng = with_env(env, lambda: MvFit(model))
         rng = np.random.default_rng(B)
         x = np.zeros((B, 118), np.float32)
         x[:, :86] = rng.normal(0, 0.2, (B, 86))
@@ -186,13 +242,48 @@ def vertex_pass_variants(model, views, skin_topk):
             ('half_basis_B32', 32, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_kernel<true>', None),
             ('half_basis_B128', 128, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_loop_kernel<true>', None)):
         ms = measure(B, env)
-        nbytes = bytes_fwd(B, skin_topk) - (8557380 + 413400 if 'HALF' in ''.join(env) else 0)     # half-width posedirs + shapedirs
+        nbytes = bytes_fwd(B, skin_topk, half_basis='MVFIT_HALF_BASIS' in env)
         ach = nbytes / (ms * 1e-3) / 1e9
         out[name] = dict(kernel=kern if skin_topk else kern.replace('<true>', '<false>'), problems=B,
                          avg_launch_us=round(ms * 1e3, 2), algorithmic_bytes=nbytes,
                          achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
-                         traffic=pmc_traffic(key, 'split_loop') if key else None)
+                         traffic=pmc_value(key, 'split_loop') if key else None)
     return out
+
+
+def prior_variants(MvFit, syn, _lib, stage_weights, model, frames, views, steps=2):
+    """The same workload with the other pose priors (VPoser-L2 - the reference's shipped yaml default,
+    use_vposer: true - and GMM): whole-fit closures/s, one warm-up fit + `steps` timed fits each, own engine."""
+    out = {}
+    for name, flag, kw in (('prior_vposer', _lib.F_VPOSER, dict(vposer=syn.make_vposer_decoder())),
+                           ('prior_gmm', _lib.F_PRIOR_GMM, dict(gmm=syn.gmm_constants(syn.make_gmm())))):
+        eng = MvFit(model, **kw)
+        cams, gt, conf, x0 = build_inputs(eng, syn, 0, frames, 1, views)
+        stages = stage_weights(1536.0, flags=flag)
+        x0_d = torch.tensor(x0, device=eng.device)
+        eng.fit(x0_d, stages)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ncl = []
+        for _ in range(steps):
+            xf, st = eng.fit(x0_d, stages)
+            ncl.append(st['n_closure'])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tot = sum(int(n.sum().item()) for n in ncl)
+        out[name] = dict(value=round(tot / dt, 1), unit='closures/s', ms_per_step=round(1e3 * dt / steps, 3),
+                         closures_per_fit_per_frame=round(tot / steps / frames, 1), closure_rounds_per_fit=int(ncl[-1].max().item()),
+                         final_loss_median=float(np.median(st['final_loss'].cpu().numpy())), vertex_passes_last_fit=st.get('passes'))
+        eng.close()
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -200,10 +291,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='configs1', choices=['configs1', 'demo'],
-                    help="configs1: BASELINE configs[1] (default); demo: configs[0], the reference's shipped demo inputs")
-    ap.add_argument('--frames', type=int, default=32, help='frames (problems) per GPU')
-    ap.add_argument('--views', type=int, default=8)
+    ap.add_argument('--config', default='configs1', choices=['configs1', 'demo', 'configs0', 'configs2', 'configs3', 'configs4'],
+                    help='named BASELINE.json workload (see the module docstring); --frames / --views / --persons override a preset')
+    ap.add_argument('--frames', type=int, default=None, help='frames per GPU and person (with --strong: the total)')
+    ap.add_argument('--views', type=int, default=None)
+    ap.add_argument('--persons', type=int, default=None, help='subjects (own shape each); every GPU fits its frames of all of them')
     ap.add_argument('--prior', default='l2', choices=['l2', 'vposer', 'gmm'])
     ap.add_argument('--sparse', action='store_true',
                     help='objective-vertices-only closure (no full vertex pass per closure)')
@@ -212,13 +304,28 @@ def main():
     ap.add_argument('--skin-topk', type=int, default=4,
                     help='non-zero skinning weights per vertex of the synthetic body (SMPL: <= 4); 0 = dense rows')
     ap.add_argument('--sdf', action='store_true',
-                    help='configs[2]: SDF interpenetration term on (as wired: first triangle, grid 128; yaml coll_loss_weights)')
+                    help='configs[2]: SDF interpenetration term on (grid 128; yaml coll_loss_weights)')
+    ap.add_argument('--sdf-faces', default='wired', choices=['wired', 'all'],
+                    help="wired: the first triangle only, as the reference's call site makes the op see it; all: the 13,776 faces")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline variants')
+    ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline / prior variants')
+    ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 PMC passes (traffic then comes from profiles/*_pmc.json)')
     ap.add_argument('--dist-backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a dry run)')
     ap.add_argument('--single-device', action='store_true',
                     help='dry run of the multi-rank path on ONE GPU: every rank uses cuda:0 (needs --dist-backend gloo)')
     args = ap.parse_args()
+
+    # ---- --gpus N without a launcher: start the N ranks here (one process per GPU, torch.distributed over 127.0.0.1) ----
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
+    from mvsmplfitting_amd import _lib
+    from mvsmplfitting_amd import synthetic as syn
+    from mvsmplfitting_amd.engine import MvFit, stage_weights
+    from mvsmplfitting_amd.sharding import gather_results, shard_range
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -237,23 +344,31 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    demo = args.config == 'demo'
+    demo = args.config in ('demo', 'configs0')
+    preset = dict(PRESETS.get(args.config, PRESETS['configs1']))
+    frames = args.frames if args.frames is not None else preset['frames']
+    views = args.views if args.views is not None else preset['views']
+    persons = args.persons if args.persons is not None else preset['persons']
+    sdf = args.sdf or preset.get('sdf', False)
+    half_basis = bool(preset.get('half_basis')) or os.environ.get('MVFIT_HALF_BASIS') == '1'
     if demo:
         assert world == 1, 'the demo is one frame'
-        g, vpw, model, cams, gt, conf, x0 = demo_inputs()
-        args.prior, args.views, args.skin_topk = 'vposer', 6, 0
+        g, vpw, model, cams, gt, conf, x0 = demo_inputs(syn)
+        args.prior, views, args.skin_topk, persons = 'vposer', 6, 0, 1
         gmm = None
-        B = total = 1
+        B = total = total_frames = 1
         lo = 0
     else:
         model = syn.make_body_model(0, skin_topk=args.skin_topk or None)
         vpw = syn.make_vposer_decoder() if args.prior == 'vposer' else None
         gmm = syn.make_gmm() if args.prior == 'gmm' else None
-        total = args.frames if args.strong else args.frames * world
-        lo, hi = shard_range(total, world, rank)       # contiguous global frames of this rank; seeds follow the global index
-        B = hi - lo
-        assert B > 0, 'more ranks than frames'
-    eng = MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank)
+        total_frames = frames if args.strong else frames * world
+        lo, hi = shard_range(total_frames, world, rank)       # contiguous global frames of this rank; seeds follow the global index
+        assert hi > lo, 'more ranks than frames'
+        B = persons * (hi - lo)
+        total = persons * total_frames
+    eng = with_env({'MVFIT_HALF_BASIS': '1'} if half_basis else {},
+                   lambda: MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank))
     flags = 0
     if args.prior == 'vposer':
         flags |= _lib.F_VPOSER
@@ -261,13 +376,13 @@ def main():
         flags |= _lib.F_PRIOR_GMM
     if args.sparse:
         flags |= _lib.F_SPARSE_VERTS
-    stages = stage_weights(1536.0, flags=flags, coll_w=[0.0, 0.0, 1000.0, 4500.0] if args.sdf else None)
-    if args.sdf:
-        eng.set_sdf(model['faces'], num_faces=1, grid_size=128)      # fit_smpl.yaml:55-59, fitting.py:367-368
+    stages = stage_weights(1536.0, flags=flags, coll_w=[0.0, 0.0, 1000.0, 4500.0] if sdf else None)
+    if sdf:                                                  # fit_smpl.yaml:55-59, fitting.py:367-368
+        eng.set_sdf(model['faces'], num_faces=1 if args.sdf_faces == 'wired' else None, grid_size=128)
     if demo:
         eng.set_problems(cams, gt, conf)
     else:
-        cams, gt, conf, x0 = build_inputs(eng, B, args.views, seed0=1000 + lo)
+        cams, gt, conf, x0 = build_inputs(eng, syn, lo, hi, persons, views)
     x0_d = torch.tensor(x0, device=dev)
 
     def barrier():
@@ -276,10 +391,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather(x):
+        # per-person blocks of this rank's frames -> [persons, frames_total, 118]: one all_gather (the path's only collective)
+        nf = x.shape[0] // persons
+        return gather_results(x.reshape(persons, nf, -1).transpose(0, 1).contiguous(), total_frames)
+
     for _ in range(max(args.warmup, 1) if args.warmup else 0):
         xw, st = eng.fit(x0_d, stages)
         if world > 1:
-            gather_results(xw, total)             # also sets up the RCCL rings outside the timed region
+            gather(xw)                            # also sets up the RCCL rings outside the timed region
     # torch loads its own reduction / copy kernels lazily on first use (~80 ms): touch the exact ops of
     # the timed loop once here (also with --warmup 0), so that module loading is not billed to a fit
     _z = torch.zeros(B, device=dev, dtype=torch.int32)
@@ -290,19 +410,21 @@ def main():
     n_iter = 0
     finals = None
     gathered = None
-    n_max = 0
     counts = []
     passes = None
+    lost = [0, 0]
     busy = 0.0
     for _ in range(args.steps):
         tb = time.perf_counter()
         xf, st = eng.fit(x0_d, stages)             # returns when this rank's GPU has finished the fit
         busy += time.perf_counter() - tb
         if world > 1:
-            gathered = gather_results(xf, total)   # the path's only collective (RCCL over xGMI), inside the step
+            gathered = gather(xf)                  # RCCL over xGMI, inside the step
         counts.append((st['n_closure'], st['n_iter']))      # device tensors: read after the timed region
         finals = st['final_loss']
         passes = st.get('passes')
+        if passes:
+            lost[0] += passes['missed']; lost[1] += passes['timed_out']
     barrier()
     dt = time.perf_counter() - t0
     for ncl_t, nit_t in counts:
@@ -315,19 +437,19 @@ def main():
     busy_all = [round(1e3 * busy / args.steps, 3)]
     if world > 1:
         import torch.distributed as dist
-        red = torch.tensor([float(n_closure), float(n_iter)], device=dev, dtype=torch.float64)
+        red = torch.tensor([float(n_closure), float(n_iter), float(lost[0]), float(lost[1])], device=dev, dtype=torch.float64)
         dist.all_reduce(red)
         tm = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         bz = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(bz, torch.tensor([busy / args.steps * 1e3], device=dev, dtype=torch.float64))
         busy_all = [round(float(b.item()), 3) for b in bz]
-        assert gathered.shape[0] == total
+        assert gathered.shape[0] == total_frames
         tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
+        lost = [int(red[2].item()), int(red[3].item())]
 
-    # roofline of the dominant HBM kernel (LBS vertex pass), measured live with HIP events on the ctx stream: 64
-    # back-to-back launches of the kernel exactly as the timed fits launched it, inside one event pair (a pair around a
-    # single launch contains the markers' own 2-4 us)
+    # roofline of the dominant HBM kernel (LBS vertex pass), measured live with HIP events on the stream the kernel is
+    # launched on
     roof = None
     if not args.sparse and not demo:
         in_fit = bool(passes and passes['run'] > 0)          # asynchronous fit: ring operands, non-temporal streams
@@ -345,27 +467,39 @@ def main():
         ms_b2b = min(eng.profile_vertex_pass_ms(64, as_in_async_fit=in_fit) for _ in range(3))
         ms_plain = min(eng.profile_vertex_pass_ms(64) for _ in range(3))
         ms_fit = pr['vertex_pass_ms'] if pr['vertex_pass_launches'] > 0 else ms_b2b
-        ach = bytes_fwd(B, args.skin_topk) / (ms_fit * 1e-3) / 1e9
+        nbytes = bytes_fwd(B, args.skin_topk, half_basis)
+        ach = nbytes / (ms_fit * 1e-3) / 1e9
+        # (c) HBM-side traffic / matrix-pipe cycles per launch: rocprofv3 PMC passes run NOW on this GPU (rank 0, one GPU),
+        #     else the committed summary of the same kernel
+        pmc_key = 'B%d' % B
+        table, src = None, None
+        standard = views == 8 and args.skin_topk == 4 and not half_basis
+        if rank == 0 and world == 1 and not args.no_pmc and standard:
+            table = measure_pmc(B)
+            src = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes, collected in this run (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 wide-read correction)'
+        if table is None and standard and pmc_file():
+            src = '%s (rocprofv3 --pmc passes of an earlier run of the same kernel; tools/collect_profiles.sh)' % os.path.relpath(pmc_file(), ROOT)
+        traffic = pmc_value(pmc_key, kname.split('<')[0], 'traffic_bytes', table) if standard else None
+        busy_cy = pmc_value(pmc_key, kname.split('<')[0], 'mfma_busy_cycles_per_launch', table) if standard else None
         roof = dict(bound='hbm', kernel=kname, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(ach / HBM_PEAK_GBS, 4),
-                    traffic=pmc_traffic('B32' if B == 32 else ('B128' if B == 128 else ''), kname.split('<')[0])
-                    if (args.views == 8 and args.skin_topk == 4) else None,
-                    traffic_source='profiles/r2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; tools/collect_profiles.sh)',
-                    algorithmic_bytes=bytes_fwd(B, args.skin_topk), avg_launch_us=round(ms_fit * 1e3, 2),
-                    mfma_util=mfma_util('B32' if B == 32 else ('B128' if B == 128 else ''), kname.split('<')[0], ms_fit * 1e3)
-                    if (args.views == 8 and args.skin_topk == 4) else None,
-                    mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per launch (profiles/r2_pmc.json) / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src if traffic is not None else None,
+                    algorithmic_bytes=nbytes, avg_launch_us=round(ms_fit * 1e3, 2),
+                    mfma_util=mfma_util(busy_cy, ms_fit * 1e3),
+                    mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per launch / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',
                     timed_region='every vertex-pass launch of one complete fit (%d launches), begin / end of each dispatch stamped by '
                                  'the runtime (hipExtLaunchKernelGGL events on the stream the kernel is launched on)' % pr['vertex_pass_launches'],
                     launch_flavour='asynchronous fit: operands from the ring, non-temporal basis stream and vertex stores, the optimiser '
-                                   'kernel running concurrently on 32 other CUs' if in_fit else 'chained mode (plain loads, side outputs)',
+                                   'kernel running concurrently on %d other CUs' % min(B, 160) if in_fit else 'chained mode (plain loads, side outputs)',
                     alone_back_to_back_us=round(ms_b2b * 1e3, 2), alone_back_to_back_plain_loads_us=round(ms_plain * 1e3, 2),
-                    frac_alone_plain_loads=round(bytes_fwd(B, args.skin_topk) / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    frac_alone_plain_loads=round(nbytes / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     launches_per_fit=(passes or {}).get('run'))
-        if rank == 0 and not args.no_variants and world == 1:
-            roof['variants'] = vertex_pass_variants(model, args.views, args.skin_topk)
+        if rank == 0 and not args.no_variants and world == 1 and args.config == 'configs1':
+            roof['variants'] = vertex_pass_variants(MvFit, syn, model, views, args.skin_topk)
 
     if rank == 0:
+        variants = None
+        if not args.no_variants and world == 1 and args.config == 'configs1' and args.prior == 'l2' and not sdf and not args.sparse:
+            variants = prior_variants(MvFit, syn, _lib, stage_weights, model, frames, views)
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.prior != 'gmm':
             cpu_stages = [dict(s) for s in stages]
@@ -375,45 +509,57 @@ def main():
                 note='the imported reference itself (create_fitting_closure + LBFGSLs + run_fitting, PyTorch CPU, 1 and 8 '
                      'threads of 8 vCPUs) as timed in SURVEY.md section 6; it does not exist on the GPU box')
         fl = finals.cpu().numpy()
+        per_gpu = '%s%d views x %d synthetic frames%s' % ('%d persons x ' % persons if persons > 1 else '1 person x ', views,
+                                                          total_frames if args.strong else (hi - lo if not demo else 1),
+                                                          ' in total' if args.strong else ' per GPU')
         if demo:
             workload = ('configs[0]: the reference demo (cfg_files/fit_smpl.yaml): 1 frame x 6 real views x 1 person, real keypoints / '
                         'cameras, VPoser decoder of the shipped checkpoint, synthetic body, 4 yaml stages')
         else:
-            workload = ('%s: 1 person x %d views x %d synthetic frames%s, GMoF + pose prior (%s) + shape + angle priors, %s, 4 yaml stages'
-                        % ('configs[2]' if args.sdf else 'configs[1]', args.views, total if args.strong else B,
-                           ' in total' if args.strong else ' per GPU', args.prior,
-                           'SDF term as wired (first triangle, grid 128, yaml coll_loss_weights)' if args.sdf else 'no SDF'))
+            tag = {'configs1': 'configs[1]', 'configs2': 'configs[2]', 'configs3': 'configs[3] (4 persons x 8 views x 256 frames over 8 GPUs = 4 x 32 frames per GPU)',
+                   'configs4': 'configs[4] (16-view rig x 1024 frames over 8 GPUs = 128 frames per GPU, half-width blendshape operands)'}[args.config]
+            if sdf and args.config == 'configs1':
+                tag = 'configs[2]'
+            sdf_txt = 'no SDF' if not sdf else ('SDF term, grid 128, yaml coll_loss_weights, %s' %
+                                               ('first triangle only as the reference wires it' if args.sdf_faces == 'wired' else 'all 13,776 faces'))
+            workload = '%s: %s, GMoF + pose prior (%s) + shape + angle priors, %s, 4 yaml stages' % (tag, per_gpu, args.prior, sdf_txt)
         if args.sparse:
             mode = 'objective-vertices-only'
         elif passes and passes['run'] > 0:
             mode = ('full 6890-vertex pass per closure, asynchronous: one optimiser kernel publishes the operands of every trial '
-                    'point, the pass of closure round r runs concurrently on the other CUs')
+                    'point, the pass of closure round r runs concurrently on the other CUs (ring with back-pressure: no pass is lost)')
         else:
             mode = 'full 6890-vertex pass per closure, chained (pass -> step kernel per round)'
         out = {
             'metric': 'L-BFGS closure evaluations per second (fwd+bwd, all concurrently fitted problems), '
-                      '%d-view 1-person 4-stage fits' % args.views,
+                      '%d-view 1-person 4-stage fits' % views,
             'value': round(tot_closure / tmax, 1), 'unit': 'closures/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * tmax / args.steps, 3),
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'dtype_note': 'all arithmetic fp32 (line-search scalars fp64 like the reference); the blendshape contraction of the '
                           'vertex pass takes its fp32 products as error-compensated split-fp16 pairs on the matrix pipe with '
-                          'fp32 accumulation (vertices 5e-7 from the float64 oracle, as with the exact fp32 chain)',
+                          'fp32 accumulation (vertices 5e-7 from the float64 oracle, as with the exact fp32 chain)' +
+                          ('; configs[4]: only the fp16 hi halves of the basis are streamed (vertices <= 2e-5)' if half_basis else ''),
             'data': ('real demo keypoints / cameras / VPoser checkpoint of the reference, seeded SMPL-shaped body' if demo else
                      'synthetic (seeded SMPL-shaped body%s, camera ring, noisy projected keypoints)'
                      % ((', %d skinning weights per vertex like SMPL' % args.skin_topk) if args.skin_topk else ', dense skinning rows')),
-            'config': {'workload': workload, 'frames_per_gpu': B, 'frames_total': total, 'views': args.views, 'prior': args.prior,
-                       'closure_mode': mode,
-                       'parallelism': 'frame-sharded x%d, RCCL all_gather of results' % world},
+            'config': {'workload': workload, 'problems_per_gpu': B, 'frames_per_gpu': B // persons, 'persons': persons,
+                       'frames_total': total_frames, 'problems_total': total, 'views': views, 'prior': args.prior,
+                       'closure_mode': mode, 'parallelism': 'frame-sharded x%d, RCCL all_gather of results' % world},
             'ms_to_convergence_per_frame': round(1e3 * tmax / args.steps / max(B, 1), 4),
             'lbfgs_iters_per_s': round(tot_iter / tmax, 1),
             'closures_per_fit_per_frame': round(tot_closure / args.steps / total, 1),
             'closure_rounds_per_fit': n_max,      # = closures of the slowest frame of rank 0's batch
             'final_loss_median': float(np.median(fl)),
             'vertex_passes_last_fit': passes,
+            'vertex_passes_lost_in_timed_fits': {'missed': lost[0], 'timed_out': lost[1]},
             'per_rank_busy_ms_per_step': busy_all,
+            'variants': variants,
             'roofline': roof, 'cpu_baseline': cpu,
         }
+        if lost[0] or lost[1]:
+            out['invalid_reason'] = ('%d vertex passes lost their operands / %d gates timed out in the timed fits: "a full pass per '
+                                     'closure" does not hold for this run' % (lost[0], lost[1]))
         if demo:
             out['reference_fit'] = dict(final_loss_fp32=float(g['fit_final32']), final_loss_fp64=float(g['fit_final64']),
                                         closures_fp32=int(g['fit_ncl32'].sum()), closures_fp64=int(g['fit_ncl64'].sum()),

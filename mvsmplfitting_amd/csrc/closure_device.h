@@ -92,6 +92,7 @@ struct ClosureLds {
     int flags_dropped;              // bit0: pose prior dropped, bit1: angle prior dropped
     int gmm_sel;
     int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
+    unsigned sh_pass_done;          // asynchronous fit: last value read from the ring's pass_done (publishing wave only)
     const SdfAdj* sdf_adj;          // SDF term of this problem (sdf_term.hip), or null
     float sdf_fac, sdf_pad;         // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
     double total;
@@ -1181,10 +1182,29 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 constexpr int PUBLISH_WAVE = 3;      // idle in the loss phase that follows (data term: waves 0-1 at <= 7 views; 3-D term and priors: waves 5-7)
 
-__device__ void publish_pose_async(const ClosureLds& L, const AsyncRing& R, int slot, int b, int tid) {
+__device__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int tid) {
     // All 129 words go out from ONE wave, which also stores the tag later: the hand-off needs no workgroup barrier.
     const int l = tid - 64 * PUBLISH_WAVE;
     if (l < 0 || l >= 64) return;
+    // Back-pressure: slot r % nslots still holds the operands of round r - nslots until that round's pass has run.  The
+    // gate kernels publish how many rounds' passes are complete; the value is cached in LDS and only re-read when it does
+    // not cover this round (it grows by ~nslots between two reads when the passes keep up: a few polls per fit).  Only this
+    // wave waits - it idles through the loss phase anyway; when the passes are slower than the optimiser the whole
+    // workgroup ends up waiting for it at the next barrier, i.e. the optimiser runs at the passes' rate.  Bounded by the
+    // wall clock (20 ms): a stuck pass stream cannot hang the fit (the overwritten slot is then counted as missed).
+    if (round >= (unsigned)R.nslots) {
+        const unsigned need = round - (unsigned)R.nslots + 1u;
+        unsigned have = L.sh_pass_done;
+        if (have < need) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                have = __hip_atomic_load(R.pass_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (have >= need || wall_clock64() - t0 > 2000000) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (l == 0) L.sh_pass_done = have;
+        }
+    }
     const unsigned Bp = (unsigned)R.Bpad;
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(R.coefH, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(R.Amat, 0, 0x7fffffff, 0x00020000);

@@ -28,7 +28,7 @@ namespace mvfit {
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t vertex_pass_configure();
-hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream);
+hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
 size_t sdf_work_bytes(int B, int nv);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
-                          const AsyncRing* ring = nullptr) {
+                          const AsyncRing* ring = nullptr, int pb = 0) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     const LbOpts& O = L.opts;
@@ -227,7 +227,7 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
     const unsigned a_round = ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
     const int a_slot = ring ? (int)(a_round % (unsigned)ring->nslots) : 0;
-    if (ring) publish_pose_async(L, *ring, a_slot, blockIdx.x, tid);
+    if (ring) publish_pose_async(L, *ring, a_slot, a_round, pb, tid);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     PH_T(3);
     if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
@@ -238,7 +238,7 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
         }
     }
     closure_backward(M, L, nviews, W, tid);
-    if (ring) publish_tag(*ring, a_slot, blockIdx.x, a_round, tid);        // the stores have long drained by now
+    if (ring) publish_tag(*ring, a_slot, pb, a_round, tid);                // the stores have long drained by now
     PH_T(8);
     LbState S;
     LbVecs<float> V;
@@ -334,16 +334,17 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 // history ring lives in LDS behind the closure workspace.
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
-                                                                 int max_rounds, AsyncRing ring) {
+                                                                 int max_rounds, AsyncRing ring, int b_lo, int done_target) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + gridDim.x): one sub-batch of mvfit_fit
     prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid);
     opts_in(L, SW, O, tid);
     __syncthreads();
     if (L.opt.lbS.status != 0) return;
     if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
+    if (tid == 64 * PUBLISH_WAVE) L.sh_pass_done = 0u;
     float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
     float* gs = F.stps + (size_t)b * LB_HIST * LB_D;
     const bool resume = L.opt.lbS.n_closure > 0;          // relaunch after a round cap: restore the ring
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         asm volatile("" : "+v"(t));
         done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
-                         ring.tag ? &ring : nullptr);
+                         ring.tag ? &ring : nullptr, b);
         if (done) break;                                  // block-uniform
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         if (ring.tag) {
             // passes of later rounds have nothing to wait for from this problem; the last problem tells the host
             __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (finished == (int)gridDim.x) __hip_atomic_store(ring.host_done, finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (finished == done_target) __hip_atomic_store(ring.host_done, finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (!done)
@@ -951,7 +952,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
                   c->d_sdf_adj, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
     {
-        void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats};
+        void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats, c->ring.pass_done};
         for (void* q : rp) if (q) hipFree(q);
         c->ring = AsyncRing{};
     }
@@ -1315,6 +1316,7 @@ static int ensure_async(mvfit_ctx* c) {
     HIP_OK(c, hipMalloc(&R.tag, kRingSlots * Bp * 4));
     HIP_OK(c, hipMalloc(&R.done_round, Bp * 4));
     HIP_OK(c, hipMalloc(&R.stats, 4 * 4));
+    HIP_OK(c, hipMalloc(&R.pass_done, 4));
     HIP_OK(c, hipMemset(R.coefH, 0, kRingSlots * Bp * KROWS * 4));
     HIP_OK(c, hipMemset(R.Amat, 0, kRingSlots * Bp * 288 * 4));
     HIP_OK(c, hipMemset(R.tau, 0, kRingSlots * Bp * 4 * 4));
@@ -1330,53 +1332,65 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     const int B = c->B;
     const AsyncRing& R = c->ring;
     volatile int* h_done = c->h_async_done;
-    *h_done = 0;
     // polled words: re-initialised every call
     HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * c->Bpad * 4, c->stream));
     HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
-    HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
-    HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
-    hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
-                       (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R);
-    HIP_OK(c, hipGetLastError());
-    // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
-    int k = 0;
+    // More problems than the optimiser gets CUs (one workgroup per CU, >= 96 CUs left to the passes): time-sliced in
+    // sub-batches of whole 32-problem chunks, one after the other - every sub-batch is the same asynchronous fit (problems
+    // are independent: the results do not depend on the slicing, tests/test_gpu_large_batch.py).
+    const int nsub = (B + kAsyncMaxB - 1) / kAsyncMaxB;
+    const int per = ((B + nsub - 1) / nsub + 31) / 32 * 32;
     static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
-    for (;; ++k) {
-        for (int i = 0; i < kPassBatch && !dbg_nopass; ++i) {
-            const unsigned r = (unsigned)(k * kPassBatch + i);
-            const int slot = (int)(r % (unsigned)kRingSlots);
-            DevPose P = c->P;                                          // side outputs / unused fields as in the chained mode
-            P.coefH = R.coefH + (size_t)slot * c->Bpad * (KROWS / 4);
-            P.coefT = nullptr;
-            P.Amat = R.Amat + (size_t)slot * c->Bpad * 288;
-            P.tau = R.tau + (size_t)slot * c->Bpad * 4;
-            P.tag = R.tag + (size_t)slot * c->Bpad;
-            P.done_round = R.done_round;
-            P.stats = R.stats;
-            P.round = r;
-            static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
-            P.pad_ = dbg_nt;                  // experiment switch: bit 0 = plain basis loads, bit 1 = plain vertex stores
-            float* vout = c->d_verts;
-            if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
-            hipError_t e = launch_pass_gate(P, B, c->pass_stream);
-            hipEvent_t ea = nullptr, eb = nullptr;
-            if (c->profile && c->ev_vp.size() < 4096) {            // mvfit_profile: the dispatch's own begin / end stamps
-                hipEventCreate(&ea); hipEventCreate(&eb);
-                c->ev_vp.emplace_back(ea, eb);
+    for (int b_lo = 0; b_lo < B; b_lo += per) {
+        const int b_hi = std::min(B, b_lo + per);
+        *h_done = 0;
+        HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4, c->stream));
+        HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
+        HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
+        hipLaunchKernelGGL(fit_persistent_kernel, dim3(b_hi - b_lo), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
+                           (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, b_hi);
+        HIP_OK(c, hipGetLastError());
+        // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
+        int k = 0;
+        for (;; ++k) {
+            for (int i = 0; i < kPassBatch && !dbg_nopass; ++i) {
+                const unsigned r = (unsigned)(k * kPassBatch + i);
+                const int slot = (int)(r % (unsigned)kRingSlots);
+                DevPose P = c->P;                                          // side outputs / unused fields as in the chained mode
+                P.coefH = R.coefH + (size_t)slot * c->Bpad * (KROWS / 4);
+                P.coefT = nullptr;
+                P.Amat = R.Amat + (size_t)slot * c->Bpad * 288;
+                P.tau = R.tau + (size_t)slot * c->Bpad * 4;
+                P.tag = R.tag + (size_t)slot * c->Bpad;
+                P.done_round = R.done_round;
+                P.stats = R.stats;
+                P.pass_done = R.pass_done;
+                P.round = r;
+                P.chunk0 = b_lo / 32;
+                static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
+                P.pad_ = dbg_nt;                  // experiment switch: bit 0 = plain basis loads, bit 1 = plain vertex stores
+                float* vout = c->d_verts;
+                if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
+                hipError_t e = launch_pass_gate(P, b_lo, b_hi, c->pass_stream);
+                hipEvent_t ea = nullptr, eb = nullptr;
+                if (c->profile && c->ev_vp.size() < 4096) {            // mvfit_profile: the dispatch's own begin / end stamps
+                    hipEventCreate(&ea); hipEventCreate(&eb);
+                    c->ev_vp.emplace_back(ea, eb);
+                }
+                if (e == hipSuccess) e = launch_vertex_pass(c->M, P, b_hi, vout, c->ksplit, c->pass_stream, ea, eb);
+                if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
             }
-            if (e == hipSuccess) e = launch_vertex_pass(c->M, P, B, vout, c->ksplit, c->pass_stream, ea, eb);
-            if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
+            HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
+            if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
+            if (*h_done >= b_hi) break;
+            if ((k + 1) * kPassBatch >= cap) break;
         }
-        HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
-        if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
-        if (*h_done >= B) break;
-        if ((k + 1) * kPassBatch >= cap) break;
+        // behind the optimiser kernel (all problems of the sub-batch, or the round cap) the ctx stream continues behind the
+        // last passes (nothing of the fit's result depends on them: ordering only)
+        HIP_OK(c, hipStreamWaitEvent(c->stream, c->ev_batch[k & 3], 0));
     }
-    // behind the optimiser kernel (all problems, or the round cap) the ctx stream continues behind the last passes
-    // (nothing of the fit's result depends on them: ordering only); one host wait for all of it below
-    HIP_OK(c, hipStreamWaitEvent(c->stream, c->ev_batch[k & 3], 0));
+    // one host wait for all of it
     HIP_OK(c, hipMemcpyAsync(c->async_stats, R.stats, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipMemcpyAsync(c->h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -1428,8 +1442,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
     // MVFIT_ROUND_MODE=serial keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
     const char* rmode = getenv("MVFIT_ROUND_MODE");
-    const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && c->B <= kAsyncMaxB &&
-                       !(rmode && !strcmp(rmode, "serial"));
+    const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && !(rmode && !strcmp(rmode, "serial"));
     for (unsigned& v : c->async_stats) v = 0;
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
@@ -1452,7 +1465,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
             const int chunk = std::min(cap - rounds, 1 << 20);
             hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
                                (const ObsBlock*)c->d_obs, c->V, SW, O, c->P,
-                               c->F, chunk, AsyncRing{});
+                               c->F, chunk, AsyncRing{}, 0, B);
             HIP_OK(c, hipGetLastError());
             rounds += chunk;
             HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));

@@ -157,6 +157,10 @@ struct DevPose {
     unsigned* stats;             // [4] passes run / chunk passes skipped (all problems finished) / missed / timed out
     unsigned round;              // closure round this pass belongs to
     unsigned pad_;
+    // sub-batch of the asynchronous fit (mvfit_fit time-slices batches with more problems than the optimiser gets CUs):
+    // this launch covers the 32-problem chunks from chunk0 on, up to the problem count it is given
+    int chunk0;
+    unsigned* pass_done;         // [1] rounds whose pass has completed (written by the gate of the next round)
 };
 
 // Pose-operand ring of the asynchronous fit: slot (r % nslots) holds, per problem, the vertex-pass operands of the
@@ -171,6 +175,10 @@ struct AsyncRing {
     unsigned* stats;             // [4]
     int* host_done;              // pinned host word: set to the number of problems by the last one to finish
     int nslots, Bpad;
+    // back-pressure: rounds whose vertex pass has completed.  A problem publishes round r into slot r % nslots only once
+    // the pass of round r - nslots has run (pass_done > r - nslots): a slot is never overwritten before its pass read it,
+    // however slow the passes are (the optimiser is throttled to their rate instead).
+    unsigned* pass_done;
 };
 
 // SDF interpenetration term (fitting.py:352-393), per problem

@@ -52,10 +52,13 @@ constexpr int VP_GPS = KGROUPS / VP_KSPLIT;      // 7 groups of 4 k-steps per sl
 // polls the tag of problem b (relaxed agent-scope loads, s_sleep between polls, bounded by the wall clock - on a
 // timeout the pass simply runs on what the slot holds).  The kernel boundary behind it is the acquire.
 __global__ void pass_gate_kernel(const unsigned* __restrict__ tag, const unsigned* __restrict__ done_round,
-                                 unsigned* __restrict__ stats, unsigned round, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;      // grid covers B; every wave polls its own 64 problems
+                                 unsigned* __restrict__ stats, unsigned* __restrict__ pass_done, unsigned round, int b_lo, int B) {
+    const int b = b_lo + blockIdx.x * blockDim.x + threadIdx.x;      // grid covers [b_lo, B); every wave polls its own 64 problems
     const bool mine = b < B;
     const unsigned want = round + 1u;
+    // stream order: the pass of round - 1 has finished when this kernel starts - tell the optimiser (back-pressure: it
+    // does not overwrite ring slot (round - 1) % nslots ... before this)
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pass_done, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned t = want, d = 0u;
     bool timed_out = false;
     const long long t_start = wall_clock64();
@@ -78,8 +81,9 @@ __global__ void pass_gate_kernel(const unsigned* __restrict__ tag, const unsigne
     }
 }
 
-hipError_t launch_pass_gate(const DevPose& P, int B, hipStream_t stream) {
-    hipLaunchKernelGGL(pass_gate_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, P.tag, P.done_round, P.stats, P.round, B);
+hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t stream) {
+    hipLaunchKernelGGL(pass_gate_kernel, dim3((B - b_lo + 63) / 64), dim3(64), 0, stream, P.tag, P.done_round, P.stats, P.pass_done,
+                       P.round, b_lo, B);
     return hipGetLastError();
 }
 
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
-    const int chunk = blockIdx.y;
+    const int chunk = P.chunk0 + blockIdx.y;
     const int b0 = chunk * 32;
     if (!pass_chunk_live(P, b0, B, smem, tid)) return;
     const bool mfma_role = wave < 4;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
-    const int chunk = blockIdx.y;
+    const int chunk = P.chunk0 + blockIdx.y;
     const int b0 = chunk * 32;
     if (!pass_chunk_live(P, b0, B, smem, tid)) return;
     const bool stream_nt = VP_NT_LOADS && P.tag != nullptr && !(P.pad_ & 1u);       // uniform
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                                              reinterpret_cast<float4*>(tau_dst), 16, 0, 0);
     };
 
-    int chunk = blockIdx.y;
+    int chunk = P.chunk0 + (int)blockIdx.y;
     load_operands(chunk, tau_l);
     __builtin_amdgcn_sched_barrier(0);
     // ---- chunk-invariant operands: the basis (B operands, kept in registers over all chunks of this workgroup:
@@ -726,7 +730,7 @@ static void vp_launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, hipEv
 hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
                               hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     (void)ksplit;
-    dim3 grid(M.ntiles, (B + 31) / 32);
+    dim3 grid(M.ntiles, (B + 31) / 32 - P.chunk0);       // chunks [P.chunk0, ceil(B / 32))
     if (M.bs_h2) {        // split-fp16 contraction (default); MVFIT_EXACT_FP32=1 at mvfit_create keeps the fp32 MFMA chain
         // more than one 32-problem chunk: one workgroup per vertex tile walks ALL chunks with the tile's basis held in
         // registers - the basis is read once per launch whatever the number of problems (MVFIT_VP_CHUNK_GRID=1: one

@@ -69,9 +69,11 @@ def parse(out_json, specs):
                 # cycles the matrix pipes were busy, summed over all SIMDs of the chip (32 per v_mfma_f32_32x32x16_f16);
                 # bench.py divides by launch duration x 2.4 GHz x 1024 SIMDs for the utilisation
                 e['mfma_busy_cycles_per_launch'] = e['SQ_VALU_MFMA_BUSY_CYCLES_avg']
-    with open(out_json, 'w') as f:
-        json.dump(res, f, indent=1, sort_keys=True)
-    print(json.dumps(res, indent=1, sort_keys=True))
+    if out_json:
+        with open(out_json, 'w') as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+        print(json.dumps(res, indent=1, sort_keys=True))
+    return res
 
 
 if __name__ == '__main__':
