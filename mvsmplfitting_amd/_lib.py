@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmvfit.so')
+LIB_PATH = os.environ.get('MVFIT_LIBRARY') or os.path.join(_HERE, 'libmvfit.so')     # MVFIT_LIBRARY: developer A/B builds of the same library
 
 D = 118
 D_MODEL = 86

@@ -424,12 +424,52 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
     __syncthreads();
 }
 
+constexpr int FWD_SLICES = 8, FWD_RPS = KROWS / FWD_SLICES;      // 28 basis rows per k-slice of the forward contraction
+
+// The same stream split in two: the loads do not depend on the trial point (pd_sub is a model constant), so the fit
+// kernels request a thread's 28 rows BEFORE the pose phase and run the FMAs once the coefficients exist - the stream
+// (186 KB through one CU: ~5 k cycles) then flies under Rodrigues / J(beta) / the relative transforms instead of
+// standing in front of the skinning.  One item per thread (true for every keypoint set up to 56 vertices); with more
+// items than threads the caller keeps contraction_forward.
+struct FwdPrefetch { float4 v[FWD_RPS]; int cq, ks; bool on; };
+
+__device__ __forceinline__ bool fwd_prefetch_fits(const ClosureLds& L) { return (L.M.nc_pad >> 2) * FWD_SLICES <= STEP_NT - 64; }
+
+__device__ __forceinline__ void contraction_forward_issue(const DevModel& M, int nc_pad, int tid, FwdPrefetch& F) {
+    const int ncq = nc_pad >> 2, item = tid - 64;
+    F.on = item >= 0 && item < ncq * FWD_SLICES;
+    const int it = F.on ? item : 0;
+    F.cq = it % ncq;
+    F.ks = (it / ncq + (int)blockIdx.x) & (FWD_SLICES - 1);
+    if (F.on) {
+        const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + (size_t)(F.ks * FWD_RPS) * ncq + F.cq;
+#pragma unroll
+        for (int r = 0; r < FWD_RPS; ++r) F.v[r] = src[(size_t)r * ncq];
+    }
+}
+
+__device__ __forceinline__ void contraction_forward_finish(ClosureLds& L, const FwdPrefetch& F) {
+    if (!F.on) return;
+    const int nc_pad = L.M.nc_pad;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+    for (int r = 0; r < FWD_RPS; r += 2) {
+        const float c0 = L.coef[F.ks * FWD_RPS + r], c1 = L.coef[F.ks * FWD_RPS + r + 1];
+        acc0.x = fmaf(c0, F.v[r].x, acc0.x); acc0.y = fmaf(c0, F.v[r].y, acc0.y);
+        acc0.z = fmaf(c0, F.v[r].z, acc0.z); acc0.w = fmaf(c0, F.v[r].w, acc0.w);
+        acc1.x = fmaf(c1, F.v[r + 1].x, acc1.x); acc1.y = fmaf(c1, F.v[r + 1].y, acc1.y);
+        acc1.z = fmaf(c1, F.v[r + 1].z, acc1.z); acc1.w = fmaf(c1, F.v[r + 1].w, acc1.w);
+    }
+    float4* dst = reinterpret_cast<float4*>(L.scratch + F.ks * nc_pad + 4 * F.cq);
+    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // E1: x -> theta, R, J, blendshape coefficients, relative transforms.   lbs.py:183-195,269-348
 // Every thread derives what it needs straight from x (Rodrigues is recomputed per output element)
 // so the phase has no internal barrier.  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
-__device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+__device__ void pose_prep_decode(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     if (flags & MVFIT_F_VPOSER) {
         vposer_forward(M, L, tid);
         if (tid < 3) L.pose.theta[tid] = L.opt.x[X_GO + tid];
@@ -438,6 +478,10 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
         if (tid < 72) L.pose.theta[tid] = L.opt.x[X_GO + tid];      // global_orient | body_pose are contiguous in x
         __syncthreads();
     }
+}
+
+// second half of E1 (force-inlined: the fit kernels keep a thread's prefetched basis rows in registers across it)
+__device__ __forceinline__ void pose_prep_elems(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     if (tid < KROWS) {
         // blendshape coefficients: pose_feature (lbs.py:192), betas, zero pad
         const int p = tid;
@@ -487,11 +531,16 @@ __device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int 
     __syncthreads();
 }
 
+__device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+    pose_prep_decode(M, L, flags, tid);
+    pose_prep_elems(M, L, flags, tid);
+}
+
 // kinematic chain (lbs.py:349-355) G_j = G_parent M_j in 3x4 form, then A_j = [Gr_j | Gt_j - Gr_j J_j]
 // (lbs.py:365-368).  Executed by ONE wave following the host-built schedule: lane = (slot q, row a,
 // column c); per pass one table word, one ds_read_b128 of the parent row and three FMAs, handed to
 // the next pass through LDS without s_barrier.
-__device__ void chain_forward_wave(ClosureLds& L, int lane) {
+__device__ __forceinline__ void chain_forward_wave(ClosureLds& L, int lane) {
     if (lane < 12) L.pose.G[0][lane] = L.pose.Mj[0][lane];
     const int q = lane / 12, e = lane - 12 * q, a = e >> 2, c = e & 3;
     const int npass = L.M.n_fwd;
@@ -537,7 +586,7 @@ __device__ void chain_forward_wave(ClosureLds& L, int lane) {
 // the steps ping-pong between L.pose.G and L.gM (the adjoint's buffer, dead during the forward).  The
 // products are associated differently from the sequential chain (last-bit differences in G); every consumer
 // (vertex pass, objective, adjoint) reads the same G / A.  Ends with __syncthreads.
-__device__ void chain_forward_block(ClosureLds& L, int tid) {
+__device__ __forceinline__ void chain_forward_block(ClosureLds& L, int tid) {
     const bool act = tid < NJ * 12;
     const int j = act ? tid / 12 : 0, e = tid - 12 * j, a = e >> 2, c = e & 3;
     const int ns = L.M.n_jump;
@@ -580,7 +629,6 @@ __device__ void chain_forward_block(ClosureLds& L, int tid) {
 // vertices): 8 slices of 28 basis rows x nc_pad/4 float4 column groups = items; threads [0, nthreads)
 // take items round-robin (one each for the SMPL keypoint set).  All 28 loads of an item are issued
 // before the first FMA: the stream is then limited by bandwidth, not by one L2 round trip per row pair.
-constexpr int FWD_SLICES = 8, FWD_RPS = KROWS / FWD_SLICES;      // 28 rows per slice
 __device__ __forceinline__ int fwd_slices(int, int) { return FWD_SLICES; }
 
 __device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
@@ -610,7 +658,7 @@ __device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int
 
 // keypoint k = selection row . xs + transl  (body_models_scale.py:393-403): thread per (keypoint, coordinate).
 // Ends with __syncthreads.
-__device__ void keypoints_from_xs(ClosureLds& L, int tid) {
+__device__ __forceinline__ void keypoints_from_xs(ClosureLds& L, int tid) {
     if (tid < NKP * 3) {
         const int k = tid / 3, a = tid - 3 * k;
         float acc = 0.f;
@@ -634,10 +682,18 @@ __device__ void keypoints_from_xs(ClosureLds& L, int tid) {
 // E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
 // from_pass: L.vposed / L.xs of the selected vertices were written by the kernel prologue from the
 // vertex pass's side outputs (full mode); run_chain = false when the pose block (G, A) is already in LDS.
-__device__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass, int tid, bool run_chain = true) {
+__device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass, int tid, bool run_chain = true,
+                               const FwdPrefetch* pf = nullptr) {
     const int nc = L.M.nc, nc_pad = L.M.nc_pad;
     const int nks = fwd_slices(nc_pad, STEP_NT - 64);
-    if (run_chain || !from_pass) {
+    if (pf) {
+        // basis rows already in registers (requested before the pose phase): the FMAs, then the chain by the whole
+        // workgroup in pointer-jumping form (4 steps instead of the one wave's 9 dependent passes - with the stream out
+        // of the way the chain is what this phase waits for); its barriers also publish the partial sums
+        contraction_forward_finish(L, *pf);
+        PH_T(22);
+        chain_forward_block(L, tid);
+    } else if (run_chain || !from_pass) {
         if (tid < 64) { if (run_chain) chain_forward_wave(L, tid); PH_T(22); }
         else if (!from_pass) contraction_forward(M, L, tid - 64, STEP_NT - 64);
         __syncthreads();
@@ -675,7 +731,7 @@ __device__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass,
 // E4: SMPLifyLoss.forward (fitting.py:290-415, no SDF term) + gradient w.r.t. keypoints / priors.
 // Returns the total loss (same value in every thread).  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
-__device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V, const DevWeights& W,
+__device__ __forceinline__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V, const DevWeights& W,
                                          bool want_grad, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const bool use_gmm = !use_vp && (W.flags & MVFIT_F_PRIOR_GMM);
@@ -851,7 +907,7 @@ __device__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V
 
 // chain adjoint by ONE wave, deepest parents first, following the host-built schedule:
 // g_G_p[a][m] += sum_children sum_col g_G_c[a][col] M_c[m][col]  (m < 3),  g_G_p[a][3] += g_G_c[a][3].
-__device__ void chain_backward_wave(ClosureLds& L, int lane) {
+__device__ __forceinline__ void chain_backward_wave(ClosureLds& L, int lane) {
     const int q = lane / 12, e = lane - 12 * q, a = e >> 2, m = e & 3;
     const int mr = m < 3 ? m : 0;
     const int npass = L.M.n_bwd;
@@ -935,15 +991,73 @@ __device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, in
     }
 }
 
+// The transposed stream split like the forward one: pd_subT is a constant, so a thread's (up to) 36 column words are
+// requested at the top of the adjoint and multiplied in E7 - the 186 KB then arrive under E5 and E6 instead of next to
+// the chain adjoint (which is what E7 then waits for).  56 row groups x 8 slices = 448 items = the threads of
+// waves 1-7, always one item per thread.
+struct BwdPrefetch { float4 v[BWD_CPS]; };
+#ifdef MVFIT_NO_BWD_PREFETCH            // developer A/B switches (tests/quick_async.py with MVFIT_LIBRARY)
+constexpr bool kBwdPrefetch = false;
+#else
+constexpr bool kBwdPrefetch = true;
+#endif
+#ifdef MVFIT_NO_FWD_PREFETCH
+constexpr bool kFwdPrefetch = false;
+#else
+constexpr bool kFwdPrefetch = true;
+#endif
+
+__device__ __forceinline__ void contraction_backward_issue(const DevModel& M, int nc_pad, int tid, BwdPrefetch& F) {
+    constexpr int npq = KROWS >> 2;
+    if (tid < 64) return;
+    const int item = tid - 64;
+    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;
+    const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
+    const int c0 = cs * cps;
+    const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
+#pragma unroll
+    for (int r = 0; r < BWD_CPS; ++r) {
+        const int c = min(c0 + r, nc_pad - 1);
+        if (r < cps) F.v[r] = src[(size_t)c * npq];
+    }
+}
+
+__device__ __forceinline__ void contraction_backward_finish(ClosureLds& L, int tid, const BwdPrefetch& F) {
+    constexpr int npq = KROWS >> 2;
+    if (tid < 64) return;
+    const int item = tid - 64;
+    const int nc_pad = L.M.nc_pad;
+    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;
+    const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
+    const int c0 = cs * cps;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+    for (int r = 0; r < BWD_CPS; r += 2) {
+        if (r < cps) {
+            const float g0 = (c0 + r < nc_pad) ? L.gvp[c0 + r] : 0.f;
+            const float g1 = (c0 + r + 1 < nc_pad) ? L.gvp[c0 + r + 1] : 0.f;
+            acc0.x = fmaf(g0, F.v[r].x, acc0.x); acc0.y = fmaf(g0, F.v[r].y, acc0.y);
+            acc0.z = fmaf(g0, F.v[r].z, acc0.z); acc0.w = fmaf(g0, F.v[r].w, acc0.w);
+            acc1.x = fmaf(g1, F.v[r + 1].x, acc1.x); acc1.y = fmaf(g1, F.v[r + 1].y, acc1.y);
+            acc1.z = fmaf(g1, F.v[r + 1].z, acc1.z); acc1.w = fmaf(g1, F.v[r + 1].w, acc1.w);
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
+    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward).
 // Ends with __syncthreads; L.grad holds the flat gradient.
 // ---------------------------------------------------------------------------------------------
-__device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
+__device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
     __syncthreads();                  // L.gkp (view sums) and L.gtau are written after E4's last barrier
     const float sdf_fac = L.sdf_fac;
+    // the transposed basis stream of E7 is requested here: it flies under E5 and E6 (two light phases)
+    BwdPrefetch pbk;
+    if (kBwdPrefetch) contraction_backward_issue(M, nc_pad, tid, pbk);
     // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
     if (tid < nc_pad) {
         float v = 0.f;
@@ -1009,6 +1123,7 @@ __device__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const 
     PH_T(5);
     // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
     if (tid < 64) { chain_backward_wave(L, tid); PH_T(23); }
+    else if (kBwdPrefetch) contraction_backward_finish(L, tid, pbk);
     else contraction_backward(M, L, tid - 64, STEP_NT - 64);
     const int ncs = bwd_slices(STEP_NT - 64);
     __syncthreads();

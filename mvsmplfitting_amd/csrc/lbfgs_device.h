@@ -533,7 +533,7 @@ __device__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid, L
 // workgroup and calls again (S.phase == PH_DIRECTION; f_new / gnew are ignored on that call).
 // lane = threadIdx & 63; element e of this lane is flat index LB_EPL * lane + e.
 template <typename T>
-__device__ int lbfgs_advance(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
+__device__ __forceinline__ int lbfgs_advance(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
                              double f_new, const T* gnew, T* xt, int lane, double* stage_final) {
     const double c1 = 1e-4, c2 = 0.9;
     const int max_ls = 25;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 
 // shared by the two fit kernels: evaluate the closure at L.opt.x, advance the optimiser, leave the
 // next trial point in L.opt.x.  Returns true when the problem is finished.
-__device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
+__device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
                           const AsyncRing* ring = nullptr, int pb = 0) {
@@ -219,9 +219,17 @@ __device__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const Lb
     PH_T0();
     // have_pose: the previous launch left the pose block of this x (and, with VPoser, the decoder state the
     // adjoint needs - the VpBlock)
-    if (!have_pose) pose_prep(M, L, W.flags, tid);
+    // the two 186 KB streams of the objective-vertex basis do not depend on the trial point: each thread's share is
+    // requested a phase or more ahead of its use (closure_device.h: FwdPrefetch / BwdPrefetch)
+    FwdPrefetch pf;
+    const bool pre_f = kFwdPrefetch && !from_pass && !have_pose && fwd_prefetch_fits(L);          // block-uniform
+    if (!have_pose) {
+        pose_prep_decode(M, L, W.flags, tid);
+        if (pre_f) contraction_forward_issue(M, L.M.nc_pad, tid, pf);
+        pose_prep_elems(M, L, W.flags, tid);
+    }
     PH_T(0);
-    sparse_forward(M, L, from_pass, tid, !have_pose);
+    sparse_forward(M, L, from_pass, tid, !have_pose, pre_f ? &pf : nullptr);
     PH_T(2);
     // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round

@@ -706,6 +706,297 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// More than 32 problems, models with <= 4 skinning weights per vertex (the SMPL family): the chunk loop as a two-role
+// software pipeline.  The loop kernel above does blend -> contraction -> apply -> store in lock-step with three barriers
+// per chunk and has every wave stall on the issue of the next chunk's 64 KiB of operands (the CU takes ~40 B/clk): 4.2 us
+// per 32-problem chunk, of which the matrix pipe works 0.6.  Here
+//   * waves 0-2 own one coordinate plane each: its basis rows stay in registers for the whole launch (112 VGPRs), per
+//     chunk 42 MFMAs (two K halves, two accumulators added in the order of the other kernels: bit-identical vertices),
+//     the partial to LDS - and they are the LOADERS: right behind the second barrier of chunk c they request the operands
+//     of chunk c + 2 (direct global -> LDS, 22 x 1 KiB per wave) into the buffer chunk c just released.  Operands are
+//     double-buffered (2 x 64 KiB), so a request has a whole iteration to land and is waited for with a COUNTED vmcnt
+//     (everything but the newest 22): nobody stalls on the stream;
+//   * waves 3-7 (320 threads) own the 512 (vertex pair, problem) items of a chunk: skinning blend T = W . A from the
+//     4-pair table (registers), then - behind the barrier that publishes the partials - v_posed, skinned position,
+//     "+ transl" and the store straight from registers (24 contiguous bytes per item, 384-byte runs per problem): no
+//     staging of the output in LDS, no third barrier.  Blend of chunk c runs WHILE the planes of chunk c are contracted.
+// Two barriers per chunk; per chunk the critical path is max(loader: request + 42 MFMAs, worker: 2 blends + 2 applies).
+// LDS: A 2 x 36 KiB, coefficients 2 x 28 KiB, partials 12.4 KiB, tau / tables 2 KiB = 143 KiB.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int VPP_NMFMA = 3;                         // loader / contraction waves
+constexpr int VPP_NWORK = (VP_NT / 64 - VPP_NMFMA) * 64;   // 320 worker threads
+constexpr int VPP_DMA_PER_WAVE = 22;                 // (28 coefficient + 36 transform + 1 tau + 1 pad) KiB-loads / 3 waves
+
+// LDS accesses of the loader waves go through inline asm: the compiler's wait-count pass cannot tell which LDS bytes an
+// in-flight global -> LDS load will write and would put `s_waitcnt vmcnt(0)` in front of every ds instruction that
+// follows one - i.e. it would wait for the request of the chunk AFTER next at the top of every iteration.  The waits are
+// placed by hand instead (lds_wait* ties the loaded registers to the counter wait so that no use can be scheduled above it).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v lds_read16_nowait(unsigned addr) {
+    f32x4v v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void lds_write4_nowait(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_wait14(f32x4v (&a)[14]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                   "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]));
+}
+
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_pipe_kernel(DevModel M, DevPose P, int B,
+                                                                float* __restrict__ verts) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A_l = smem;                                               // [2][32][A_STRIDE]
+    float4* coef_l = reinterpret_cast<float4*>(A_l + 2 * 32 * A_STRIDE);     // [2][VP_NBLK][hi, lo][64]
+    float* part = reinterpret_cast<float*>(coef_l + 2 * VP_NBLK * 2 * 64);   // [3][32][33]  (K halves already added)
+    float* tau_l = part + 3 * 32 * 33;                               // [2][32][4]
+    float4* sw_l = reinterpret_cast<float4*>(tau_l + 2 * 32 * 4);    // [32] weights of the tile's vertices
+    int4* sj_l = reinterpret_cast<int4*>(sw_l + 32);                 // [32] their joints
+    int* sel_l = reinterpret_cast<int*>(sj_l + 32);                  // [32] objective slot of a vertex or -1 (chained mode)
+    int* live_l = sel_l + 32;                                        // [4] (2 used) chunk has a problem that is still running
+    unsigned* dn_l = reinterpret_cast<unsigned*>(live_l + 4);        // [2][32] done_round words of a chunk (asynchronous fit)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int nchunks = (B + 31) >> 5;
+    const int c_first = P.chunk0, nloop = nchunks - c_first;
+    const bool async = P.tag != nullptr;
+    const bool stream_nt = VP_NT_LOADS && async && !(P.pad_ & 1u);
+    const bool store_nt = VP_NT_LOADS && async && !(P.pad_ & 2u);
+    const int vbase = tile * TILE_V;
+    const int nvalid_v = min(TILE_V, M.nv - vbase);                  // vertices of this tile that exist
+    const float inv_scale = 1.0f / M.bs_scale;                       // power of two: exact
+
+    if (wave < VPP_NMFMA) {
+        // =========================== loader / contraction wave: coordinate plane `wave` ===========================
+        // every loader wave requests its third of a chunk's operands: items 0..27 coefficient words, 28..63 transform
+        // rows, 64 tau, 65 the chunk's done_round words (asynchronous fit; else tau again) - always 22 requests per wave,
+        // also for a chunk index past the end (clamped), so that the counted wait below has a fixed meaning
+        auto request = [&](int it, int buf) {
+            const int chunk = min(c_first + it, nchunks - 1);
+            const float4* csrc = P.coefH + (size_t)chunk * VP_NBLK * 2 * 64 + lane;
+            const float4* asrc = reinterpret_cast<const float4*>(P.Amat + (size_t)chunk * 32 * 288) + lane;     // Bpad rows exist
+            const float4* tsrc = reinterpret_cast<const float4*>(P.tau + (size_t)chunk * 32 * 4) + (lane & 31);
+            float4* cdst = coef_l + buf * VP_NBLK * 2 * 64;
+            float4* adst = reinterpret_cast<float4*>(A_l + buf * 32 * A_STRIDE);
+            float4* tdst = reinterpret_cast<float4*>(tau_l + buf * 32 * 4);
+#pragma unroll
+            for (int q = 0; q < VPP_DMA_PER_WAVE; ++q) {
+                const int i = wave + VPP_NMFMA * q;                  // wave-uniform
+                if (i < 28) __builtin_amdgcn_global_load_lds(csrc + i * 64, cdst + i * 64, 16, 0, 0);
+                else if (i < 64) __builtin_amdgcn_global_load_lds(asrc + (i - 28) * 64, adst + (i - 28) * 64, 16, 0, 0);
+                // (the LDS side of a request is lane-indexed: 32 lanes for the 32-word rows)
+                else if (i == 64 || !async) { if (lane < 32) __builtin_amdgcn_global_load_lds(tsrc, tdst, 16, 0, 0); }
+                else if (lane < 32) __builtin_amdgcn_global_load_lds(P.done_round + (size_t)chunk * 32 + lane, dn_l + buf * 32, 4, 0, 0);
+            }
+        };
+        request(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const float vt_init = M.vt_planes[wave * M.nv_pad + vbase + (lane & 31)] * M.bs_scale;
+        float4 bh[VP_NBLK], bl[VP_NBLK];
+        {
+            const float4* cb = M.bs_h2 + ((size_t)(tile * 3 + wave) * VP_NBLK * 2) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < VP_NBLK; ++g) {
+                bh[g] = stream_nt ? nt_load16(&cb[(2 * g) * 64]) : cb[(2 * g) * 64];
+                if (!M.half_basis) bl[g] = stream_nt ? nt_load16(&cb[(2 * g + 1) * 64]) : cb[(2 * g + 1) * 64];
+                else bl[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        request(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned coef_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)coef_l + 16u * (unsigned)lane;
+        // D layout -> part[plane][problem][vertex]: col (vertex) = lane & 31, row (problem) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const unsigned part_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)part +
+                                4u * (unsigned)((wave * 32 + 4 * (lane >> 5)) * 33 + (lane & 31));
+        const unsigned live_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)live_l;
+        // Liveness of a chunk (asynchronous fit: a chunk whose 32 problems had all finished before this round is skipped):
+        // the chunk's done_round words arrive with its operands (item 65, requested by the last loader wave); that wave
+        // turns them into the verdict word right behind its counted wait.
+        const bool live_wave = wave == (65 % VPP_NMFMA);
+        const unsigned dn_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)dn_l + 4u * (unsigned)(lane & 31);
+        __syncthreads();                                             // (0) tables written by the workers, first liveness word
+        for (int it = 0; it < nloop; ++it) {
+            const int buf = it & 1;
+#ifdef MVFIT_TIMING
+            const long long t_it = clock64();               // timeline of the third chunk (steady state), tests/vp_timeline.py
+#define VPP_T(k_) do { if (it == 2) VP_T(k_, t_it); } while (0)
+#else
+#define VPP_T(k_) do { } while (0)
+#endif
+            // the operands of this chunk were requested two iterations ago (the first two: up front); only the request of
+            // the NEXT chunk - the newest 22 loads of this wave - may still be in flight
+            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            VPP_T(0);
+            if (live_wave) {
+                bool lv = true;
+                if (async) {
+                    unsigned d;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(dn_a + 128u * (unsigned)buf));
+                    const int b = (c_first + it) * 32 + lane;
+                    lv = __ballot(lane < 32 && b < B && d > P.round) != 0ull;
+                }
+                if (lane == 0) lds_write4_nowait(live_a + 4u * (unsigned)buf, __builtin_bit_cast(float, lv ? 1 : 0));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                                         // (1) operands visible; partials of the last chunk consumed
+            VPP_T(1);
+            int live;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(live) : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(live_l + buf)));
+            live = __builtin_amdgcn_readfirstlane(live);
+            if (live) {
+                // ---- contraction: K half 0 (v_template in the accumulator), K half 1; small products first ----
+                floatx16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = vt_init; acc1[r] = 0.f; }
+                const unsigned ca = coef_a + (unsigned)buf * (VP_NBLK * 2 * 64 * 16);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4v aw[14];                                   // (hi, lo) words of 7 blocks
+#pragma unroll
+                    for (int q = 0; q < 14; ++q) aw[q] = lds_read16_nowait(ca + (unsigned)((14 * h + q) * 64 * 16));
+                    lds_wait14(aw);
+#pragma unroll
+                    for (int g = 0; g < VP_BPW; ++g) {
+                        const half8 Ah = __builtin_bit_cast(half8, aw[2 * g]), Al = __builtin_bit_cast(half8, aw[2 * g + 1]);
+                        const half8 Bh = __builtin_bit_cast(half8, bh[VP_BPW * h + g]), Bl = __builtin_bit_cast(half8, bl[VP_BPW * h + g]);
+                        if (h == 0) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc0, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc0, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc0, 0, 0, 0);
+                        } else {
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc1, 0, 0, 0);
+                        }
+                    }
+                }
+                VPP_T(2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lds_write4_nowait(part_a + 4u * (unsigned)(((r & 3) + 8 * (r >> 2)) * 33), acc0[r] + acc1[r]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                VPP_T(3);
+                __syncthreads();                                     // (2) partials published; this chunk's operand buffer is free
+                VPP_T(4);
+            }
+            request(it + 2, buf);                                    // the chunk after next, into the buffer just released
+            VPP_T(5);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no request may outlive the workgroup's LDS
+        return;
+    }
+
+    // ======================================= worker waves: 320 threads, 512 items =======================================
+    const int wt = tid - 64 * VPP_NMFMA;                             // 0..319
+    const int w_vp2 = wt & 15, w_bb0 = wt >> 4;                      // item 0: problem 0..19; item 1: problem 20..31
+    const bool w_two = wt < (512 - VPP_NWORK);
+    if (wt < 32) sw_l[wt] = M.wsp_w[(size_t)vbase + wt];
+    else if (wt < 64) sj_l[wt - 32] = M.wsp_j[(size_t)vbase + wt - 32];
+    else if (wt < 96) sel_l[wt - 64] = -1;
+    if (!async) {                                                    // objective slots of this tile's vertices (side outputs)
+        wave_lds_fence();
+        if (wave == VPP_NMFMA + 1) {                                 // the wave that wrote the -1s
+            const int s0 = M.tile_sel_start[tile], s1 = M.tile_sel_start[tile + 1];
+            if (lane < s1 - s0) sel_l[M.tile_sel_local[s0 + lane]] = M.tile_sel_slot[s0 + lane];
+        }
+    }
+    __syncthreads();                                                 // (0)
+    for (int it = 0; it < nloop; ++it) {
+        const int chunk = c_first + it, b0 = chunk * 32, buf = it & 1;
+#ifdef MVFIT_TIMING
+        const long long t_it = clock64();
+#endif
+        __syncthreads();                                             // (1)
+        VPP_T(1);
+        const bool live = live_l[buf] != 0;                          // uniform
+        if (async && blockIdx.x == 0 && wt == 0) atomicAdd(P.stats + (live ? 0 : 1), 1u);      // chunk passes run / skipped
+        if (!live) continue;
+        // ---- skinning blend of this chunk's items, while the planes are contracted ----
+        const float* A_c = A_l + buf * 32 * A_STRIDE;
+        float tr0[3][2][4], tr1[3][2][4];
+        vp_blend_zero(tr0);
+        vp_blend_zero(tr1);
+        {
+            const float4 swa = sw_l[2 * w_vp2], swb = sw_l[2 * w_vp2 + 1];
+            const int4 sja = sj_l[2 * w_vp2], sjb = sj_l[2 * w_vp2 + 1];
+            vp_blend_pairs(tr0, 0, A_c + w_bb0 * A_STRIDE, swa, sja);
+            vp_blend_pairs(tr0, 1, A_c + w_bb0 * A_STRIDE, swb, sjb);
+            if (w_two) {
+                vp_blend_pairs(tr1, 0, A_c + (w_bb0 + 20) * A_STRIDE, swa, sja);
+                vp_blend_pairs(tr1, 1, A_c + (w_bb0 + 20) * A_STRIDE, swb, sjb);
+            }
+        }
+        const float4 ta = *reinterpret_cast<const float4*>(tau_l + buf * 32 * 4 + w_bb0 * 4);
+        const float4 tb = *reinterpret_cast<const float4*>(tau_l + buf * 32 * 4 + (w_two ? w_bb0 + 20 : w_bb0) * 4);
+        VPP_T(2);
+        __syncthreads();                                             // (2) partials published
+        VPP_T(4);
+        // ---- v_posed (K halves added by the contraction wave; scale undone), T applied, + transl, store ----
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (e == 1 && !w_two) break;
+            const int bb = e ? w_bb0 + 20 : w_bb0;
+            const float (&tr)[3][2][4] = e ? tr1 : tr0;
+            const float tau3[3] = {e ? tb.x : ta.x, e ? tb.y : ta.y, e ? tb.z : ta.z};
+            float o[6];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int v = 2 * w_vp2 + i;
+                float vp[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vp[k] = part[(k * 32 + bb) * 33 + v] * inv_scale;
+                float xs[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    xs[k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
+                if (!async) {                                        // side outputs of the chained mode (objective vertices only)
+                    const int slot = sel_l[v];
+                    if (slot >= 0 && b0 + bb < B) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            P.vposed_sel[(size_t)(b0 + bb) * NC_MAX + 3 * slot + k] = vp[k];
+                            P.xs_sel[(size_t)(b0 + bb) * NC_MAX + 3 * slot + k] = xs[k];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[3 * i + k] = xs[k] + tau3[k];
+            }
+            if (b0 + bb < B) {
+                // 24 contiguous bytes (vertices 2 vp2, 2 vp2 + 1), 8-byte aligned (even vertex count, checked at launch)
+                float* dst = verts + ((size_t)(b0 + bb) * M.nv + vbase + 2 * w_vp2) * 3;
+                const int nv_ok = nvalid_v - 2 * w_vp2;              // vertices of this pair that exist
+                if (nv_ok >= 2) {
+                    const f32x2 q0 = {o[0], o[1]}, q1 = {o[2], o[3]}, q2 = {o[4], o[5]};
+                    if (store_nt) {
+                        __builtin_nontemporal_store(q0, reinterpret_cast<f32x2*>(dst));
+                        __builtin_nontemporal_store(q1, reinterpret_cast<f32x2*>(dst + 2));
+                        __builtin_nontemporal_store(q2, reinterpret_cast<f32x2*>(dst + 4));
+                    } else {
+                        *reinterpret_cast<f32x2*>(dst) = q0; *reinterpret_cast<f32x2*>(dst + 2) = q1; *reinterpret_cast<f32x2*>(dst + 4) = q2;
+                    }
+                } else if (nv_ok == 1) {
+                    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+                }
+            }
+        }
+        VPP_T(5);
+    }
+#ifdef MVFIT_TIMING
+    if (blockIdx.x == 5 && threadIdx.x == 256) g_vp[7] += 1;
+#endif
+}
+
+size_t vertex_pass_pipe_lds_bytes() {
+    return sizeof(float) * (size_t)(2 * 32 * A_STRIDE + 3 * 32 * 33 + 2 * 32 * 4) + 16 * (size_t)(2 * VP_NBLK * 2 * 64 + 32 + 32) + 4 * (32 + 4 + 64);
+}
+
 size_t vertex_pass_split_lds_bytes() {
     return sizeof(float) * (size_t)(32 * A_STRIDE + 4 * NJ * 32 + 32 * 4 + 2 * 3 * 32 * 33 + 2 * 32 * 96);
 }
@@ -741,7 +1032,12 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
             else vp_launch(lbs_vertex_pass_split_kernel<false>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
         } else {
             const dim3 g1(M.ntiles, 1);
-            if (M.wsp_w) vp_launch(lbs_vertex_pass_split_loop_kernel<true>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+            // models with <= 4 weights per vertex and an even vertex count: the two-role pipeline (MVFIT_VP_LOCKSTEP=1 keeps
+            // the lock-step chunk loop, which also serves dense skinning rows)
+            static const bool lockstep = getenv("MVFIT_VP_LOCKSTEP") != nullptr;
+            if (M.wsp_w && (M.nv & 1) == 0 && !lockstep)
+                vp_launch(lbs_vertex_pass_pipe_kernel, g1, vertex_pass_pipe_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+            else if (M.wsp_w) vp_launch(lbs_vertex_pass_split_loop_kernel<true>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
             else vp_launch(lbs_vertex_pass_split_loop_kernel<false>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
         }
         return hipGetLastError();
@@ -767,8 +1063,11 @@ hipError_t vertex_pass_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_pipe_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_pipe_lds_bytes());
 }
 
 }  // namespace mvfit

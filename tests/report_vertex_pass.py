@@ -1,6 +1,9 @@
 """Report (not a test): LBS vertex pass duration and roofline fraction vs the number of problems.
 PYTHONPATH=. python tests/report_vertex_pass.py [B ...]"""
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch

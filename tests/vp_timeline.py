@@ -32,8 +32,15 @@ for _ in range(N):
 torch.cuda.synchronize()
 eng._lib.mvfit_debug_vp(vb)
 d = [(vb[i] - base[i]) / N for i in range(16)]
-names = ['operand wait', 'barrier', 'blend', 'mfma+partials', 'apply', 'barrier2', 'stores issued']
-print('B = %d, chunk iteration 1 of workgroup 5, cumulative shader-clock cycles since the iteration start' % B)
-print('  wave 0 (contraction):', ' '.join('%s=%.0f' % (names[i], d[i]) for i in range(7)))
-print('  wave 4 (blend only) :', ' '.join('%s=%.0f' % (names[i], d[8 + i]) for i in range(7)))
+if os.environ.get('MVFIT_VP_LOCKSTEP'):
+    names = ['operand wait', 'barrier', 'blend', 'mfma+partials', 'apply', 'barrier2', 'stores issued']
+    print('B = %d, lock-step chunk loop, iteration 1 of workgroup 5, cumulative shader-clock cycles since the iteration start' % B)
+    print('  wave 0 (contraction):', ' '.join('%s=%.0f' % (names[i], d[i]) for i in range(7)))
+    print('  wave 4 (blend only) :', ' '.join('%s=%.0f' % (names[i], d[8 + i]) for i in range(7)))
+else:
+    ln = ['counted operand wait', 'barrier 1', 'coefficient reads + 42 MFMAs', 'partials written', 'barrier 2', 'request of chunk + 2 issued']
+    wn = ['-', 'barrier 1', 'two blends', '-', 'barrier 2', 'apply + stores issued']
+    print('B = %d, two-role pipeline, third chunk of workgroup 5, cumulative shader-clock cycles since the iteration start' % B)
+    print('  wave 0 (loader / contraction):', ' | '.join('%s=%.0f' % (ln[i], d[i]) for i in range(6)))
+    print('  wave 4 (worker)              :', ' | '.join('%s=%.0f' % (wn[i], d[8 + i]) for i in (1, 2, 4, 5)))
 print('  avg launch us (64 back-to-back):', eng.profile_vertex_pass_ms(64) * 1e3)
