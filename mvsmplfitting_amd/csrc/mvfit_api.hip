@@ -51,7 +51,7 @@ struct FitBuffers {
     float* grow;         // [B][LB_GSIZE] pre-scaled Gram matrices (lbfgs_device.h:LbHist)
     float* gcol;         // [B][LB_GSIZE]
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
-    int* n_done;         // [1]
+    int* n_done;         // [2]: problems finished | problems that left the asynchronous phase (finished or paused at a stage boundary)
     VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
     const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
     int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
@@ -342,7 +342,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 // history ring lives in LDS behind the closure workspace.
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
-                                                                 int max_rounds, AsyncRing ring, int b_lo, int done_target) {
+                                                                 int max_rounds, AsyncRing ring, int b_lo, int done_target,
+                                                                 int pause_stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     LbHist<float> H{hist, hist + LB_HIST * LB_D, L.opt.lb_ro, F.grow + (size_t)b * LB_GSIZE,
                     F.gcol + (size_t)b * LB_GSIZE};
     __syncthreads();
-    bool done = false;
+    bool done = false, paused = false;
     for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
         // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
@@ -371,20 +372,31 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring.tag ? &ring : nullptr, b);
         if (done) break;                                  // block-uniform
+        // two-phase fit (stages without the SDF term run here, the rest in chained rounds): leave at the stage boundary -
+        // the trial point in L.opt.x is the first one of the next stage, the optimiser is fresh (non_linear_solver.py:172)
+        if (L.sh_stage >= pause_stage) { paused = true; break; }
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
-    if (tid == 0 && done) {
-        const int finished = atomicAdd(F.n_done, 1) + 1;
+    if (tid == 0 && (done || paused)) {
+        if (done) atomicAdd(F.n_done, 1);
+        const int left = atomicAdd(F.n_done + 1, 1) + 1;
         if (ring.tag) {
             // passes of later rounds have nothing to wait for from this problem; the last problem tells the host
             __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (finished == done_target) __hip_atomic_store(ring.host_done, finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (!done)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
+    if (paused) {
+        // what the chained rounds' step kernel expects from its predecessor: the pose block of the trial point (+ the
+        // decoder state with VPoser) and the SDF gate of the stage that starts
+        store_block16(F.pose + b, &L.pose, sizeof(PoseBlock), tid);
+        if (SW.w[0].flags & MVFIT_F_VPOSER) store_block16(F.vp + b, L.vp_pre1, sizeof(VpBlock), tid);
+        if (tid == 0 && F.sdf_adj) F.sdf_gate[b] = L.sw[L.sh_stage].coll_w > 0.f ? 1 : 0;
+    }
 }
 
 __global__ void fit_finish_kernel(FitBuffers F, float* __restrict__ params, float* __restrict__ final_loss,
@@ -1033,7 +1045,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMemset(c->F.grow, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMemset(c->F.gcol, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
-        HIP_OK(c, hipMalloc(&c->F.n_done, 4));
+        HIP_OK(c, hipMalloc(&c->F.n_done, 8));
         HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
         HIP_OK(c, hipMalloc(&c->F.vp, (size_t)B * sizeof(VpBlock)));
         HIP_OK(c, hipMalloc(&c->d_gt3d, (size_t)B * NKP * 3 * 4));
@@ -1334,7 +1346,7 @@ static int ensure_async(mvfit_ctx* c) {
     return MVFIT_OK;
 }
 
-static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out) {
+static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1) {
     int rc = ensure_async(c);
     if (rc) return rc;
     const int B = c->B;
@@ -1357,7 +1369,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
         hipLaunchKernelGGL(fit_persistent_kernel, dim3(b_hi - b_lo), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
-                           (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, b_hi);
+                           (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, b_hi, pause_stage);
         HIP_OK(c, hipGetLastError());
         // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
         int k = 0;
@@ -1450,19 +1462,32 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
     // MVFIT_ROUND_MODE=serial keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
     const char* rmode = getenv("MVFIT_ROUND_MODE");
-    const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && !(rmode && !strcmp(rmode, "serial"));
+    const bool serial = rmode && !strcmp(rmode, "serial");
+    const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && !serial;
+    // With the SDF term: the leading stages whose coll_loss_weight is 0 (stages 1-2 of the yaml) do not need the vertices
+    // before the loss - they run asynchronously like a fit without the term, every problem leaves at the stage boundary,
+    // and the chained rounds take over from the stored optimiser / pose state (a fresh optimiser starts there anyway).
+    int lead = 0;
+    while (lead < o->num_stages && !(sw[lead].coll_loss_weight > 0.f)) ++lead;
+    const bool two_phase = any_sdf && lead >= 1 && lead < o->num_stages && c->M.bs_h2 != nullptr && !serial &&
+                           !getenv("MVFIT_SDF_ONE_PHASE");
     for (unsigned& v : c->async_stats) v = 0;
     const int B = c->B;
-    HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 4, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 8, c->stream));
     HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
                        (const float*)params,
-                       sw[0].flags, (sparse || async) ? 0 : 1);
+                       sw[0].flags, (sparse || async || two_phase) ? 0 : 1);
     HIP_OK(c, hipGetLastError());
     int* h_done = c->h_done;
     *h_done = 0;
     int rounds = 0;
     const int cap = o->max_rounds > 0 ? o->max_rounds : (o->num_stages * o->maxiters * (O.max_eval + 30) + 8);
+    if (two_phase) {
+        int seen = 0;
+        rc = fit_async(c, SW, O, cap, &seen, lead);
+        if (rc) return rc;
+    }
     if (async) {
         int seen = 0;
         rc = fit_async(c, SW, O, cap, &seen);
@@ -1473,7 +1498,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
             const int chunk = std::min(cap - rounds, 1 << 20);
             hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
                                (const ObsBlock*)c->d_obs, c->V, SW, O, c->P,
-                               c->F, chunk, AsyncRing{}, 0, B);
+                               c->F, chunk, AsyncRing{}, 0, B, MVFIT_MAX_STAGES + 1);
             HIP_OK(c, hipGetLastError());
             rounds += chunk;
             HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
