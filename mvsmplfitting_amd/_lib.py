@@ -21,6 +21,7 @@ F_FIX_SHAPE = 4
 F_FIX_SCALE = 8
 F_SPARSE_VERTS = 16
 F_USE_3D = 32
+F_REUSE_OUTER_VALUE = 64
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)

@@ -1236,6 +1236,7 @@ static int make_opts(mvfit_ctx* c, const mvfit_lbfgs_opts* o, uint32_t flags, Lb
     O.lr = o->lr; O.tol_grad = o->tolerance_grad; O.tol_change = o->tolerance_change; O.ftol = o->ftol; O.gtol = o->gtol;
     O.max_iter = o->max_iter; O.max_eval = o->max_iter * 5 / 4; O.history = o->history; O.maxiters = o->maxiters;
     O.num_stages = o->num_stages;
+    O.reuse_outer = (flags & MVFIT_F_REUSE_OUTER_VALUE) ? 1 : 0;
     // parameter tensors that take part in the gtol test (fitting.py:115-116): requires_grad ones,
     // as index ranges of the compact optimiser vector (reference final_params order)
     int n = 0;
