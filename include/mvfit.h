@@ -185,6 +185,14 @@ int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lb
  * their pass read them (expected 0), passes that gave up waiting for their operands (expected 0) }. */
 int mvfit_fit_stats(mvfit_ctx* ctx, uint32_t* out4);
 
+/* Counters of the decoder helpers of the last mvfit_fit.  With MVFIT_F_VPOSER the single-launch fits (asynchronous and
+ * objective-vertices-only) run the VPoser decoder's layers (VPoser.py:218-232) on helper workgroups of the same launch
+ * that keep the weights in registers (csrc/vposer_service.h; MVFIT_VP_HELPERS=0 in the environment keeps them in the
+ * problems' own workgroups):
+ * out3 = { launches that carried helpers, answers that did not arrive within 50 ms (expected 0: that problem decodes
+ * locally from then on), helpers that gave up after 0.2 s without a request (expected 0) }.  Waits for the ctx stream. */
+int mvfit_decoder_stats(mvfit_ctx* ctx, uint32_t* out3);
+
 /* Test hook for the asynchronous fit: the vertex pass that belongs to closure round `round` (0-based, of every
  * problem) writes its vertices to verts[B,Nv,3] (dev) instead of the internal buffer; together with mvfit_fit_trace
  * (the trial points) this lets a test check that the pass of round r really computed the trial point of round r.

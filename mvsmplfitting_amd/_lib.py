@@ -53,7 +53,7 @@ class LbfgsOpts(C.Structure):
 
 
 EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',
-           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex',
+           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex',
            'mvfit_lbfgs_kat']
 
 
@@ -89,6 +89,8 @@ def load():
     lib.mvfit_debug_capture_pass.restype = C.c_int
     lib.mvfit_fit_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.mvfit_fit_stats.restype = C.c_int
+    lib.mvfit_decoder_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.mvfit_decoder_stats.restype = C.c_int
     lib.mvfit_fit_trace.argtypes = [vp, vp, C.c_int]
     lib.mvfit_fit_trace.restype = C.c_int
     lib.mvfit_sdf.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]

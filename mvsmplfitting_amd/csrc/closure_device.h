@@ -93,6 +93,8 @@ struct ClosureLds {
     int gmm_sel;
     int sh_stage, sh_status;        // optimiser scalars broadcast from wave 0 to the block
     unsigned sh_pass_done;          // asynchronous fit: last value read from the ring's pass_done (publishing wave only)
+    unsigned vp_seq;                // decoder service (vposer_service.h): number of the last request of this problem
+    int vp_remote;                  // 1: the decoder layers run on the launch's helper workgroups
     const SdfAdj* sdf_adj;          // SDF term of this problem (sdf_term.hip), or null
     float sdf_fac, sdf_pad;         // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
     double total;
@@ -160,7 +162,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     if (x_g && tid < DPAD) L.opt.x[tid] = xv;
     if (vp_g && tid < nvp) reinterpret_cast<float4*>(L.vp_pre1)[tid] = vvp;
     if (tid >= 384 && tid < 384 + 8 * 12) (&L.gG[NJ][0])[tid - 384] = 0.f;               // "no child" rows
-    if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; }
+    if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; L.vp_remote = M.vps.nsets > 0 ? 1 : 0; L.vp_seq = 0u; }
 }
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {   // c = a b
@@ -237,7 +239,8 @@ __device__ __forceinline__ void gemv4_partial(const float* __restrict__ W, int l
 // ---------------------------------------------------------------------------------------------
 constexpr int VP_U = 16;          // rows (16-byte loads) in flight per thread in the decoder streams
 
-__device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
+// the three layers in this workgroup: z -> L.vp_o[138] (+ the pre-activations the adjoint needs)
+__device__ void vposer_layers_local(const DevModel& M, ClosureLds& L, int tid) {
     constexpr int nt = STEP_NT;
     // h1 = lrelu(W1 z + b1): one output per thread
     for (int o = tid; o < 512; o += nt) {
@@ -273,6 +276,75 @@ __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
     }
     __syncthreads();
     PH_T(28);
+}
+
+// Answers of the eight helpers of this problem's set -> dst[h * VPS_GRAN + o], o < n_used (n_used * 8 <= 3 * STEP_NT).
+// false when an answer did not arrive within 50 ms.
+__device__ __forceinline__ bool vps_collect(const unsigned long long* rp, unsigned tag, int n_used, float* dst, int tid) {
+    int idx[3];
+    unsigned pending = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int item = tid + STEP_NT * k;
+        const int h = item / n_used, o = item - h * n_used;
+        idx[k] = h * VPS_GRAN + o;
+        if (h < VPS_SLICES) pending |= 1u << k;
+    }
+    const long long t0 = wall_clock64();
+    int it = 0;
+    while (pending) {
+        unsigned long long g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if ((pending >> k) & 1u) g[k] = vps_load(rp + idx[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (((pending >> k) & 1u) && vps_tag(g[k]) == tag) { dst[idx[k]] = vps_val(g[k]); pending &= ~(1u << k); }
+        if (pending) {
+            if ((++it & 63) == 0 && wall_clock64() - t0 > 5000000) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return pending == 0u;
+}
+
+__device__ __forceinline__ unsigned long long* vps_request_slot(const VpService& V) {
+    const int pl = (int)blockIdx.x, s = pl % V.nsets, p = pl / V.nsets;
+    return V.req + ((size_t)s * VPS_PMAX + p) * VPS_GRAN;
+}
+__device__ __forceinline__ const unsigned long long* vps_answer_slot(const VpService& V) {
+    const int pl = (int)blockIdx.x, s = pl % V.nsets, p = pl / V.nsets;
+    return V.resp + ((size_t)s * VPS_PMAX + p) * VPS_SLICES * VPS_GRAN;
+}
+
+// the three layers on the helpers (vposer_service.h): false = no answer, the caller decodes locally from now on
+__device__ bool vposer_layers_remote(const DevModel& M, ClosureLds& L, int tid) {
+    const VpService& V = M.vps;
+    const unsigned seq = L.vp_seq + 1u, tag = seq << 2 | VPS_FWD;
+    if (tid < 32) vps_store(vps_request_slot(V) + tid, L.opt.x[X_EMB + tid], tag);
+    PH_T(26);
+    const bool ok = vps_collect(vps_answer_slot(V), tag, 138, L.scratch, tid);
+    const int bad = __syncthreads_or(ok ? 0 : 1);
+    PH_T(27);
+    if (bad) {
+        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); }
+        __syncthreads();
+        return false;
+    }
+    if (tid == 0) L.vp_seq = seq;
+    if (tid < 138) {
+        float acc = M.vp_b3[tid];
+#pragma unroll
+        for (int h = 0; h < VPS_SLICES; ++h) acc += L.scratch[h * VPS_GRAN + tid];
+        L.vp_o[tid] = acc;
+    }
+    __syncthreads();
+    PH_T(28);
+    return true;
+}
+
+__device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
+    constexpr int nt = STEP_NT;
+    if (!(L.vp_remote && vposer_layers_remote(M, L, tid))) vposer_layers_local(M, L, tid);
     // per joint: Gram-Schmidt -> R^T rows -> quaternion (4-way branch) -> axis-angle
     for (int j = tid; j < 23; j += nt) {
         float* C = L.vp_cache[j];
@@ -391,6 +463,30 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
     }
     __syncthreads();
     PH_T(29);
+    if (L.vp_remote) {
+        const VpService& V = M.vps;
+        const unsigned seq = L.vp_seq + 1u, tag = seq << 2 | VPS_BWD;
+        if (tid < 138) vps_store(vps_request_slot(V) + tid, L.vp_go[tid], tag);
+        const bool ok = vps_collect(vps_answer_slot(V), tag, 32, L.scratch, tid);
+        const int bad = __syncthreads_or(ok ? 0 : 1);
+        PH_T(30);
+        if (!bad) {
+            if (tid == 0) L.vp_seq = seq;
+            if (tid < 32) {
+                float acc = L.scratch[tid];
+#pragma unroll
+                for (int h = 1; h < VPS_SLICES; ++h) acc += L.scratch[h * VPS_GRAN + tid];
+                L.grad[X_EMB + tid] += acc;
+            }
+            __syncthreads();
+            PH_T(31);
+            return;
+        }
+        // no answer: local from now on; the local adjoint needs the pre-activations of the local forward
+        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); }
+        __syncthreads();
+        vposer_layers_local(M, L, tid);
+    }
     // g_h2 = W3^T g_o ; through lrelu.  w3[o][i]: thread i, consecutive threads consecutive addresses
     gemv4_partial<VP_U>(M.vp_w3, 512, 138, 512, 4, L.vp_go, L.scratch, tid);
     __syncthreads();

@@ -345,13 +345,22 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
                                                                  int max_rounds, AsyncRing ring, int b_lo, int done_target,
                                                                  int pause_stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (M.vps.nsets && (int)blockIdx.x >= M.vps.nprob) {
+        // decoder helper of this launch (vposer_service.h): workgroups behind the problems' ones; set = blockIdx % nsets
+        // like the problems it serves (dispatch is round-robin over the XCDs: same L2 when nsets == 8 - speed only)
+        vposer_helper(M.vpt, M.vps, smem_raw, (int)blockIdx.x % M.vps.nsets, ((int)blockIdx.x - M.vps.nprob) / M.vps.nsets);
+        return;
+    }
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
-    const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + gridDim.x): one sub-batch of mvfit_fit
+    const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + nprob): one sub-batch of mvfit_fit
     prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid);
     opts_in(L, SW, O, tid);
     __syncthreads();
-    if (L.opt.lbS.status != 0) return;
+    if (L.opt.lbS.status != 0) {
+        if (tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
+        return;
+    }
     if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
     if (tid == 64 * PUBLISH_WAVE) L.sh_pass_done = 0u;
     float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
@@ -388,6 +397,13 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     }
     if (!done)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
+    if (L.vp_remote) {
+        // goodbye to the helpers; the pose of the final point is decoded here (with the pre-activations the chained
+        // rounds of a two-phase fit expect from their predecessor)
+        __syncthreads();
+        if (tid == 0) { vps_store(vps_request_slot(M.vps), 0.f, (L.vp_seq + 1u) << 2 | VPS_BYE); L.vp_remote = 0; }
+        __syncthreads();
+    }
     pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
     if (paused) {
@@ -537,6 +553,10 @@ struct mvfit_ctx {
     hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr}, ev_init = nullptr;
     int* h_async_done = nullptr;       // pinned host word the last finishing problem writes
     unsigned async_stats[4] = {0, 0, 0, 0};
+    // decoder helpers of the single-launch fit (vposer_service.h): granule memory [requests | answers | 2 counters]
+    unsigned long long* vps_mem = nullptr;
+    size_t vps_words = 0;
+    unsigned vps_stats[3] = {0, 0, 0};     // launches with helpers in the last fit, answers timed out, helpers that gave up
     float* capture_verts = nullptr;    // mvfit_debug_capture_pass: the pass of closure round capture_round writes here
     int capture_round = -1;
     float* trace = nullptr;            // caller's device buffer (mvfit_fit_trace), not owned
@@ -931,6 +951,29 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         M.vp_w2 = dev_upload(c, w2); M.vp_b2 = dev_upload(c, b2);
         M.vp_w3 = dev_upload(c, w3); M.vp_b3 = dev_upload(c, b3);
         M.vp_w1T = dev_upload(c, w1T); M.vp_w2T = dev_upload(c, w2T); M.vp_w3T = dev_upload(c, w3T);
+        {   // register tiles of the decoder helpers (vposer_service.h: VpTiles), 16-byte words, thread-minor
+            std::vector<float> tw2((size_t)VPS_SLICES * 16 * 512 * 4), tw3((size_t)VPS_SLICES * 6 * 512 * 4, 0.f);
+            for (int h = 0; h < VPS_SLICES; ++h)
+                for (int tid = 0; tid < 512; ++tid) {
+                    const int w = tid >> 6, l = tid & 63;
+                    for (int j = 0; j < 16; ++j)
+                        for (int q = 0; q < 4; ++q)
+                            tw2[(((size_t)h * 16 + j) * 512 + tid) * 4 + q] = w2[(size_t)(64 * h + 8 * w + (j >> 1)) * 512 + 8 * l + 4 * (j & 1) + q];
+                    for (int j = 0; j < 6; ++j) {
+                        const int o = l + 64 * (j >> 1);
+                        if (o < 138)
+                            for (int q = 0; q < 4; ++q)
+                                tw3[(((size_t)h * 6 + j) * 512 + tid) * 4 + q] = w3[(size_t)o * 512 + 64 * h + 8 * w + 4 * (j & 1) + q];
+                    }
+                }
+            M.vpt.tw2 = reinterpret_cast<const float4*>(dev_upload(c, tw2));
+            M.vpt.tw3 = reinterpret_cast<const float4*>(dev_upload(c, tw3));
+            M.vpt.w1T = M.vp_w1T; M.vpt.b1 = M.vp_b1; M.vpt.b2 = M.vp_b2;
+            // request / answer granules of one launch (re-initialised before every launch that has helpers)
+            c->vps_words = (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN * (1 + VPS_SLICES);
+            std::vector<unsigned long long> zero(c->vps_words + 1, 0ull);
+            c->vps_mem = dev_upload(c, zero);
+        }
         c->has_vposer = true;
     }
     // ---- GMM ----
@@ -1347,6 +1390,44 @@ static int ensure_async(mvfit_ctx* c) {
     return MVFIT_OK;
 }
 
+// Decoder helpers (vposer_service.h) ride on the single-launch fits with the VPoser prior: min(8, n) sets of 8 helper
+// workgroups behind the n problems' ones, every set serving the problems b with b % nsets == s.  All workgroups of the
+// launch must be resident at once (the problems wait for their helpers' answers): such fits run in sub-batches of at most
+// kVpsMaxSparse problems (objective vertices only) / kVpsMaxAsync (asynchronous: the passes keep >= 96 CUs) - every
+// problem's arithmetic is the same whatever the slicing.  MVFIT_VP_HELPERS=0 keeps the decoder in the problems' own
+// workgroups (another summation order: results differ in the last bits).
+constexpr int kVpsHelpers = VPS_MAX_SETS * VPS_SLICES;                 // 64 CUs
+constexpr int kVpsMaxSparse = 160, kVpsMaxAsync = 96;
+static_assert(kVpsMaxSparse <= VPS_MAX_SETS * VPS_PMAX && kVpsMaxSparse + kVpsHelpers <= 256, "all workgroups resident");
+
+static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
+    const char* e = getenv("MVFIT_VP_HELPERS");          // read per fit: tests switch it inside one process
+    const bool off = e && atoi(e) == 0;
+    return (SW.w[0].flags & MVFIT_F_VPOSER) && c->vps_mem && !off;
+}
+
+static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, const AsyncRing& R, int b_lo,
+                             int b_hi, int done_target, int pause_stage) {
+    const int n = b_hi - b_lo;
+    DevModel M = c->M;
+    int grid = n;
+    if (vps_enabled(c, SW) && n <= kVpsMaxSparse) {
+        const int nsets = std::min(VPS_MAX_SETS, n);
+        HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8, c->stream));
+        M.vps.req = c->vps_mem;
+        M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;
+        M.vps.stat = reinterpret_cast<unsigned*>(c->vps_mem + c->vps_words);
+        M.vps.nsets = nsets;
+        M.vps.nprob = n;
+        grid = n + nsets * VPS_SLICES;
+        c->vps_stats[0] += 1;
+    }
+    hipLaunchKernelGGL(fit_persistent_kernel, dim3(grid), dim3(STEP_NT), persistent_lds(), c->stream, M,
+                       (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage);
+    HIP_OK(c, hipGetLastError());
+    return MVFIT_OK;
+}
+
 static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1) {
     int rc = ensure_async(c);
     if (rc) return rc;
@@ -1360,7 +1441,8 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     // More problems than the optimiser gets CUs (one workgroup per CU, >= 96 CUs left to the passes): time-sliced in
     // sub-batches of whole 32-problem chunks, one after the other - every sub-batch is the same asynchronous fit (problems
     // are independent: the results do not depend on the slicing, tests/test_gpu_large_batch.py).
-    const int nsub = (B + kAsyncMaxB - 1) / kAsyncMaxB;
+    const int maxb = vps_enabled(c, SW) ? kVpsMaxAsync : kAsyncMaxB;
+    const int nsub = (B + maxb - 1) / maxb;
     const int per = ((B + nsub - 1) / nsub + 31) / 32 * 32;
     static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
     for (int b_lo = 0; b_lo < B; b_lo += per) {
@@ -1369,9 +1451,8 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4, c->stream));
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
-        hipLaunchKernelGGL(fit_persistent_kernel, dim3(b_hi - b_lo), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
-                           (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, b_hi, pause_stage);
-        HIP_OK(c, hipGetLastError());
+        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi, pause_stage);
+        if (rc) return rc;
         // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
         int k = 0;
         for (;; ++k) {
@@ -1432,6 +1513,18 @@ extern "C" int mvfit_fit_stats(mvfit_ctx* c, uint32_t* out4) {
     return MVFIT_OK;
 }
 
+extern "C" int mvfit_decoder_stats(mvfit_ctx* c, uint32_t* out3) {
+    if (!c || !out3) return MVFIT_E_ARG;
+    unsigned st[2] = {0, 0};
+    if (c->vps_mem && c->vps_stats[0]) {
+        HIP_OK(c, hipSetDevice(c->device));
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        HIP_OK(c, hipMemcpy(st, c->vps_mem + c->vps_words, 8, hipMemcpyDeviceToHost));
+    }
+    out3[0] = c->vps_stats[0]; out3[1] = st[0]; out3[2] = st[1];
+    return MVFIT_OK;
+}
+
 extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfgs_opts* o, float* params,
                          float* final_loss, int32_t* n_closure, int32_t* n_iter) {
     if (!c || !sw || !o || !params) return MVFIT_E_ARG;
@@ -1473,6 +1566,8 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     const bool two_phase = any_sdf && lead >= 1 && lead < o->num_stages && c->M.bs_h2 != nullptr && !serial &&
                            !getenv("MVFIT_SDF_ONE_PHASE");
     for (unsigned& v : c->async_stats) v = 0;
+    for (unsigned& v : c->vps_stats) v = 0;
+    if (c->vps_mem) HIP_OK(c, hipMemsetAsync(c->vps_mem + c->vps_words, 0, 8, c->stream));
     const int B = c->B;
     HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 8, c->stream));
     HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
@@ -1495,16 +1590,21 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
         if (rc) return rc;
         *h_done = seen;
     } else if (sparse) {
-        while (rounds < cap) {
-            const int chunk = std::min(cap - rounds, 1 << 20);
-            hipLaunchKernelGGL(fit_persistent_kernel, dim3(B), dim3(STEP_NT), persistent_lds(), c->stream, c->M,
-                               (const ObsBlock*)c->d_obs, c->V, SW, O, c->P,
-                               c->F, chunk, AsyncRing{}, 0, B, MVFIT_MAX_STAGES + 1);
-            HIP_OK(c, hipGetLastError());
-            rounds += chunk;
-            HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_OK(c, hipStreamSynchronize(c->stream));
-            if (*h_done >= B) break;
+        // (with decoder helpers: sub-batches whose workgroups are all resident, one after the other)
+        const int maxb = vps_enabled(c, SW) ? kVpsMaxSparse : B;
+        const int nsub = (B + maxb - 1) / maxb, per = (B + nsub - 1) / nsub;
+        for (int b_lo = 0; b_lo < B; b_lo += per) {
+            const int b_hi = std::min(B, b_lo + per);
+            rounds = 0;
+            while (rounds < cap) {
+                const int chunk = std::min(cap - rounds, 1 << 20);
+                rc = launch_persistent(c, SW, O, chunk, AsyncRing{}, b_lo, b_hi, b_hi, MVFIT_MAX_STAGES + 1);
+                if (rc) return rc;
+                rounds += chunk;
+                HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(c, hipStreamSynchronize(c->stream));
+                if (*h_done >= b_hi) break;
+            }
         }
     } else if (c->profile) {
         // eager launches bracketed by events (bench.py's per-launch timing of the vertex pass)
@@ -1601,6 +1701,12 @@ extern "C" int mvfit_debug_timing(long long* out32, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 32);
     if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z)); }
+    return 0;
+}
+extern "C" int mvfit_debug_timing_helpers(long long* out16, int reset) {       // g_dbg[32..47]: decoder helper (set 0, slice 0)
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16, sizeof(long long) * 32);
+    if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z), sizeof(long long) * 32); }
     return 0;
 }
 #endif

@@ -5,6 +5,7 @@
 #include "../../include/mvfit.h"
 #include "wave_ops.h"
 #include "lbfgs_device.h"
+#include "vposer_service.h"
 
 namespace mvfit {
 
@@ -105,6 +106,8 @@ struct DevModel {
     const float* vp_w1T;                        // [32][512]
     const float* vp_w2T;                        // [512][512]
     const float* vp_w3T;                        // [512][138->144]
+    VpTiles vpt;                                // the same weights as register tiles of the decoder helpers (vposer_service.h)
+    VpService vps;                              // per launch: the helpers of THIS launch (nsets == 0: none)
     // GMM
     int gmm_M;
     const float* gmm_means;      // [M][69]

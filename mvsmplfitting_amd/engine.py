@@ -224,6 +224,13 @@ class MvFit:
         return x, dict(final_loss=final, n_closure=ncl, n_iter=nit,
                        passes=dict(run=int(st4[0]), skipped=int(st4[1]), missed=int(st4[2]), timed_out=int(st4[3])))
 
+    def decoder_stats(self):
+        """Counters of the VPoser decoder helpers of the last fit (include/mvfit.h:mvfit_decoder_stats): launches that
+        carried helpers, answers that timed out, helpers that gave up (both expected 0).  Waits for the fit."""
+        st3 = (C.c_uint32 * 3)()
+        self._check(self._lib.mvfit_decoder_stats(self._ctx, st3))
+        return dict(launches=int(st3[0]), answers_timed_out=int(st3[1]), helpers_gave_up=int(st3[2]))
+
     def fit_trace(self, max_closures=0):
         """Record (x_trial[118], loss) of the first ``max_closures`` closure calls of every problem during the next
         fits (include/mvfit.h:mvfit_fit_trace); returns the [B, max_closures, 119] tensor (NaN where nothing was

@@ -17,7 +17,10 @@ _, joints = eng.vertices(xgt)
 gt, conf = syn.make_observations(joints.cpu().numpy(), cams); eng.set_problems(cams, gt, conf)
 x0 = np.zeros((B,118), np.float32); x0[:,85]=1
 buf = (C.c_longlong*32)()
-for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
+hb = (C.c_longlong*16)()
+for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS), ('vposer_sparse_helpers_off', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
+    os.environ['MVFIT_VP_HELPERS'] = '0' if name.endswith('off') else '1'
+    lib.mvfit_debug_timing_helpers(hb, 1)
     lib.mvfit_debug_timing(buf, 1)
     xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
     lib.mvfit_debug_timing(buf, 1)
@@ -27,7 +30,9 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     print('   ', ' | '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(13)), '| total=%.0f cycles/round' % (sum(buf[i] for i in range(13))/n))
     print('    step-kernel prologue=%.0f epilogue (state store + pose/chain of next x + publish)=%.0f' % (buf[24]/n, buf[25]/n))
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
-    print('    vposer: L1=%.0f L2=%.0f out=%.0f | (GS+quat in pose_prep rest) | bwd: joints=%.0f W3T=%.0f W2T=%.0f (W1T in E9 rest)' % tuple(buf[i]/n for i in (26,27,28,29,30,31)))
+    print('    vposer (helpers: request sent / answers in / summed ; adjoint: joints / answers in / summed): L1=%.0f L2=%.0f out=%.0f | (GS+quat in pose_prep rest) | bwd: joints=%.0f W3T=%.0f W2T=%.0f (W1T in E9 rest)' % tuple(buf[i]/n for i in (26,27,28,29,30,31)))
+    lib.mvfit_debug_timing_helpers(hb, 1)
+    if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
     if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
     print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
 

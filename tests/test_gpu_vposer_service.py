@@ -1,0 +1,89 @@
+"""GPU: the VPoser decoder helpers of the single-launch fits (csrc/vposer_service.h): the decoder's three layers
+(code/model/VPoser.py:218-232) evaluated on helper workgroups with register-resident weights instead of in every
+problem's own workgroup.  The parity pin of that arithmetic is tests/test_gpu_trajectory.py (the helpers are on by
+default: the production fit follows the reference's own float32 trajectory closure for closure); here: the helpers
+really run, nothing times out, the fit agrees with the in-workgroup decoder as closely as two summation orders of the
+same float32 products can (first closures to rounding, then the usual line-search amplification), and a problem's
+result does not depend on the batch it is fitted in (set / slot / sub-batch)."""
+import os
+
+import numpy as np
+import pytest
+
+from mvsmplfitting_amd import _lib
+from mvsmplfitting_amd import synthetic as syn
+from mvsmplfitting_amd.engine import MvFit, stage_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(eng, B, views=8, seed=5):
+    cams = syn.make_camera_ring(views)
+    fr = syn.make_frames(B, seed0=seed)
+    x = np.zeros((B, 118), np.float32)
+    for k, (a, b) in dict(betas=(0, 10), global_orient=(10, 13), body_pose=(13, 82), transl=(82, 85), scale=(85, 86)).items():
+        x[:, a:b] = fr[k]
+    eng.set_problems(cams, np.zeros((B, views, 17, 2), np.float32), np.ones((B, views, 17), np.float32))
+    _, joints = eng.vertices(x)
+    gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=seed + 7)
+    eng.set_problems(cams, gt, conf)
+    x0 = np.zeros((B, 118), np.float32)
+    x0[:, 85] = 1.0
+    return x0, cams, gt, conf
+
+
+def _fit(eng, x0, flags, helpers, trace=0):
+    old = os.environ.get('MVFIT_VP_HELPERS')
+    os.environ['MVFIT_VP_HELPERS'] = '1' if helpers else '0'
+    try:
+        tr = eng.fit_trace(trace) if trace else None
+        xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
+        ds = eng.decoder_stats()
+        out = dict(x=xf.cpu().numpy(), final=st['final_loss'].cpu().numpy(), ncl=st['n_closure'].cpu().numpy(), stats=ds,
+                   passes=st['passes'], trace=None if tr is None else tr.cpu().numpy().astype(np.float64))
+        if trace:
+            eng.fit_trace(0)
+        return out
+    finally:
+        if old is None:
+            del os.environ['MVFIT_VP_HELPERS']
+        else:
+            os.environ['MVFIT_VP_HELPERS'] = old
+
+
+@pytest.mark.parametrize('sparse', [True, False])
+def test_helpers_run_and_agree_with_the_in_workgroup_decoder(sparse):
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    B = 11                                                  # 8 sets, three of them with two problems
+    x0 = _problems(eng, B)[0]
+    flags = _lib.F_VPOSER | (_lib.F_SPARSE_VERTS if sparse else 0)
+    a = _fit(eng, x0, flags, True, trace=40)
+    b = _fit(eng, x0, flags, False, trace=40)
+    assert a['stats'] == dict(launches=1, answers_timed_out=0, helpers_gave_up=0), a['stats']
+    assert b['stats']['launches'] == 0
+    assert a['passes']['missed'] == 0 and a['passes']['timed_out'] == 0
+    for k in range(12):                 # rounding at the first closures, then the line search amplifies (cf. test_gpu_trajectory.tol)
+        rel = 3e-6 if k == 0 else (2e-5 if k < 3 else 5e-3)
+        la, lb = a['trace'][:, k, 118], b['trace'][:, k, 118]
+        assert np.all(np.abs(la - lb) <= rel * np.abs(lb)), (k, la, lb)
+        assert np.abs(a['trace'][:, k, :118] - b['trace'][:, k, :118]).max() <= (0.0 if k == 0 else 50 * rel), k
+    assert np.all(np.isfinite(a['final'])) and np.all(a['final'] <= 1.5 * b['final'] + 1.0), (a['final'], b['final'])
+    eng.close()
+
+
+def test_a_problems_fit_does_not_depend_on_the_batch_around_it():
+    """33 problems (sets of 4-5 problems, slots 0..4) against the same problems fitted 3 at a time (sets of one): same
+    helper arithmetic whatever the set, the slot or the number of problems a helper serves - bit for bit."""
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    B = 33
+    flags = _lib.F_VPOSER | _lib.F_SPARSE_VERTS
+    x0, cams, gt, conf = _problems(eng, B)
+    big = _fit(eng, x0, flags, True)
+    assert big['stats']['answers_timed_out'] == 0 and big['stats']['helpers_gave_up'] == 0
+    for lo in (0, 15, 30):
+        eng.set_problems(cams, gt[lo:lo + 3], conf[lo:lo + 3])
+        small = _fit(eng, x0[lo:lo + 3], flags, True)
+        assert np.array_equal(small['x'], big['x'][lo:lo + 3]), lo
+        assert np.array_equal(small['final'], big['final'][lo:lo + 3])
+        assert np.array_equal(small['ncl'], big['ncl'][lo:lo + 3])
+    eng.close()
