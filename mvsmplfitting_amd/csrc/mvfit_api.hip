@@ -1396,9 +1396,10 @@ static int ensure_async(mvfit_ctx* c) {
 // kVpsMaxSparse problems (objective vertices only) / kVpsMaxAsync (asynchronous: the passes keep >= 96 CUs) - every
 // problem's arithmetic is the same whatever the slicing.  MVFIT_VP_HELPERS=0 keeps the decoder in the problems' own
 // workgroups (another summation order: results differ in the last bits).
-constexpr int kVpsHelpers = VPS_MAX_SETS * VPS_SLICES;                 // 64 CUs
+constexpr int kVpsSets = 8;                                             // sets of a launch with more than 32 problems
+constexpr int kVpsHelpers = kVpsSets * VPS_SLICES;                      // 64 CUs
 constexpr int kVpsMaxSparse = 160, kVpsMaxAsync = 96;
-static_assert(kVpsMaxSparse <= VPS_MAX_SETS * VPS_PMAX && kVpsMaxSparse + kVpsHelpers <= 256, "all workgroups resident");
+static_assert(kVpsMaxSparse <= kVpsSets * VPS_PMAX && kVpsMaxSparse + kVpsHelpers <= 256 && 32 + VPS_MAX_SETS * VPS_SLICES <= 160, "all workgroups resident");
 
 static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
     const char* e = getenv("MVFIT_VP_HELPERS");          // read per fit: tests switch it inside one process
@@ -1412,7 +1413,10 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
     DevModel M = c->M;
     int grid = n;
     if (vps_enabled(c, SW) && n <= kVpsMaxSparse) {
-        const int nsets = std::min(VPS_MAX_SETS, n);
+        // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
+        const char* e = getenv("MVFIT_VP_SETS");
+        const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
+        const int nsets = std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n);
         HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8, c->stream));
         M.vps.req = c->vps_mem;
         M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;

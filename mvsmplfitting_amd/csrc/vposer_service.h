@@ -36,7 +36,7 @@ namespace mvfit {
 
 constexpr int VPS_SLICES = 8;           // helpers per set = slices of the 512 fc2 units
 constexpr int VPS_PMAX = 24;            // problems per set (wave w polls the slots w, w + 8, w + 16)
-constexpr int VPS_MAX_SETS = 8;
+constexpr int VPS_MAX_SETS = 16;          // 16 for launches of <= 32 problems, else 8
 constexpr int VPS_GRAN = 144;           // granules per request / per answer (138 used)
 constexpr unsigned VPS_FWD = 1u, VPS_BWD = 2u, VPS_BYE = 3u;
 
@@ -60,36 +60,63 @@ __device__ __forceinline__ unsigned long long vps_load(const unsigned long long*
 }
 
 // v[N] per lane -> the wave total of ONE element per lane: exchange steps over lane bits 5, 4, ... halve the vector
-// (a lane keeps the half its bit selects and adds the partner's copy of it), the remaining lane bits are plain
-// butterflies.  Returns element e(l) = the kept-half bits, most significant first: N = 8: 4 b5 + 2 b4 + b3;
-// N = 32: 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1.  Same bits in all lanes that share e(l).
+// (a lane keeps the half its bit selects and adds its partner's copy of that half), the remaining lane bits are plain
+// butterflies.  Partners: the other 32-lane half / the other 16-lane row (v_permlane32_swap / v_permlane16_swap: the swap
+// IS the exchange, one instruction per pair of elements), then the mirror lane of the row, of the 8-lane group, of the
+// quad (DPP modifiers on the add) - every partner differs in the step's bit and agrees in all higher ones, which is all
+// a reduce-scatter needs.  Returns element e(l) = the kept-half bits, most significant first: N = 8: 4 b5 + 2 b4 + b3;
+// N = 32: 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1.  Same bits in all lanes that share e(l); fixed association.
+template <int M>
+__device__ __forceinline__ float vps_partner(float x) {
+    if constexpr (M == 8) return dpp_mov<DPP_MIRROR>(x);
+    else if constexpr (M == 4) return dpp_mov<DPP_HALF_MIRROR>(x);
+    else if constexpr (M == 2) return dpp_mov<DPP_XOR2>(x);
+    else return dpp_mov<DPP_XOR1>(x);
+}
 template <int N, int M0 = 32>
 __device__ __forceinline__ float wave_reduce_scatter(float (&v)[N], int lane) {
     if constexpr (N > 1) {
-        const bool up = (lane & M0) != 0;
         float u[N / 2];
+        if constexpr (M0 >= 16) {
 #pragma unroll
-        for (int j = 0; j < N / 2; ++j) {
-            const float send = up ? v[j] : v[j + N / 2];
-            const float keep = up ? v[j + N / 2] : v[j];
-            u[j] = keep + __shfl_xor(send, M0, 64);
+            for (int j = 0; j < N / 2; ++j) {
+                const unsigned a = __builtin_bit_cast(unsigned, v[j]), b = __builtin_bit_cast(unsigned, v[j + N / 2]);
+                if constexpr (M0 == 32) {
+                    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                    u[j] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+                } else {
+                    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+                    u[j] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+                }
+            }
+        } else {
+            const bool up = (lane & M0) != 0;
+#pragma unroll
+            for (int j = 0; j < N / 2; ++j) {
+                const float send = up ? v[j] : v[j + N / 2];
+                const float keep = up ? v[j + N / 2] : v[j];
+                u[j] = keep + vps_partner<M0>(send);
+            }
         }
         return wave_reduce_scatter<N / 2, M0 / 2>(u, lane);
     } else {
         float t = v[0];
-#pragma unroll
-        for (int m = M0; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if constexpr (M0 >= 32) { float a, b; swap_pair<true>(t, a, b); t = a + b; }
+        if constexpr (M0 >= 16) { float a, b; swap_pair<false>(t, a, b); t = a + b; }
+        if constexpr (M0 >= 8) t += vps_partner<8>(t);
+        if constexpr (M0 >= 4) t += vps_partner<4>(t);
+        if constexpr (M0 >= 2) t += vps_partner<2>(t);
+        if constexpr (M0 >= 1) t += vps_partner<1>(t);
         return t;
     }
 }
 // the same for the 32 products w[i] * g, formed inside the first exchange step (16 live values instead of 32)
 __device__ __forceinline__ float wave_reduce_scatter_scaled32(const float (&w)[32], float g, int lane) {
     float v[16];
-    const bool up = (lane & 32) != 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float a = w[j] * g, b = w[j + 16] * g;
-        v[j] = (up ? b : a) + __shfl_xor(up ? a : b, 32, 64);
+        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, w[j] * g), __builtin_bit_cast(unsigned, w[j + 16] * g), false, false);
+        v[j] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
     }
     return wave_reduce_scatter<16, 16>(v, lane);
 }
@@ -192,13 +219,14 @@ __device__ void vposer_helper(const VpTiles& T, const VpService& V, unsigned cha
             const long long tq0 = clock64();
 #endif
             if (kind == VPS_FWD) {
-                float s1 = b1o;
+                float c4[4] = {0.f, 0.f, 0.f, 0.f};             // four chains of eight: z[i], i = q (mod 4)
 #pragma unroll
                 for (int i4 = 0; i4 < 8; ++i4) {
                     const float4 z = *reinterpret_cast<const float4*>(&S.req[p][4 * i4]);
-                    s1 = fmaf(w1[4 * i4], z.x, s1); s1 = fmaf(w1[4 * i4 + 1], z.y, s1);
-                    s1 = fmaf(w1[4 * i4 + 2], z.z, s1); s1 = fmaf(w1[4 * i4 + 3], z.w, s1);
+                    c4[0] = fmaf(w1[4 * i4], z.x, c4[0]); c4[1] = fmaf(w1[4 * i4 + 1], z.y, c4[1]);
+                    c4[2] = fmaf(w1[4 * i4 + 2], z.z, c4[2]); c4[3] = fmaf(w1[4 * i4 + 3], z.w, c4[3]);
                 }
+                const float s1 = b1o + ((c4[0] + c4[1]) + (c4[2] + c4[3]));
                 S.h1[tid] = s1 > 0.f ? s1 : 0.2f * s1;
                 const unsigned long long pos = __ballot(s1 > 0.f);
                 if (l == 0) S.mask1[p][w] = pos;
