@@ -238,16 +238,18 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
         return ms
     for name, B, env, kern, key in (
             ('exact_fp32_B32', 32, {'MVFIT_EXACT_FP32': '1'}, 'lbs_vertex_pass_kernel<true>', None),
-            ('split_fp16_B128', 128, {}, 'lbs_vertex_pass_split_loop_kernel<true>', 'B128'),
+            ('split_fp16_B128', 128, {}, 'lbs_vertex_pass_pipe_kernel', 'B128'),
             ('half_basis_B32', 32, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_kernel<true>', None),
-            ('half_basis_B128', 128, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_loop_kernel<true>', None)):
+            ('half_basis_B128', 128, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_pipe_kernel', None)):
         ms = measure(B, env)
         nbytes = bytes_fwd(B, skin_topk, half_basis='MVFIT_HALF_BASIS' in env)
         ach = nbytes / (ms * 1e-3) / 1e9
+        if B > 32 and not (skin_topk and skin_topk <= 4):
+            kern = 'lbs_vertex_pass_split_loop_kernel<false>'     # dense skinning rows: the lock-step chunk loop
         out[name] = dict(kernel=kern if skin_topk else kern.replace('<true>', '<false>'), problems=B,
                          avg_launch_us=round(ms * 1e3, 2), algorithmic_bytes=nbytes,
                          achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
-                         traffic=pmc_value(key, 'split_loop') if key else None)
+                         traffic=pmc_value(key, 'vertex_pass_pipe') if key else None)
     return out
 
 
@@ -274,6 +276,8 @@ def prior_variants(MvFit, syn, _lib, stage_weights, model, frames, views, steps=
         out[name] = dict(value=round(tot / dt, 1), unit='closures/s', ms_per_step=round(1e3 * dt / steps, 3),
                          closures_per_fit_per_frame=round(tot / steps / frames, 1), closure_rounds_per_fit=int(ncl[-1].max().item()),
                          final_loss_median=float(np.median(st['final_loss'].cpu().numpy())), vertex_passes_last_fit=st.get('passes'))
+        if flag & _lib.F_VPOSER:
+            out[name]['decoder_helpers_last_fit'] = eng.decoder_stats()
         eng.close()
     return out
 
@@ -449,6 +453,8 @@ def main():
             lost[0] += passes['missed']; lost[1] += passes['timed_out']
     barrier()
     dt = time.perf_counter() - t0
+    # VPoser prior: the decoder layers of the single-launch fits run on helper workgroups (csrc/vposer_service.h)
+    decoder = eng.decoder_stats() if (flags & _lib.F_VPOSER) else None
     for ncl_t, nit_t in counts:
         n_closure += int(ncl_t.sum().item())
         n_iter += int(nit_t.sum().item())
@@ -476,8 +482,11 @@ def main():
     if not args.sparse and not demo:
         in_fit = bool(passes and passes['run'] > 0)          # asynchronous fit: ring operands, non-temporal streams
         nchunks = (B + 31) // 32
-        kname = ('lbs_vertex_pass_split_kernel' if nchunks == 1 else 'lbs_vertex_pass_split_loop_kernel') + \
-                ('<true>' if args.skin_topk and args.skin_topk <= 4 else '<false>')
+        sparse_w = bool(args.skin_topk and args.skin_topk <= 4)
+        if nchunks == 1:
+            kname = 'lbs_vertex_pass_split_kernel' + ('<true>' if sparse_w else '<false>')
+        else:        # more than 32 problems: the two-role pipelined chunk loop (<= 4 weights per vertex), else the lock-step loop
+            kname = 'lbs_vertex_pass_pipe_kernel' if sparse_w else 'lbs_vertex_pass_split_loop_kernel<false>'
         # (a) the kernel as it ran inside a fit: one more identical fit (outside the timed region) in which every pass
         #     launch carries an event pair stamped by the runtime with the dispatch's own begin / end (hipExtLaunchKernelGGL)
         eng.profile(True)
@@ -576,6 +585,7 @@ def main():
             'final_loss_median': float(np.median(fl)),
             'vertex_passes_last_fit': passes,
             'vertex_passes_lost_in_timed_fits': {'missed': lost[0], 'timed_out': lost[1]},
+            'decoder_helpers_last_fit': decoder,
             'per_rank_busy_ms_per_step': busy_all,
             'variants': variants,
             'roofline': roof, 'cpu_baseline': cpu,

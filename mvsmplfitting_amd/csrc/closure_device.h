@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemv4_partial(const float* __restrict__ W, int l
 constexpr int VP_U = 16;          // rows (16-byte loads) in flight per thread in the decoder streams
 
 // the three layers in this workgroup: z -> L.vp_o[138] (+ the pre-activations the adjoint needs)
-__device__ void vposer_layers_local(const DevModel& M, ClosureLds& L, int tid) {
+__device__ __forceinline__ void vposer_layers_local(const DevModel& M, ClosureLds& L, int tid) {
     constexpr int nt = STEP_NT;
     // h1 = lrelu(W1 z + b1): one output per thread
     for (int o = tid; o < 512; o += nt) {
@@ -342,9 +342,14 @@ __device__ bool vposer_layers_remote(const DevModel& M, ClosureLds& L, int tid) 
     return true;
 }
 
-__device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
+// REMOTE: the single-launch fit kernel (its launches may carry decoder helpers); every other kernel instantiates the
+// local decoder only - their per-round launches must stay below the scratch size the runtime keeps resident.
+template <bool REMOTE>
+__device__ __forceinline__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
     constexpr int nt = STEP_NT;
-    if (!(L.vp_remote && vposer_layers_remote(M, L, tid))) vposer_layers_local(M, L, tid);
+    bool decoded = false;
+    if constexpr (REMOTE) decoded = L.vp_remote && vposer_layers_remote(M, L, tid);
+    if (!decoded) vposer_layers_local(M, L, tid);
     // per joint: Gram-Schmidt -> R^T rows -> quaternion (4-way branch) -> axis-angle
     for (int j = tid; j < 23; j += nt) {
         float* C = L.vp_cache[j];
@@ -388,7 +393,8 @@ __device__ void vposer_forward(const DevModel& M, ClosureLds& L, int tid) {
 }
 
 // g_z += (d body_pose / d z)^T g_body_pose   (transcription of oracle vposer_decode_bwd)
-__device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
+template <bool REMOTE>
+__device__ __forceinline__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
     constexpr int nt = STEP_NT;
     for (int j = tid; j < 23; j += nt) {
         const float* C = L.vp_cache[j];
@@ -463,7 +469,7 @@ __device__ void vposer_backward(const DevModel& M, ClosureLds& L, int tid) {
     }
     __syncthreads();
     PH_T(29);
-    if (L.vp_remote) {
+    if (REMOTE && L.vp_remote) {
         const VpService& V = M.vps;
         const unsigned seq = L.vp_seq + 1u, tag = seq << 2 | VPS_BWD;
         if (tid < 138) vps_store(vps_request_slot(V) + tid, L.vp_go[tid], tag);
@@ -565,9 +571,14 @@ __device__ __forceinline__ void contraction_forward_finish(ClosureLds& L, const 
 // Every thread derives what it needs straight from x (Rodrigues is recomputed per output element)
 // so the phase has no internal barrier.  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
-__device__ void pose_prep_decode(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+template <bool REMOTE = false>
+// (inlining is spelled out for everything the fit kernels use: left to the heuristics it changes with the number of
+// kernel instantiations, and the single-launch kernel's register allocation - hence its speed - with it.  The
+// single-launch kernel CALLS this phase - pose_prep_decode below -, every other kernel inlines it: a call's frame in a
+// per-round kernel would push its scratch size past what the runtime keeps resident between dispatches)
+__device__ __forceinline__ void pose_prep_decode_inl(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
     if (flags & MVFIT_F_VPOSER) {
-        vposer_forward(M, L, tid);
+        vposer_forward<REMOTE>(M, L, tid);
         if (tid < 3) L.pose.theta[tid] = L.opt.x[X_GO + tid];
         __syncthreads();
     } else {
@@ -627,8 +638,15 @@ __device__ __forceinline__ void pose_prep_elems(const DevModel& M, ClosureLds& L
     __syncthreads();
 }
 
-__device__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
-    pose_prep_decode(M, L, flags, tid);
+template <bool REMOTE = false>
+__device__ __attribute__((noinline)) void pose_prep_decode(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+    pose_prep_decode_inl<REMOTE>(M, L, flags, tid);
+}
+
+template <bool CALL = false>
+__device__ __forceinline__ void pose_prep(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+    if constexpr (CALL) pose_prep_decode<false>(M, L, flags, tid);
+    else pose_prep_decode_inl<false>(M, L, flags, tid);
     pose_prep_elems(M, L, flags, tid);
 }
 
@@ -1146,6 +1164,7 @@ __device__ __forceinline__ void contraction_backward_finish(ClosureLds& L, int t
 // Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward).
 // Ends with __syncthreads; L.grad holds the flat gradient.
 // ---------------------------------------------------------------------------------------------
+template <bool REMOTE = false>
 __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
@@ -1358,11 +1377,11 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
         L.grad[i] = g;
     }
     __syncthreads();
-    if (use_vp) vposer_backward(M, L, tid);
+    if (use_vp) vposer_backward<REMOTE>(M, L, tid);
 }
 
 // write the operands of the vertex pass for problem b
-__device__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid) {
+__device__ __forceinline__ void publish_pose(const ClosureLds& L, const DevPose& P, int b, int tid) {
     float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
     _Float16* ch = reinterpret_cast<_Float16*>(P.coefH) + (size_t)(b >> 5) * (KROWS / 16) * 2 * 64 * 8;
     for (int p = tid; p < KROWS; p += STEP_NT) {
@@ -1393,7 +1412,7 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 constexpr int PUBLISH_WAVE = 3;      // idle in the loss phase that follows (data term: waves 0-1 at <= 7 views; 3-D term and priors: waves 5-7)
 
-__device__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int tid) {
+__device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int tid) {
     // All 129 words go out from ONE wave, which also stores the tag later: the hand-off needs no workgroup barrier.
     const int l = tid - 64 * PUBLISH_WAVE;
     if (l < 0 || l >= 64) return;

@@ -494,7 +494,7 @@ __device__ void lb_direction_compact(const LbHist<T>& Hh, LbWork<T>& W, LbCompac
 // d = -H g (lbfgs_ls.py:336-358) by the whole workgroup (NT threads, wave 0 = the optimiser wave).
 // In: W.qv = -g, W.n/head/ins_slot/Hdiag, history rows incl. the freshly inserted pair.  Out: W.dv.
 template <typename T, int NT>
-__device__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid, LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
+__device__ __forceinline__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid, LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
     // the window was requested before the optimiser advanced: it is usable if the ring head is where it was (or one
     // further: the oldest pair was evicted) and the rows the walks touch are inside it; a stage change resets the
     // ring and a head wrap moves the walk far away - then the recurrences read global memory as before
@@ -826,10 +826,23 @@ L_emit_trial:                                                         // _direct
 // leave through `gtd > -tolerance_change` (lbfgs_ls.py:379-380) into run_fitting's gtol test (fitting.py:115-116),
 // which reads the .grad the last closure call left, i.e. this round's gnew.  Called by all NT threads (wave 0 = the
 // optimiser wave; S, V, gnew, xt are meaningful in wave 0 only).  On return xt = the next trial point.
-template <typename T, int NT, typename DirFn>
+// REUSE: the instantiation for O.reuse_outer (MVFIT_F_REUSE_OUTER_VALUE); without it the round is the plain two-call form.
+template <typename T, int NT, bool REUSE, typename DirFn>
 __device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
                                             double f_new, const T* gnew, T* xt, int tid, double* stage_final,
                                             DirFn&& direction) {
+    if constexpr (!REUSE) {
+        if (tid < 64) {
+            const int need = lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+            if (tid == 0) W.need_dir = need;
+        }
+        __syncthreads();
+        if (W.need_dir) {                                  // block-uniform
+            direction();
+            if (tid < 64) lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+        }
+        return;
+    }
     // Opt-in reuse (O.reuse_outer, a kernel argument: uniform): while the machine sits at a step start whose opening
     // closure call would return what it already holds, (loss, g) are fed back without an evaluation - further passes of
     // the same loop, so that the state machine stays inlined at two call sites.  Bounded: every pass either emits a
@@ -851,7 +864,6 @@ __device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHi
             direction();
             if (tid < 64) lbfgs_advance<T>(S, V, Hh, W, O, fv, gv, xt, tid, stage_final, virt);
         }
-        if (!O.reuse_outer) return;
         __syncthreads();
         if (tid == 0) W.need_dir = (S.phase == PH_STEP_START && S.reuse_ok && !S.status) ? 1 : 0;
         __syncthreads();

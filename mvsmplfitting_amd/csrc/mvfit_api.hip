@@ -67,8 +67,9 @@ __device__ __forceinline__ int cmap(int i, bool use_vp) {
 __device__ __forceinline__ int dact(bool use_vp) { return use_vp ? 49 : 86; }
 
 // pose operands of the vertex pass only: E1 + chain
+template <bool CALL = false>
 __device__ __forceinline__ void pose_and_chain(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
-    pose_prep(M, L, flags, tid);
+    pose_prep<CALL>(M, L, flags, tid);
     chain_forward_block(L, tid);
 }
 
@@ -208,6 +209,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 
 // shared by the two fit kernels: evaluate the closure at L.opt.x, advance the optimiser, leave the
 // next trial point in L.opt.x.  Returns true when the problem is finished.
+// REMOTE: the launch may carry VPoser decoder helpers (fit_persistent_kernel only); REUSE: MVFIT_F_REUSE_OUTER_VALUE
+template <bool REMOTE = false, bool REUSE = false>
 __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
@@ -224,7 +227,7 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     FwdPrefetch pf;
     const bool pre_f = kFwdPrefetch && !from_pass && !have_pose && fwd_prefetch_fits(L);          // block-uniform
     if (!have_pose) {
-        pose_prep_decode(M, L, W.flags, tid);
+        pose_prep_decode<REMOTE>(M, L, W.flags, tid);
         if (pre_f) contraction_forward_issue(M, L.M.nc_pad, tid, pf);
         pose_prep_elems(M, L, W.flags, tid);
     }
@@ -245,7 +248,7 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
             if (tid == 0) trace[(size_t)k * (DV + 1) + DV] = (float)total;
         }
     }
-    closure_backward(M, L, nviews, W, tid);
+    closure_backward<REMOTE>(M, L, nviews, W, tid);
     if (ring) publish_tag(*ring, a_slot, pb, a_round, tid);                // the stores have long drained by now
     PH_T(8);
     LbState S;
@@ -263,7 +266,7 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
         }
     }
     // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
-    lbfgs_round<float, STEP_NT>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
+    lbfgs_round<float, STEP_NT, REUSE>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
         PH_T(10);
         lb_direction_block<float, STEP_NT>(H, L.lbW, tid, GL);
         PH_T(11); PH_ADD(15, 1);
@@ -287,6 +290,7 @@ __device__ __forceinline__ size_t step_lds_dev() { return (sizeof(ClosureLds) + 
 
 // one closure round per launch (full mode): the objective reads the vertex pass's output for its
 // vertices; afterwards the pose operands of the NEXT trial point are published for the next pass.
+template <bool REUSE>
 __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                            StageWeights SW, LbOpts O, DevPose P, FitBuffers F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
                  min(L.opt.lbS.hist_len + 1, LB_HIST) + 3 + 4 * LB_PD};
     lb_gram_dma<STEP_NT>(H.gcol, GL.row0, GL.buf, GL.nrows, tid);
     PH_T(24);
-    const bool done = fit_round(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid, GL,
+    const bool done = fit_round<false, REUSE>(M, L, nviews, H, true, true, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, tid, GL,
                                 F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap);
     PH_T0();
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
@@ -340,12 +344,15 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 
 // the whole fit of one problem in a single launch (objective-vertices-only closure): the L-BFGS
 // history ring lives in LDS behind the closure workspace.
+// REMOTE: the launch carries VPoser decoder helpers behind the problems' workgroups (vposer_service.h); launches without
+// them run the instantiation that has no trace of the service.
+template <bool REMOTE, bool REUSE>
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
                                                                  int max_rounds, AsyncRing ring, int b_lo, int done_target,
                                                                  int pause_stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (M.vps.nsets && (int)blockIdx.x >= M.vps.nprob) {
+    if (REMOTE && (int)blockIdx.x >= M.vps.nprob) {
         // decoder helper of this launch (vposer_service.h): workgroups behind the problems' ones; set = blockIdx % nsets
         // like the problems it serves (dispatch is round-robin over the XCDs: same L2 when nsets == 8 - speed only)
         vposer_helper(M.vpt, M.vps, smem_raw, (int)blockIdx.x % M.vps.nsets, ((int)blockIdx.x - M.vps.nprob) / M.vps.nsets);
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     opts_in(L, SW, O, tid);
     __syncthreads();
     if (L.opt.lbS.status != 0) {
-        if (tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
+        if (REMOTE && tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
         return;
     }
     if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
+        done = fit_round<REMOTE, REUSE>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring.tag ? &ring : nullptr, b);
         if (done) break;                                  // block-uniform
@@ -397,14 +404,14 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     }
     if (!done)
         for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
-    if (L.vp_remote) {
+    if (REMOTE && L.vp_remote) {
         // goodbye to the helpers; the pose of the final point is decoded here (with the pre-activations the chained
         // rounds of a two-phase fit expect from their predecessor)
         __syncthreads();
         if (tid == 0) { vps_store(vps_request_slot(M.vps), 0.f, (L.vp_seq + 1u) << 2 | VPS_BYE); L.vp_remote = 0; }
         __syncthreads();
     }
-    pose_and_chain(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
+    pose_and_chain<true>(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
     if (paused) {
         // what the chained rounds' step kernel expects from its predecessor: the pose block of the trial point (+ the
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
-        lbfgs_round<double, 64>(S, V, H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
+        lbfgs_round<double, 64, false>(S, V, H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
             if (compact) lb_direction_compact<double, 64>(H, W, CW, lane);
             else lb_direction_block<double, 64>(H, W, lane);
         });
@@ -634,6 +641,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     M.nv_pad = M.ntiles * TILE_V;
     if (m->parents[0] >= 0) return fail(c, MVFIT_E_ARG, "parents[0] must be -1");
     if (persistent_lds() > 160 * 1024) return fail(c, MVFIT_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", persistent_lds());
+    static_assert(sizeof(VpHelperLds) <= sizeof(ClosureLds), "the decoder helpers share the fit kernel's dynamic LDS");
 
     // ---- blendshape basis, re-tiled in MFMA B-operand order: [tile][coord][group][lane][4] ----
     // element (tile T, coord k, group g, lane l, q): row p = 2*(4g+q) + (l>>5), vertex v = 32T + (l&31)
@@ -1000,8 +1008,12 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_persistent_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
     HIP_OK(c, hipHostMalloc(&c->h_done, 8));
     HIP_OK(c, hipDeviceSynchronize());
     return MVFIT_OK;
@@ -1322,7 +1334,7 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
             if (e == hipSuccess && c->F.sdf_adj)
                 e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
                                     c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs);
-            hipLaunchKernelGGL(fit_step_kernel, dim3(c->B), dim3(STEP_NT), step_gram_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+            hipLaunchKernelGGL(O.reuse_outer ? fit_step_kernel<true> : fit_step_kernel<false>, dim3(c->B), dim3(STEP_NT), step_gram_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                c->P, c->F);
         }
         hipError_t e2 = hipStreamEndCapture(cs, &g);
@@ -1426,7 +1438,9 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         grid = n + nsets * VPS_SLICES;
         c->vps_stats[0] += 1;
     }
-    hipLaunchKernelGGL(fit_persistent_kernel, dim3(grid), dim3(STEP_NT), persistent_lds(), c->stream, M,
+    auto kern = M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true> : fit_persistent_kernel<true, false>)
+                            : (O.reuse_outer ? fit_persistent_kernel<false, true> : fit_persistent_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds(), c->stream, M,
                        (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage);
     HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
@@ -1618,7 +1632,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                 if (!rc && any_sdf) rc = run_sdf_term(c, c->d_verts, c->F.sdf_gate, c->stream);
                 if (rc) return rc;
                 prof_begin(c, c->ev_step);
-                hipLaunchKernelGGL(fit_step_kernel, dim3(B), dim3(STEP_NT), step_gram_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
+                hipLaunchKernelGGL(O.reuse_outer ? fit_step_kernel<true> : fit_step_kernel<false>, dim3(B), dim3(STEP_NT), step_gram_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                    c->P, c->F);
                 prof_end(c, c->ev_step);
             }

@@ -145,7 +145,7 @@ struct VpHelperLds {
 struct VpTiles { const float4* tw2; const float4* tw3; const float* w1T; const float* b1; const float* b2; };
 
 // The helper's main loop; returns when every problem of its set has said goodbye (or nothing arrived for 0.2 s).
-__device__ void vposer_helper(const VpTiles& T, const VpService& V, unsigned char* smem, int s, int h) {
+__device__ __attribute__((noinline)) void vposer_helper(const VpTiles& T, const VpService& V, unsigned char* smem, int s, int h) {
     VpHelperLds& S = *reinterpret_cast<VpHelperLds*>(smem);
     const int tid = threadIdx.x, w = tid >> 6;
     int l = tid & 63;

@@ -2,12 +2,12 @@
 # Run on the MI355X box (gpurun): kernel stats of the bench command + PMC traffic of the vertex pass at 32 / 128
 # problems.  Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>/...  (copy the summaries into profiles/)
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log   # (event stamps of the in-fit launches are distorted under the profiler: use the csv for durations, a plain run for the JSON line)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants --no-pmc > $OUT/bench_under_rocprof.json 2> $OUT/stats.log   # (event stamps of the in-fit launches are distorted under the profiler: use the csv for durations, a plain run for the JSON line)
 for B in 32 128; do
   for CN in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $CN --kernel-trace --output-format csv -d $OUT/pmc_b${B}_$CN -o p -- python $R/tools/pmc_vertex_pass.py drive $B 40 > /dev/null 2> $OUT/pmc_b${B}_$CN.log
