@@ -86,7 +86,7 @@ def pmc_value(key, kernel_substr, field='traffic_bytes', table=None):
     return None
 
 
-def measure_pmc(B, launches=40, timeout_s=150):
+def measure_pmc(B, launches=40, timeout_s=90):
     """HBM-side traffic and matrix-pipe busy cycles of the vertex pass at B problems, measured NOW with rocprofv3 PMC
     counters on this GPU: separate passes for FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES (the guide's
     recipe: the two size counters do not fit one pass), `--kernel-trace` only, on tools/pmc_vertex_pass.py's driver.
