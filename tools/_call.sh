@@ -1,39 +1,22 @@
 set -u
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3g
+O=gpurun_out/r3j
 rm -rf $O; mkdir -p $O
-R=$GRAFT_REPO_ROOT
-( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -o s -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants --no-pmc > $R/$O/bench_under_rocprof.json 2> $R/$O/stats.log )
-find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_vp -o s -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-pmc --prior vposer > $R/$O/bench_vposer_under_rocprof.json 2> $R/$O/stats_vp.log )
-find $O/stats_vp -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_vposer.csv \;
-rm -rf $O/stats $O/stats_vp
-timeout 900 python bench.py > $O/bench.json.log 2> $O/bench.err
+timeout 900 python -m pytest tests/test_gpu_async.py tests/test_gpu_trajectory.py tests/test_gpu_lbfgs.py tests/test_gpu_large_batch.py tests/test_gpu_closure.py -q > $O/tests.log 2>&1; tail -2 $O/tests.log
 B="timeout 400 python bench.py --no-cpu-baseline --no-pmc --no-variants"
-$B --config configs2 > $O/bench_sdf.json.log 2>&1
-$B --config configs3 > $O/bench_configs3.json.log 2>&1
-$B --config configs4 > $O/bench_configs4.json.log 2>&1
-$B --config demo > $O/bench_demo.json.log 2>&1
-MVFIT_VP_HELPERS=0 $B --config demo > $O/bench_demo_helpers_off.json.log 2>&1
-$B --prior vposer > $O/bench_vposer.json.log 2>&1
-MVFIT_VP_HELPERS=0 $B --prior vposer > $O/bench_vposer_helpers_off.json.log 2>&1
-$B --prior vposer --sparse > $O/bench_vposer_sparse.json.log 2>&1
-$B --sparse > $O/bench_sparse.json.log 2>&1
-$B --frames 128 > $O/bench_b128.json.log 2>&1
-$B --frames 256 > $O/bench_b256.json.log 2>&1
-$B --config configs3 --prior vposer > $O/bench_configs3_vposer.json.log 2>&1
-MVFIT_ROUND_MODE=serial $B > $O/bench_chained.json.log 2>&1
-$B --gpus 2 --dist-backend gloo --single-device > $O/bench_2rank_gloo_single_device.json.log 2>&1
-timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-variants --config configs2 --sdf-faces all --steps 1 --warmup 0 > $O/bench_sdf_all_faces.json.log 2>&1
-PYTHONPATH=. timeout 300 python tests/report_vertex_pass.py > $O/report_vertex_pass.log 2>&1
+for rep in 1 2 3; do
+  $B > $O/default_$rep.log 2>&1
+  $B --sparse > $O/sparse_$rep.log 2>&1
+done
+$B --prior gmm > $O/gmm.log 2>&1
+$B --config configs3 > $O/configs3.log 2>&1
 python - <<'PY'
 import json, glob
-for fn in sorted(glob.glob('gpurun_out/r3g/bench*.log')):
+for fn in sorted(glob.glob('gpurun_out/r3j/*.log')):
     try:
         l=[x for x in open(fn) if x.startswith('{')]
         d=json.loads(l[-1]); r=d.get('roofline') or {}
-        print(fn.split('/')[-1], d['value'], d['ms_per_step'], d['closure_rounds_per_fit'], d.get('vertex_passes_lost_in_timed_fits'), d.get('decoder_helpers_last_fit'), r.get('avg_launch_us'), r.get('frac'), r.get('traffic'), (d.get('cpu_baseline') or {}).get('value'))
+        print(fn.split('/')[-1], d['value'], d['ms_per_step'], d['closure_rounds_per_fit'], r.get('avg_launch_us'))
     except Exception as e:
-        print(fn, 'failed', e); print(open(fn).read()[-800:])
+        pass
 PY
-head -6 $O/kernel_stats.csv | cut -c1-160; head -6 $O/kernel_stats_vposer.csv | cut -c1-160; tail -12 $O/report_vertex_pass.log
