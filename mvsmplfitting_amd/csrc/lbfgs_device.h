@@ -832,14 +832,18 @@ __device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHi
                                             double f_new, const T* gnew, T* xt, int tid, double* stage_final,
                                             DirFn&& direction) {
     if constexpr (!REUSE) {
-        if (tid < 64) {
-            const int need = lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
-            if (tid == 0) W.need_dir = need;
-        }
-        __syncthreads();
-        if (W.need_dir) {                                  // block-uniform
+        // advance; if it asks for a direction: direction, advance again - written as a two-trip loop that is NOT unrolled,
+        // so that the state machine is in the kernel once (~10 KB less code per round to stream through the instruction cache)
+#pragma nounroll
+        for (int trip = 0; trip < 2; ++trip) {
+            if (tid < 64) {
+                const int need = lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+                if (tid == 0 && trip == 0) W.need_dir = need;
+            }
+            if (trip == 1) break;
+            __syncthreads();
+            if (!W.need_dir) break;                        // block-uniform
             direction();
-            if (tid < 64) lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
         }
         return;
     }

@@ -10,6 +10,9 @@ for rep in 1 2 3; do
 done
 $B --prior gmm > $O/gmm.log 2>&1
 $B --config configs3 > $O/configs3.log 2>&1
+MVFIT_ROUND_MODE=serial $B > $O/chained.log 2>&1
+$B --prior vposer > $O/vposer.log 2>&1
+$B --config configs2 > $O/sdf.log 2>&1
 python - <<'PY'
 import json, glob
 for fn in sorted(glob.glob('gpurun_out/r3j/*.log')):
