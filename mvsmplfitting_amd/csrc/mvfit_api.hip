@@ -1444,6 +1444,7 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         M.vps.stat = reinterpret_cast<unsigned*>(c->vps_mem + c->vps_words);
         M.vps.nsets = nsets;
         M.vps.nprob = n;
+        { const char* f = getenv("MVFIT_VP_FAULT"); M.vps.fault = f && atoi(f) != 0; }      // test hook: helpers that never answer
         grid = n + nsets * VPS_SLICES;
         c->vps_stats[0] += 1;
     }

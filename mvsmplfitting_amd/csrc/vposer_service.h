@@ -45,6 +45,7 @@ struct VpService {
     unsigned long long* resp;           // [nsets][VPS_PMAX][VPS_SLICES][VPS_GRAN]
     unsigned* stat;                     // [0] answers that timed out (the problem then decodes locally), [1] helpers that gave up
     int nsets, nprob;                   // nsets == 0: no service in this launch
+    int fault, pad_;                    // test hook (MVFIT_VP_FAULT=1): the helpers leave at once - every problem must time out and decode locally
 };
 
 __device__ __forceinline__ unsigned long long vps_pack(float v, unsigned tag) {
@@ -146,6 +147,7 @@ struct VpTiles { const float4* tw2; const float4* tw3; const float* w1T; const f
 
 // The helper's main loop; returns when every problem of its set has said goodbye (or nothing arrived for 0.2 s).
 __device__ __attribute__((noinline)) void vposer_helper(const VpTiles& T, const VpService& V, unsigned char* smem, int s, int h) {
+    if (V.fault) { if (threadIdx.x == 0) atomicAdd(V.stat + 1, 1u); return; }
     VpHelperLds& S = *reinterpret_cast<VpHelperLds*>(smem);
     const int tid = threadIdx.x, w = tid >> 6;
     int l = tid & 63;

@@ -87,3 +87,22 @@ def test_a_problems_fit_does_not_depend_on_the_batch_around_it():
         assert np.array_equal(small['final'], big['final'][lo:lo + 3])
         assert np.array_equal(small['ncl'], big['ncl'][lo:lo + 3])
     eng.close()
+
+
+def test_a_fit_whose_helpers_never_answer_falls_back_to_the_local_decoder():
+    """Fault injection (MVFIT_VP_FAULT=1: the helper workgroups leave at once): every problem's first request times out
+    (50 ms), the problem decodes in its own workgroup from then on - the fit completes, the counters say what happened,
+    and the result is the helpers-off fit bit for bit."""
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    B = 5
+    x0 = _problems(eng, B)[0]
+    flags = _lib.F_VPOSER | _lib.F_SPARSE_VERTS
+    off = _fit(eng, x0, flags, False)
+    os.environ['MVFIT_VP_FAULT'] = '1'
+    try:
+        bad = _fit(eng, x0, flags, True)
+    finally:
+        del os.environ['MVFIT_VP_FAULT']
+    assert bad['stats']['launches'] == 1 and bad['stats']['answers_timed_out'] == B and bad['stats']['helpers_gave_up'] == 5 * 8, bad['stats']
+    assert np.array_equal(bad['x'], off['x']) and np.array_equal(bad['final'], off['final']) and np.array_equal(bad['ncl'], off['ncl'])
+    eng.close()
