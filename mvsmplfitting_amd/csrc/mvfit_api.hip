@@ -1021,6 +1021,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                           reinterpret_cast<const void*>(fit_persistent_kernel<false, false, false>),
                           reinterpret_cast<const void*>(fit_persistent_kernel<true, false, false>),
                           reinterpret_cast<const void*>(fit_persistent_kernel<false, true, false>),
+                          reinterpret_cast<const void*>(fit_persistent_kernel<false, true, true>),
                           reinterpret_cast<const void*>(fit_persistent_kernel<true, true, false>)})
         HIP_OK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
     HIP_OK(c, hipHostMalloc(&c->h_done, 8));
@@ -1448,9 +1449,9 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         grid = n + nsets * VPS_SLICES;
         c->vps_stats[0] += 1;
     }
-    const bool lean = !O.reuse_outer && !(SW.w[0].flags & (MVFIT_F_VPOSER | MVFIT_F_PRIOR_GMM | MVFIT_F_USE_3D));    // (flags are the same in all stages)
+    const bool lean = !(SW.w[0].flags & (MVFIT_F_VPOSER | MVFIT_F_PRIOR_GMM | MVFIT_F_USE_3D));    // (flags are the same in all stages)
     auto kern = M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true, false> : fit_persistent_kernel<true, false, false>)
-                : O.reuse_outer ? fit_persistent_kernel<false, true, false>
+                : O.reuse_outer ? (lean ? fit_persistent_kernel<false, true, true> : fit_persistent_kernel<false, true, false>)
                 : lean ? fit_persistent_kernel<false, false, true> : fit_persistent_kernel<false, false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds(), c->stream, M,
                        (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage);
