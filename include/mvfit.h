@@ -36,6 +36,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libmvfit.so is built with -fvisibility=hidden: the functions declared in this header are its only exports */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MVFIT_NUM_JOINTS 24
 #define MVFIT_NUM_BETAS 10
@@ -289,6 +293,9 @@ int mvfit_lbfgs_kat(int device, int kind, int D, const int32_t* segs, int nseg,
                     const mvfit_lbfgs_opts* opts, double* x_inout, double* trace, int max_trace,
                     int* n_closure, double* final_loss);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 """GPU: the SDF voxelisation op (mvfit_sdf) against the NumPy restatement of the reference's CUDA kernel
-(oracle/sdf_np.py; parity unpinned - the reference op cannot run here).  Inside/outside parity
+(oracle/sdf_np.py, itself bit-exact against the reference kernel source compiled for the host: tests/test_sdf_ref.py).  Inside/outside parity
 flips are discontinuous in the inputs, so agreement is asserted as: identical classification
 and |delta| <= 1e-5 on >= 99.5 % of the voxels."""
 import numpy as np
