@@ -32,6 +32,7 @@ hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t strea
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
 size_t sdf_work_bytes(int B, int nv);
+size_t sdf_ticket_offset(int B, int nv);
 hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
                               hipStream_t stream);
 hipError_t launch_umeyama(const double* src, const double* dst, int B, int npts, int estimate_scale, double* rot, double* rvec,
@@ -1182,7 +1183,8 @@ static int ensure_sdf_buffers(mvfit_ctx* c) {
     if (c->d_sdf_adj) return MVFIT_OK;
     HIP_OK(c, hipMalloc(&c->d_sdf_box, (size_t)c->B * sizeof(SdfBox)));
     HIP_OK(c, hipMalloc(&c->d_sdf_samp, (size_t)c->B * c->nv * sizeof(float4)));
-    HIP_OK(c, hipMalloc(&c->d_sdf_entries, sdf_work_bytes(c->B, c->nv)));      // entry lists + slice partials + heads
+    HIP_OK(c, hipMalloc(&c->d_sdf_entries, sdf_work_bytes(c->B, c->nv)));      // entry lists + slice partials + heads + tickets
+    HIP_OK(c, hipMemset(reinterpret_cast<unsigned char*>(c->d_sdf_entries) + sdf_ticket_offset(c->B, c->nv), 0, (size_t)c->B * sizeof(int)));
     HIP_OK(c, hipMalloc(&c->d_sdf_adj, (size_t)c->B * sizeof(SdfAdj)));
     return MVFIT_OK;
 }

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
 __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, DevPose P, const int* __restrict__ gate,
                                                                   const SdfBox* __restrict__ box,
                                                                   const SdfEntry* __restrict__ entries,
-                                                                  const SdfChunk* __restrict__ chunks, SdfAdj* __restrict__ part) {
+                                                                  const SdfChunk* __restrict__ chunks, SdfAdj* __restrict__ part,
+                                                                  int* __restrict__ tickets, SdfAdj* __restrict__ out) {
     __shared__ int sh_pref[SDF_NC + 1];
     __shared__ float sh_box[4];                                      // box adjoint: d S / d centre (3), d S / d scale
     __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
@@ -433,37 +434,44 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
             }
         }
     }
+    // Slice partial out with write-through stores, then the slice takes a ticket of its problem: the slice that arrives
+    // LAST adds the eight partials in slice order (deterministic whoever it is) - the former third kernel, without its
+    // launch.  Hand-off as the guide prescribes for other-CU data: agent-scope (sc1) stores, this wave's stores drained
+    // before the workgroup barrier in front of the ticket, agent-scope loads on the reading side.
     SdfAdj& O = part[(size_t)b * SDF_NS + y];
-    if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
-    if (tid < 3) O.gtau[tid] = gtv;
-}
-
-// Kernel 3: slice partials -> the problem's adjoint, in slice order.
-__global__ __launch_bounds__(SDF_ADJ_NT) void sdf_reduce_kernel(const int* __restrict__ gate, const SdfChunk* __restrict__ chunks,
-                                                                const SdfAdj* __restrict__ part, SdfAdj* __restrict__ out) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (gate && !gate[b]) return;
+    __hip_atomic_store(tid < KROWS ? &O.gcoef[tid] : &O.gA[tid - KROWS], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 3) __hip_atomic_store(&O.gtau[tid], gtv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int sh_last;
+    __syncthreads();
+    if (tid == 0) sh_last = __hip_atomic_fetch_add(tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SDF_NS - 1;
+    __syncthreads();
+    if (!sh_last) return;                                            // uniform
     const SdfAdj* p = part + (size_t)b * SDF_NS;
-    float acc = 0.f, gtv = 0.f;
+    float racc = 0.f, rgt = 0.f;
 #pragma unroll
-    for (int y = 0; y < SDF_NS; ++y) {
-        acc += tid < KROWS ? p[y].gcoef[tid] : p[y].gA[tid - KROWS];
-        if (tid < 3) gtv += p[y].gtau[tid];
+    for (int yy = 0; yy < SDF_NS; ++yy) {
+        racc += __hip_atomic_load(tid < KROWS ? &p[yy].gcoef[tid] : &p[yy].gA[tid - KROWS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 3) rgt += __hip_atomic_load(&p[yy].gtau[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    SdfAdj& O = out[b];
-    if (tid < KROWS) O.gcoef[tid] = acc; else O.gA[tid - KROWS] = acc;
-    if (tid < 3) O.gtau[tid] = gtv;
+    SdfAdj& R = out[b];
+    if (tid < KROWS) R.gcoef[tid] = racc; else R.gA[tid - KROWS] = racc;
+    if (tid < 3) R.gtau[tid] = rgt;
     if (tid == 0) {
         double S = 0.0;
         for (int c = 0; c < SDF_NC; ++c) S += chunks[(size_t)b * SDF_NC + c].S;
-        O.S = (float)S;
+        R.S = (float)S;
+        __hip_atomic_store(tickets + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next round (a launch boundary away)
     }
 }
 
-// work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B][SDF_NC] SdfChunk
+// work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B][SDF_NC] SdfChunk | [B] tickets
+// (the tickets must be zero before the first round: mvfit_api.hip clears them when it allocates the area; every round
+// leaves them at zero)
 static size_t sdf_part_offset(int B, int nv) { return ((size_t)B * nv * sizeof(SdfEntry) + 255) & ~(size_t)255; }
 static size_t sdf_chunk_offset(int B, int nv) { return sdf_part_offset(B, nv) + (size_t)B * SDF_NS * sizeof(SdfAdj); }
-size_t sdf_work_bytes(int B, int nv) { return sdf_chunk_offset(B, nv) + (size_t)B * SDF_NC * sizeof(SdfChunk); }
+size_t sdf_ticket_offset(int B, int nv) { return (sdf_chunk_offset(B, nv) + (size_t)B * SDF_NC * sizeof(SdfChunk) + 255) & ~(size_t)255; }
+size_t sdf_work_bytes(int B, int nv) { return sdf_ticket_offset(B, nv) + (size_t)B * sizeof(int); }
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream) {
@@ -471,6 +479,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
     unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
     SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
     SdfChunk* chunks = reinterpret_cast<SdfChunk*>(wk + sdf_chunk_offset(B, M.nv));
+    int* tickets = reinterpret_cast<int*>(wk + sdf_ticket_offset(B, M.nv));
     if (M.nv > SDF_NC * 8 * SDF_NIT * 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box);
     hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
@@ -478,8 +487,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
     hipLaunchKernelGGL(sdf_entries_kernel, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
                        (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), chunks);
     hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
-                       reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part);
-    hipLaunchKernelGGL(sdf_reduce_kernel, dim3(B), dim3(SDF_ADJ_NT), 0, stream, gate, (const SdfChunk*)chunks, (const SdfAdj*)part, adj);
+                       reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part, tickets, adj);
     return hipGetLastError();
 }
 
