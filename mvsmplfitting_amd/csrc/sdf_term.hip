@@ -7,7 +7,7 @@
 //   adjoint of S = sum_v phi_v w.r.t. the pose operands of the vertex pass
 //                                      ->  sdf_entries_kernel   8 workgroups per problem: S, box-adjoint sums, entry lists
 //                                          sdf_pullback_kernel  8 workgroups per problem: entries through skinning / basis
-//                                          sdf_reduce_kernel    slice partials in slice order
+//                                          (slice partials added in slice order by the problem's last-arriving pull-back workgroup)
 //
 // The reference voxelises G^3 = 2 M voxels per closure and then samples 6890 x 8 of them; phi is a pure
 // function of the voxel index, so the sample kernel evaluates exactly those <= 55 k voxels on the fly with the
