@@ -179,8 +179,10 @@ int mvfit_vertices(mvfit_ctx* ctx, const float* params /*[B,MVFIT_D] dev*/, uint
  *   n_closure[B], n_iter[B] dev int32 (closure evaluations / L-BFGS iterations spent), may be NULL.
  * The vertices of the trial points (the reference's return_verts=True) are computed per closure round into an internal
  * buffer and are NOT an output of this call - mvfit_vertices(params) gives the vertices of the result.  In the
- * asynchronous mode (default without the SDF term) those per-round passes run beside the optimiser and nothing of the
- * result depends on them; mvfit_fit_stats reports how many ran and whether any was lost (expected: none). */
+ * asynchronous mode (the default; with the SDF term: for the stages whose coll_loss_weight is 0) those per-round passes
+ * run beside the optimiser and nothing of the result depends on them; mvfit_fit_stats reports how many ran and whether
+ * any was lost (none: the operand ring has back-pressure).  Any number of problems: batches beyond what is resident at
+ * once are fitted in sub-batches, a problem's result does not depend on the slicing. */
 int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lbfgs_opts* opts,
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
 
