@@ -1,8 +1,8 @@
 set -u
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3s
-rm -rf $O; mkdir -p $O
-for T in t1 t2 full; do
-  if [ $T = full ]; then L=$PWD/mvsmplfitting_amd/libmvfit.so; else L=$PWD/mvsmplfitting_amd/libmvfit_$T.so; fi
-  echo $T; MVFIT_LIBRARY=$L PYTHONPATH=. timeout 300 python tests/report_vertex_pass.py > $O/vp_$T.log 2>&1; grep "^B " $O/vp_$T.log
-done
+O=gpurun_out/r3u; rm -rf $O; mkdir -p $O
+T0=$(date +%s.%N); python bench.py --gpus 1 --steps 20 --warmup 2 > $O/bench_driver_cmd.log 2> $O/bench_driver_cmd.err; T1=$(date +%s.%N); echo "wall $(echo "$T1 - $T0" | bc) s"; grep -c "^{" $O/bench_driver_cmd.log; wc -l $O/bench_driver_cmd.log; python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r3u/bench_driver_cmd.log') if x.startswith('{')]
+d=json.loads(l[-1]); print(d['value'], d['ms_per_step'], d['steps'], d['roofline']['frac'], d['roofline']['traffic_source'][:60], d['cpu_baseline']['value'])
+PY
