@@ -1,9 +1,8 @@
+# Scratch driver for `gpurun -- 'bash tools/_call.sh'`: the standard validation sequence (GPU suite, smoke, default bench).
 set -u
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3s
-rm -rf $O; mkdir -p $O
-export MVFIT_VP_PIPE14=1
-timeout 900 python -m pytest tests/test_gpu_large_batch.py tests/test_gpu_closure.py tests/test_gpu_async.py -q > $O/tests.log 2>&1; grep -E "passed|failed|Error|assert " $O/tests.log | tail -6
-for r in 1 2; do PYTHONPATH=. timeout 300 python tests/report_vertex_pass.py > $O/vp_$r.log 2>&1; grep "^B " $O/vp_$r.log; done
-unset MVFIT_VP_PIPE14
-PYTHONPATH=. timeout 300 python tests/report_vertex_pass.py > $O/vp_8.log 2>&1; grep "^B " $O/vp_8.log
+O=gpurun_out/validate; rm -rf $O; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; echo "rc=$?" >> $O/gpu_tests.log
+grep -E "passed|failed|rc=" $O/gpu_tests.log | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+timeout 900 python bench.py > $O/bench.json.log 2> $O/bench.err; grep -o '"value": [0-9.]*' $O/bench.json.log | head -1
