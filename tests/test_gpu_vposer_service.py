@@ -89,6 +89,24 @@ def test_a_problems_fit_does_not_depend_on_the_batch_around_it():
     eng.close()
 
 
+@pytest.mark.parametrize('B,sparse', [(150, True), (96, False)])
+def test_helpers_serving_many_problems_each(B, sparse):
+    """One launch with 8 sets: 150 problems objective-only = 19 per helper (every polling wave watches three slots), 96
+    asynchronous = 12 per helper.  No time-out, and a sample of the problems equals the same problems fitted alone."""
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    flags = _lib.F_VPOSER | (_lib.F_SPARSE_VERTS if sparse else 0)
+    x0, cams, gt, conf = _problems(eng, B, seed=11)
+    big = _fit(eng, x0, flags, True)
+    assert big['stats'] == dict(launches=1, answers_timed_out=0, helpers_gave_up=0), big['stats']
+    assert np.all(np.isfinite(big['final']))
+    for lo in (0, 70, B - 2):
+        eng.set_problems(cams, gt[lo:lo + 2], conf[lo:lo + 2])
+        small = _fit(eng, x0[lo:lo + 2], flags, True)
+        assert np.array_equal(small['x'], big['x'][lo:lo + 2]), lo
+        assert np.array_equal(small['final'], big['final'][lo:lo + 2])
+    eng.close()
+
+
 def test_a_fit_whose_helpers_never_answer_falls_back_to_the_local_decoder():
     """Fault injection (MVFIT_VP_FAULT=1: the helper workgroups leave at once): every problem's first request times out
     (50 ms), the problem decodes in its own workgroup from then on - the fit completes, the counters say what happened,
