@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from mvsmplfitting_amd import _lib
+from mvsmplfitting_amd import synthetic as syn
 from oracle import closure_np as cn
 from oracle import lbfgs_np as ln
 from oracle import sdf_term_np as st
@@ -185,3 +186,42 @@ def test_fit_with_sdf_term_last_stage():
             n_cl += opt.func_evals
         assert final[b] <= 1.25 * f_last + 1.0, (final[b], f_last)
         assert 0.25 * n_cl < ncl[b] < 4 * n_cl, (ncl[b], n_cl)
+
+
+@pytest.mark.parametrize('use_vp', [False, True])
+def test_two_phase_fit_hands_over_to_the_chained_rounds(use_vp):
+    """mvfit_fit with the term in the last two stages runs the leading stages as an asynchronous single-launch fit that
+    pauses at the stage boundary (with VPoser: decoder helpers in that phase, the in-workgroup decoder and its
+    pre-activations handed to the chained rounds) - MVFIT_SDF_ONE_PHASE=1 runs all stages chained.  Both must end on a
+    finite loss that IS the objective at the returned parameters; the two structures differ in the arithmetic of the
+    leading stages (objective vertices evaluated in the optimiser kernel vs read from the vertex pass: 2e-6), so the end
+    points agree only as far as the piecewise-smooth objective lets two roundings agree (cf. the test above)."""
+    g = dict(np.load(os.path.join(GOLD, 'fit_vposer.npz' if use_vp else 'fit_l2.npz')))
+    model = body_model()
+    cams = (g['cam_R'], g['cam_t'], g['cam_f'], g['cam_c'])
+    B = 2
+    eng = make_engine(model, syn.make_vposer_decoder() if use_vp else None)
+    eng.set_problems(cams, g['gt_xy'][:B], g['conf'][:B])
+    eng.set_sdf(model['faces'], num_faces=32, grid_size=16)
+    x0 = np.stack([to118(g['x0'][b], use_vp) for b in range(B)]).astype(np.float32)
+    stages = eng_stage_weights(1536.0, flags=_lib.F_VPOSER if use_vp else 0)
+    for s_, cw in enumerate([0.0, 0.0, 5.0, 20.0]):
+        stages[s_]['coll_loss_weight'] = cw
+    out = {}
+    for mode in ('two_phase', 'one_phase'):
+        if mode == 'one_phase':
+            os.environ['MVFIT_SDF_ONE_PHASE'] = '1'
+        try:
+            xf, st = eng.fit(x0, stages)
+            ds = eng.decoder_stats()
+        finally:
+            os.environ.pop('MVFIT_SDF_ONE_PHASE', None)
+        fk = st['final_loss'].cpu().numpy().astype(np.float64)
+        chk = eng.closure(xf, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
+        assert np.all(np.isfinite(fk)) and np.all(chk <= fk * (1 + 1e-3) + 1e-3), (mode, fk, chk)
+        assert ds['answers_timed_out'] == 0 and ds['helpers_gave_up'] == 0
+        assert ds['launches'] == (1 if (use_vp and mode == 'two_phase') else 0), (mode, ds)
+        assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0
+        out[mode] = fk
+    assert np.all(out['two_phase'] <= 2.0 * out['one_phase'] + 1.0) and np.all(out['one_phase'] <= 2.0 * out['two_phase'] + 1.0), out
+    eng.close()
