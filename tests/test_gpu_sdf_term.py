@@ -225,3 +225,24 @@ def test_two_phase_fit_hands_over_to_the_chained_rounds(use_vp):
         out[mode] = fk
     assert np.all(out['two_phase'] <= 2.0 * out['one_phase'] + 1.0) and np.all(out['one_phase'] <= 2.0 * out['two_phase'] + 1.0), out
     eng.close()
+
+
+def test_sdf_adjoint_is_the_same_bits_in_every_run():
+    """The slice partials of the pull-back are added by whichever of a problem's eight workgroups arrives last - in slice
+    order all the same: loss and gradient of 12 repeated closure calls are bit-identical (8 problems x 8 slices racing)."""
+    cfg, g, model, vpw, gmm, wts, cams = load_case('l2_s3_v6')
+    nprob = min(8, g['gt_xy'].shape[0])
+    eng = make_engine(model, vpw, gmm)
+    eng.set_problems(cams, g['gt_xy'][:nprob], g['conf'][:nprob])
+    eng.set_sdf(model['faces'], num_faces=64, grid_size=32)
+    x = np.stack([to118(g['x'][b], False) for b in range(nprob)]).astype(np.float32)
+    w = dict(wts, coll_loss_weight=20.0, flags=0)
+    ref = None
+    for _ in range(12):
+        out = eng.closure(x, w, want_grad=True)
+        cur = (out['loss'].cpu().numpy().copy(), out['grad'].cpu().numpy().copy())
+        if ref is None:
+            ref = cur
+            assert np.abs(cur[1]).max() > 0
+        assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+    eng.close()
