@@ -89,16 +89,18 @@ def test_a_problems_fit_does_not_depend_on_the_batch_around_it():
     eng.close()
 
 
-@pytest.mark.parametrize('B,sparse', [(150, True), (96, False)])
-def test_helpers_serving_many_problems_each(B, sparse):
+@pytest.mark.parametrize('B,sparse,launches', [(150, True, 1), (96, False, 1), (170, True, 2), (100, False, 2)])
+def test_helpers_serving_many_problems_each(B, sparse, launches):
     """One launch with 8 sets: 150 problems objective-only = 19 per helper (every polling wave watches three slots), 96
-    asynchronous = 12 per helper.  No time-out, and a sample of the problems equals the same problems fitted alone."""
+    asynchronous = 12 per helper; 170 / 100 problems = two sub-batches (all workgroups of a launch must be resident).
+    No time-out, and a sample of the problems equals the same problems fitted alone."""
     eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
     flags = _lib.F_VPOSER | (_lib.F_SPARSE_VERTS if sparse else 0)
     x0, cams, gt, conf = _problems(eng, B, seed=11)
     big = _fit(eng, x0, flags, True)
-    assert big['stats'] == dict(launches=1, answers_timed_out=0, helpers_gave_up=0), big['stats']
+    assert big['stats'] == dict(launches=launches, answers_timed_out=0, helpers_gave_up=0), big['stats']
     assert np.all(np.isfinite(big['final']))
+    assert big['passes']['missed'] == 0 and big['passes']['timed_out'] == 0
     for lo in (0, 70, B - 2):
         eng.set_problems(cams, gt[lo:lo + 2], conf[lo:lo + 2])
         small = _fit(eng, x0[lo:lo + 2], flags, True)
