@@ -158,7 +158,11 @@ int mvfit_set_joints3d(mvfit_ctx* ctx, const float* gt3d, const float* conf3d);
 /* One closure evaluation for all B problems: fitting_func(backward=True)
  * (code/utils/fitting.py:162-203) = SMPL.forward + SMPLifyLoss.forward + backward.
  *   params[B,MVFIT_D] dev ; loss[B] dev ; grad[B,MVFIT_D] dev or NULL (forward only) ;
- *   verts[B,Nv,3] dev or NULL ; joints[B,17,3] dev or NULL. */
+ *   verts[B,Nv,3] dev or NULL ; joints[B,17,3] dev or NULL.
+ * Environment, read per call: MVFIT_CLOSURE_VP_HELPERS=1 (with MVFIT_F_VPOSER, no SDF term, B <= 160) decodes the body
+ * pose on helper workgroups of the closure's own launch - the decoder arithmetic of the single-launch fits (another
+ * summation order than the in-workgroup decoder, ~1e-7 relative) - so that the parity tests can hold the shipping decoder
+ * against the closure-level goldens (tests/test_gpu_closure_helpers.py); mvfit_decoder_stats reports that launch. */
 int mvfit_closure(mvfit_ctx* ctx, const mvfit_weights* w, const float* params,
                   float* loss, float* grad, float* verts, float* joints);
 
@@ -247,6 +251,17 @@ int mvfit_sdf_term_read(mvfit_ctx* ctx, float* samples, float* sums);
 int mvfit_triangulate(mvfit_ctx* ctx, int B, int V, const float* keypoints, const double* intris, const double* extris,
                       double* joints3d);
 
+/* Per-frame initial guess, stage 1 for single-view input (code/utils/init_guess.py:54-74): the depth guess that replaces
+ * the triangulation when a frame has ONE view - the model's rest-pose keypoints pushed along the camera's z axis by
+ * est_d = fx * (torso height in camera space) / (torso height in the image) and mapped back with inv(extri); the
+ * reference's arithmetic is kept (the left shoulder-hip pair taken twice in the 2-D height, over (u, v, confidence)
+ * rows in float32; everything else float64).  Batched over B frames seen by the same camera.
+ *   rest_joints[17,3] float64 dev (the 17 keypoints of mvfit_vertices at zero pose / shape / translation and the start
+ *   scale, init_guess.py:31-52) ; extri[4,4], intri[3,3] float64 dev ; keypoints[B,17,3] float32 dev (u, v, confidence)
+ *   -> joints3d[B,17,3] float64 dev: what mvfit_umeyama takes as dst. */
+int mvfit_depth_guess(mvfit_ctx* ctx, int B, const double* rest_joints, const double* extri, const double* intri,
+                      const float* keypoints, double* joints3d);
+
 /* Per-frame initial guess, stage 2 (code/utils/init_guess.py:95-106): similarity alignment src -> dst by the
  * reference's umeyama (code/utils/umeyama.py:16-109, incl. its full-rank formula U diag(d) Vh^T and the two-candidate
  * choice with the translation of the second candidate) and cv2.Rodrigues of the chosen rotation; batched over B frames
@@ -254,7 +269,8 @@ int mvfit_triangulate(mvfit_ctx* ctx, int B, int V, const float* keypoints, cons
  *   src[npts,3] dev, dst[B,npts,3] dev (npts = 4: the torso joints 5, 6, 11, 12 with use_torso, or 17) ->
  *   rot[B,3,3], rvec[B,3] (the model's global_orient), trans[B,3], scale[B] dev.
  * The signs of the singular-vector pairs - which the reference's formula is sensitive to and LAPACK chooses for it -
- * are those of the device's Jacobi SVD. */
+ * are LAPACK's own: the device SVD walks dgesdd's path for a 3 x 3 matrix (dgebd2, dbdsqr, dormbr; csrc/lapack_svd3.h)
+ * and returns numpy's pairs, so rot / trans / scale equal the reference's (tests/golden/init_guess_ref.npz). */
 int mvfit_umeyama(mvfit_ctx* ctx, int B, int npts, const double* src, const double* dst, int estimate_scale,
                   double* rot, double* rvec, double* trans, double* scale);
 

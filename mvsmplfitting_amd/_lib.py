@@ -53,7 +53,7 @@ class LbfgsOpts(C.Structure):
 
 
 EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',
-           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex',
+           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_depth_guess', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex',
            'mvfit_lbfgs_kat']
 
 
@@ -101,6 +101,8 @@ def load():
     lib.mvfit_sdf_term_read.restype = C.c_int
     lib.mvfit_triangulate.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.mvfit_triangulate.restype = C.c_int
+    lib.mvfit_depth_guess.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.mvfit_depth_guess.restype = C.c_int
     lib.mvfit_umeyama.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.mvfit_umeyama.restype = C.c_int
     lib.mvfit_project_points.argtypes = [vp, vp, C.c_int, vp]

@@ -155,8 +155,17 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
             x0 = initial_params(guess, use_vposer, fixed_shape=fix_shape)
 
             def stages_for(with_3d):
-                return user_stages if user_stages is not None else \
-                    stage_weights(float(image_height), flags=flags | (_lib.F_USE_3D if with_3d else 0))
+                if user_stages is None:
+                    return stage_weights(float(image_height), flags=flags | (_lib.F_USE_3D if with_3d else 0))
+                # caller's stage list: the 3-D term follows the group being fitted (annotated frames carry it, the others
+                # must not run it against absent targets), whatever the caller's flag words say
+                out = []
+                for st_ in user_stages:
+                    st_ = dict(st_)
+                    f_ = int(st_.get('flags', 0))
+                    st_['flags'] = (f_ | _lib.F_USE_3D) if with_3d else (f_ & ~_lib.F_USE_3D)
+                    out.append(st_)
+                return out
             if is_seq:
                 if has.all():
                     eng.set_joints3d(ann[:, :, :3], c3)

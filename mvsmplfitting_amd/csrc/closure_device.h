@@ -162,7 +162,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     if (x_g && tid < DPAD) L.opt.x[tid] = xv;
     if (vp_g && tid < nvp) reinterpret_cast<float4*>(L.vp_pre1)[tid] = vvp;
     if (tid >= 384 && tid < 384 + 8 * 12) (&L.gG[NJ][0])[tid - 384] = 0.f;               // "no child" rows
-    if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; L.vp_remote = M.vps.nsets > 0 ? 1 : 0; L.vp_seq = 0u; }
+    if (tid == 511) { L.sdf_adj = sdf_adj; L.sdf_fac = 0.f; L.vp_remote = (M.vps.nsets > 0 && (int)blockIdx.x / max(M.vps.nsets, 1) < VPS_PMAX) ? 1 : 0; L.vp_seq = 0u; }   // (a set has VPS_PMAX slots; the host never launches more problems per set)
 }
 
 __device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {   // c = a b
@@ -326,7 +326,9 @@ __device__ bool vposer_layers_remote(const DevModel& M, ClosureLds& L, int tid) 
     const int bad = __syncthreads_or(ok ? 0 : 1);
     PH_T(27);
     if (bad) {
-        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); }
+        // local from now on; tell the set's helpers at once (a BYE numbered past the request that timed out: accepted whether
+        // or not the helpers still get to that request) - they must not wait 0.2 s for this problem before they can retire
+        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); vps_store(vps_request_slot(V), 0.f, (seq + 1u) << 2 | VPS_BYE); }
         __syncthreads();
         return false;
     }
@@ -488,8 +490,8 @@ __device__ __forceinline__ void vposer_backward(const DevModel& M, ClosureLds& L
             PH_T(31);
             return;
         }
-        // no answer: local from now on; the local adjoint needs the pre-activations of the local forward
-        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); }
+        // no answer: local from now on (BYE as in the forward); the local adjoint needs the pre-activations of the local forward
+        if (tid == 0) { L.vp_remote = 0; atomicAdd(V.stat, 1u); vps_store(vps_request_slot(V), 0.f, (seq + 1u) << 2 | VPS_BYE); }
         __syncthreads();
         vposer_layers_local(M, L, tid);
     }

@@ -78,6 +78,72 @@ hipError_t launch_triangulate(const float* kps, const double* intris, const doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Single-view branch of the initial guess (code/utils/init_guess.py:54-74): with one camera there is nothing to
+// triangulate; the rest-pose keypoints are pushed along the camera's z axis by
+//     est_d = fx * (torso height in camera space) / (torso height in the image)
+// and mapped back with inv(extri).  The reference's arithmetic is kept as it is: the 3-D height is the mean of the two
+// shoulder-hip distances in float64 (:62-63); the 2-D "mean" takes the LEFT shoulder-hip pair twice (:65) over the rows
+// (u, v, confidence) of the float32 keypoint array - the confidence difference is inside the norm, and the norm is
+// float32 (:66).  One thread per (frame, keypoint); every thread derives the frame's est_d and inv(extri) itself
+// (a 4 x 4 Gauss-Jordan with partial pivoting in float64, np.linalg.inv = LAPACK getrf / getri up to rounding).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void inv4(const double* E, double* Ei) {
+    double M[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { M[r][c] = E[4 * r + c]; M[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+        if (p != c) for (int q = 0; q < 8; ++q) { const double t = M[c][q]; M[c][q] = M[p][q]; M[p][q] = t; }
+        const double ip = 1.0 / M[c][c];
+        for (int q = 0; q < 8; ++q) M[c][q] *= ip;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            for (int q = 0; q < 8; ++q) M[r][q] -= f * M[c][q];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Ei[4 * r + c] = M[r][4 + c];
+}
+
+__global__ void depth_guess_kernel(const double* __restrict__ rest, const double* __restrict__ extri, const double* __restrict__ intri,
+                                   const float* __restrict__ kps, int B, int J, double* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * J) return;
+    const int b = idx / J, j = idx - b * J;
+    double E[16], Ei[16];
+    for (int i = 0; i < 16; ++i) E[i] = extri[i];
+    inv4(E, Ei);
+    auto cam = [&](int k, double* c4) {                         // extri . (rest_k ; 1), all four rows (:70-71)
+        const double x = rest[3 * k], y = rest[3 * k + 1], z = rest[3 * k + 2];
+        for (int r = 0; r < 4; ++r) c4[r] = ((E[4 * r] * x + E[4 * r + 1] * y) + E[4 * r + 2] * z) + E[4 * r + 3];
+    };
+    // torso: L / R shoulder 5, 6 ; L / R hip 11, 12 (:55-60)
+    double s5[4], s6[4], h11[4], h12[4];
+    cam(5, s5); cam(6, s6); cam(11, h11); cam(12, h12);
+    const double dl = sqrt(((s5[0] - h11[0]) * (s5[0] - h11[0]) + (s5[1] - h11[1]) * (s5[1] - h11[1])) + (s5[2] - h11[2]) * (s5[2] - h11[2]));
+    const double dr = sqrt(((s6[0] - h12[0]) * (s6[0] - h12[0]) + (s6[1] - h12[1]) * (s6[1] - h12[1])) + (s6[2] - h12[2]) * (s6[2] - h12[2]));
+    const double h3 = (dl + dr) / 2.0;                                                     // :63
+    const float* k5 = kps + ((size_t)b * J + 5) * 3;
+    const float* k11 = kps + ((size_t)b * J + 11) * 3;
+    const float d0 = k5[0] - k11[0], d1 = k5[1] - k11[1], d2 = k5[2] - k11[2];             // :65, float32 rows
+    const float n2 = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+    const float h2 = __fdiv_rn(__fadd_rn(n2, n2), 2.0f);                                    // :66: mean of the same value twice
+    const double est_d = intri[0] * (h3 / (double)h2);                                      // :68
+    double c4[4];
+    cam(j, c4);
+    c4[2] += est_d;                                                                         // :72
+    for (int r = 0; r < 3; ++r)
+        out[(size_t)idx * 3 + r] = ((Ei[4 * r] * c4[0] + Ei[4 * r + 1] * c4[1]) + Ei[4 * r + 2] * c4[2]) + Ei[4 * r + 3] * c4[3];
+}
+
+hipError_t launch_depth_guess(const double* rest, const double* extri, const double* intri, const float* kps, int B, int J,
+                              double* out, hipStream_t stream) {
+    const int n = B * J;
+    hipLaunchKernelGGL(depth_guess_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, rest, extri, intri, kps, B, J, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Second stage of the initial guess (code/utils/init_guess.py:95-106): similarity alignment of the rest-pose keypoints
 // to the triangulated ones - the reference's umeyama (code/utils/umeyama.py:16-109) with its two local changes kept
 // as they are (full-rank branch U diag(d) Vh^T, :73; two candidates with the first two rotation columns negated in

@@ -35,6 +35,8 @@ size_t sdf_work_bytes(int B, int nv);
 size_t sdf_ticket_offset(int B, int nv);
 hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
                               hipStream_t stream);
+hipError_t launch_depth_guess(const double* rest, const double* extri, const double* intri, const float* kps, int B, int J,
+                              double* out, hipStream_t stream);
 hipError_t launch_umeyama(const double* src, const double* dst, int B, int npts, int estimate_scale, double* rot, double* rvec,
                           double* trans, double* scale, hipStream_t stream);
 hipError_t launch_project_points(const DevProblems& Q, const float* pts, int N, float* uv, hipStream_t stream);
@@ -116,26 +118,45 @@ __global__ __launch_bounds__(STEP_NT) void prep_kernel(DevModel M, const ObsBloc
     if (full_pose && tid < 72) full_pose[(size_t)b * 72 + tid] = L.pose.theta[tid];
 }
 
+// REMOTE (test route, MVFIT_CLOSURE_VP_HELPERS=1): the launch carries VPoser decoder helpers behind the problems'
+// workgroups and the closure decodes through them - the decoder arithmetic of the production single-launch fit
+// (vposer_service.h) under the closure-level goldens; the pose operands of the trial point are published for the
+// vertex pass that follows (like the asynchronous fit: objective from its own vertices, full pass beside it).
+template <bool REMOTE>
 __global__ __launch_bounds__(STEP_NT) void closure_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                           DevWeights W, DevPose P, const float* __restrict__ params,
                                                           int from_pass, float* __restrict__ loss,
                                                           float* __restrict__ grad, float* __restrict__ joints,
                                                           const SdfAdj* __restrict__ sdf_adj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (REMOTE && (int)blockIdx.x >= M.vps.nprob) {
+        vposer_helper(M.vpt, M.vps, smem_raw, (int)blockIdx.x % M.vps.nsets, ((int)blockIdx.x - M.vps.nprob) / M.vps.nsets);
+        return;
+    }
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
     const int b = blockIdx.x, tid = threadIdx.x;
     prologue(L, M, obs + b, nullptr, nullptr, from_pass ? P.vposed_sel + (size_t)b * NC_MAX : nullptr,
              from_pass ? P.xs_sel + (size_t)b * NC_MAX : nullptr, params + (size_t)b * DV, tid, sdf_adj ? sdf_adj + b : nullptr);
     __syncthreads();
-    pose_prep(M, L, W.flags, tid);
+    if constexpr (REMOTE) {
+        pose_prep_decode_inl<true>(M, L, W.flags, tid);
+        pose_prep_elems(M, L, W.flags, tid);
+    } else {
+        pose_prep(M, L, W.flags, tid);
+    }
     sparse_forward(M, L, from_pass != 0, tid);
+    if constexpr (REMOTE) publish_pose(L, P, b, tid);
     const bool want_grad = grad != nullptr;
     const double total = loss_and_keypoint_grad(M, L, nviews, W, want_grad, tid);
     if (tid == 0 && loss) loss[b] = (float)total;
     if (joints && tid < NKP * 3) joints[(size_t)b * NKP * 3 + tid] = (&L.kp[0][0])[tid];
     if (want_grad) {
-        closure_backward(M, L, nviews, W, tid);
+        closure_backward<REMOTE>(M, L, nviews, W, tid);
         if (tid < DV) grad[(size_t)b * DV + tid] = L.grad[tid];
+    }
+    if constexpr (REMOTE) {
+        __syncthreads();
+        if (tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, (L.vp_seq + 1u) << 2 | VPS_BYE);
     }
 }
 
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         asm volatile("" : "+v"(t));
         done = fit_round<REMOTE, REUSE, LEAN>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
-                         ring.tag ? &ring : nullptr, b);
+                         ring.tag ? &ring : nullptr, (int)blockIdx.x);      // ring slots: sub-batch-relative problem index
         if (done) break;                                  // block-uniform
         // two-phase fit (stages without the SDF term run here, the rest in chained rounds): leave at the stage boundary -
         // the trial point in L.opt.x is the first one of the next stage, the optimiser is fresh (non_linear_solver.py:172)
@@ -1014,7 +1035,8 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     if (c->upload_failed) return fail(c, MVFIT_E_HIP, "copying the model constants to the device failed");
     HIP_OK(c, vertex_pass_configure());
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
-    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(fit_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_gram_lds()));
@@ -1261,6 +1283,15 @@ extern "C" int mvfit_full_pose(mvfit_ctx* c, const float* params, uint32_t flags
     return MVFIT_OK;
 }
 
+// decoder helpers (vposer_service.h): launch geometry, see launch_persistent
+constexpr int kVpsSets = 8;                                             // sets of a launch with more than 32 problems
+constexpr int kVpsHelpers = kVpsSets * VPS_SLICES;                      // 64 CUs
+constexpr int kVpsMaxSparse = 160, kVpsMaxAsync = 96;
+static_assert(kVpsMaxSparse <= kVpsSets * VPS_PMAX && kVpsMaxSparse + kVpsHelpers <= 256 && 32 + VPS_MAX_SETS * VPS_SLICES <= 160, "all workgroups resident");
+
+static int closure_via_helpers(mvfit_ctx* c, const mvfit_weights* w, const float* params, float* loss, float* grad,
+                               float* verts, float* joints);
+
 extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* params, float* loss, float* grad,
                              float* verts, float* joints) {
     if (!c || !w || !params || !loss) return MVFIT_E_ARG;
@@ -1271,6 +1302,10 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     if (sdf && !c->sdf_num_faces)
         return fail(c, MVFIT_E_STATE, "coll_loss_weight > 0 needs the SDF term's faces: call mvfit_set_sdf first");
     HIP_OK(c, hipSetDevice(c->device));
+    {
+        const char* e = getenv("MVFIT_CLOSURE_VP_HELPERS");
+        if (e && atoi(e) != 0 && (w->flags & MVFIT_F_VPOSER) && c->vps_mem && !sdf) return closure_via_helpers(c, w, params, loss, grad, verts, joints);
+    }
     float* vbuf = verts ? verts : c->d_verts;
     // the interpenetration term reads every vertex: it forces the vertex pass
     const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0 && !sdf;
@@ -1287,11 +1322,37 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
         if (rc) return rc;
     }
     prof_begin(c, c->ev_step);
-    hipLaunchKernelGGL(closure_kernel, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V,
+    hipLaunchKernelGGL(closure_kernel<false>, dim3(c->B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->V,
                        to_dev(*w), c->P, params,
                        sparse ? 0 : 1, loss, grad, joints, sdf ? (const SdfAdj*)c->d_sdf_adj : (const SdfAdj*)nullptr);
     prof_end(c, c->ev_step);
     HIP_OK(c, hipGetLastError());
+    return MVFIT_OK;
+}
+
+// Test route of mvfit_closure (MVFIT_CLOSURE_VP_HELPERS=1, read per call; VPoser flag, no SDF term): the closure decodes
+// the body pose on helper workgroups of its own launch - the decoder of the production single-launch fits
+// (vposer_service.h), whose summation order differs from the in-workgroup decoder - and, like those fits, evaluates the
+// objective from the vertices it computes itself while the full vertex pass runs on the operands it published.
+static int closure_via_helpers(mvfit_ctx* c, const mvfit_weights* w, const float* params, float* loss, float* grad,
+                               float* verts, float* joints) {
+    const int n = c->B;
+    if (n > kVpsMaxSparse) return fail(c, MVFIT_E_ARG, "MVFIT_CLOSURE_VP_HELPERS: at most %d problems (all workgroups resident)", kVpsMaxSparse);
+    DevModel M = c->M;
+    const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
+    const int nsets = std::max((n + VPS_PMAX - 1) / VPS_PMAX, std::min(cap, n));
+    HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8 + 8, c->stream));
+    M.vps.req = c->vps_mem;
+    M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;
+    M.vps.stat = reinterpret_cast<unsigned*>(c->vps_mem + c->vps_words);
+    M.vps.nsets = nsets;
+    M.vps.nprob = n;
+    M.vps.fault = 0;
+    c->vps_stats[0] = 1;
+    hipLaunchKernelGGL(closure_kernel<true>, dim3(n + nsets * VPS_SLICES), dim3(STEP_NT), step_lds(), c->stream, M,
+                       (const ObsBlock*)c->d_obs, c->V, to_dev(*w), c->P, params, 0, loss, grad, joints, (const SdfAdj*)nullptr);
+    HIP_OK(c, hipGetLastError());
+    if (verts) return run_vertex_pass(c, verts);
     return MVFIT_OK;
 }
 
@@ -1387,22 +1448,32 @@ static const int kRingSlots = 128;
 static const int kPassBatch = 24;
 static const int kAsyncMaxB = 160;        // one CU per problem for the optimiser: leave >= 96 CUs to the passes
 
-static int ensure_async(mvfit_ctx* c) {
+// The ring is sized by the SUB-BATCH (rb problems, a multiple of 32), not by the batch: only one sub-batch uses it at a
+// time (128 slots x 2.06 KB per problem: 34 MB at 128 problems whatever the batch size).  Everything indexed by ring slot
+// takes sub-batch-relative problem indices; done_round stays indexed by the global problem index.
+static int ensure_async(mvfit_ctx* c, int rb) {
     if (!c->pass_stream) {
         HIP_OK(c, hipStreamCreateWithFlags(&c->pass_stream, hipStreamNonBlocking));
         for (hipEvent_t& e : c->ev_batch) HIP_OK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_OK(c, hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
         HIP_OK(c, hipHostMalloc(&c->h_async_done, 64));
     }
-    if (c->ring.tag) return MVFIT_OK;
     AsyncRing& R = c->ring;
-    const size_t Bp = (size_t)c->Bpad;
-    R.nslots = kRingSlots; R.Bpad = c->Bpad;
+    if (R.tag && R.Bpad >= rb) return MVFIT_OK;
+    if (R.tag) {
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        HIP_OK(c, hipStreamSynchronize(c->pass_stream));
+        void* rp[] = {R.coefH, R.Amat, R.tau, R.tag, R.done_round, R.stats, R.pass_done};
+        for (void* q : rp) if (q) hipFree(q);
+        R = AsyncRing{};
+    }
+    const size_t Bp = (size_t)rb;
+    R.nslots = kRingSlots; R.Bpad = rb;
     HIP_OK(c, hipMalloc(&R.coefH, kRingSlots * Bp * KROWS * 4));
     HIP_OK(c, hipMalloc(&R.Amat, kRingSlots * Bp * 288 * 4));
     HIP_OK(c, hipMalloc(&R.tau, kRingSlots * Bp * 4 * 4));
     HIP_OK(c, hipMalloc(&R.tag, kRingSlots * Bp * 4));
-    HIP_OK(c, hipMalloc(&R.done_round, Bp * 4));
+    HIP_OK(c, hipMalloc(&R.done_round, (size_t)c->Bpad * 4));
     HIP_OK(c, hipMalloc(&R.stats, 4 * 4));
     HIP_OK(c, hipMalloc(&R.pass_done, 4));
     HIP_OK(c, hipMemset(R.coefH, 0, kRingSlots * Bp * KROWS * 4));
@@ -1420,11 +1491,6 @@ static int ensure_async(mvfit_ctx* c) {
 // kVpsMaxSparse problems (objective vertices only) / kVpsMaxAsync (asynchronous: the passes keep >= 96 CUs) - every
 // problem's arithmetic is the same whatever the slicing.  MVFIT_VP_HELPERS=0 keeps the decoder in the problems' own
 // workgroups (another summation order: results differ in the last bits).
-constexpr int kVpsSets = 8;                                             // sets of a launch with more than 32 problems
-constexpr int kVpsHelpers = kVpsSets * VPS_SLICES;                      // 64 CUs
-constexpr int kVpsMaxSparse = 160, kVpsMaxAsync = 96;
-static_assert(kVpsMaxSparse <= kVpsSets * VPS_PMAX && kVpsMaxSparse + kVpsHelpers <= 256 && 32 + VPS_MAX_SETS * VPS_SLICES <= 160, "all workgroups resident");
-
 static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
     const char* e = getenv("MVFIT_VP_HELPERS");          // read per fit: tests switch it inside one process
     const bool off = e && atoi(e) == 0;
@@ -1440,7 +1506,9 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
         const char* e = getenv("MVFIT_VP_SETS");
         const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
-        const int nsets = std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n);
+        // at least ceil(n / VPS_PMAX) sets: a set has VPS_PMAX request / answer slots (the knob cannot push problems past them)
+        const int need = (n + VPS_PMAX - 1) / VPS_PMAX;
+        const int nsets = std::max(need, std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n));
         HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8, c->stream));
         M.vps.req = c->vps_mem;
         M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;
@@ -1462,29 +1530,34 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
 }
 
 static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1) {
-    int rc = ensure_async(c);
-    if (rc) return rc;
     const int B = c->B;
-    const AsyncRing& R = c->ring;
-    volatile int* h_done = c->h_async_done;
-    // polled words: re-initialised every call
-    HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * c->Bpad * 4, c->stream));
-    HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
-    HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
     // More problems than the optimiser gets CUs (one workgroup per CU, >= 96 CUs left to the passes): time-sliced in
     // sub-batches of whole 32-problem chunks, one after the other - every sub-batch is the same asynchronous fit (problems
     // are independent: the results do not depend on the slicing, tests/test_gpu_large_batch.py).
     const int maxb = vps_enabled(c, SW) ? kVpsMaxAsync : kAsyncMaxB;
     const int nsub = (B + maxb - 1) / maxb;
     const int per = ((B + nsub - 1) / nsub + 31) / 32 * 32;
+    int rc = ensure_async(c, per);
+    if (rc) return rc;
+    const AsyncRing& R = c->ring;
+    const size_t rb = (size_t)R.Bpad;                       // ring stride in problems (>= per)
+    volatile int* h_done = c->h_async_done;
+    // polled words: re-initialised every call
+    HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
+    HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
     static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
     for (int b_lo = 0; b_lo < B; b_lo += per) {
         const int b_hi = std::min(B, b_lo + per);
         *h_done = 0;
+        // per sub-batch: its tags (the slots are reused by other problems), the pass counter and the count of problems
+        // that left the launch (finished or paused) - a sub-batch that stops at the round cap does not keep the later ones
+        // from seeing theirs complete.  (The ctx stream is behind the previous sub-batch's last passes here.)
+        HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * rb * 4, c->stream));
         HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4, c->stream));
+        HIP_OK(c, hipMemsetAsync(c->F.n_done + 1, 0, 4, c->stream));
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
-        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi, pause_stage);
+        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi - b_lo, pause_stage);
         if (rc) return rc;
         // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
         int k = 0;
@@ -1493,11 +1566,12 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                 const unsigned r = (unsigned)(k * kPassBatch + i);
                 const int slot = (int)(r % (unsigned)kRingSlots);
                 DevPose P = c->P;                                          // side outputs / unused fields as in the chained mode
-                P.coefH = R.coefH + (size_t)slot * c->Bpad * (KROWS / 4);
+                // the pass addresses its operands by the global problem / chunk index: slot bases shifted by the sub-batch start
+                P.coefH = R.coefH + ((ptrdiff_t)slot * (ptrdiff_t)rb - (ptrdiff_t)b_lo) * (KROWS / 4);
                 P.coefT = nullptr;
-                P.Amat = R.Amat + (size_t)slot * c->Bpad * 288;
-                P.tau = R.tau + (size_t)slot * c->Bpad * 4;
-                P.tag = R.tag + (size_t)slot * c->Bpad;
+                P.Amat = R.Amat + ((ptrdiff_t)slot * (ptrdiff_t)rb - (ptrdiff_t)b_lo) * 288;
+                P.tau = R.tau + ((ptrdiff_t)slot * (ptrdiff_t)rb - (ptrdiff_t)b_lo) * 4;
+                P.tag = R.tag + ((ptrdiff_t)slot * (ptrdiff_t)rb - (ptrdiff_t)b_lo);
                 P.done_round = R.done_round;
                 P.stats = R.stats;
                 P.pass_done = R.pass_done;
@@ -1518,7 +1592,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             }
             HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
             if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
-            if (*h_done >= b_hi) break;
+            if (*h_done >= b_hi - b_lo) break;
             if ((k + 1) * kPassBatch >= cap) break;
         }
         // behind the optimiser kernel (all problems of the sub-batch, or the round cap) the ctx stream continues behind the
@@ -1628,6 +1702,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
         const int nsub = (B + maxb - 1) / maxb, per = (B + nsub - 1) / nsub;
         for (int b_lo = 0; b_lo < B; b_lo += per) {
             const int b_hi = std::min(B, b_lo + per);
+            const int done_before = *h_done;          // (synchronised: problems finished by the earlier sub-batches)
             rounds = 0;
             while (rounds < cap) {
                 const int chunk = std::min(cap - rounds, 1 << 20);
@@ -1636,7 +1711,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
                 rounds += chunk;
                 HIP_OK(c, hipMemcpyAsync(h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
                 HIP_OK(c, hipStreamSynchronize(c->stream));
-                if (*h_done >= b_hi) break;
+                if (*h_done >= done_before + (b_hi - b_lo)) break;      // this sub-batch is complete (an earlier one may have hit the cap)
             }
         }
     } else if (c->profile) {
@@ -1763,6 +1838,17 @@ extern "C" int mvfit_triangulate(mvfit_ctx* c, int B, int V, const float* keypoi
     HIP_OK(c, hipSetDevice(c->device));
     hipError_t e = launch_triangulate(keypoints, intris, extris, B, V, NKP, joints3d, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "triangulate launch: %s", hipGetErrorString(e));
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_depth_guess(mvfit_ctx* c, int B, const double* rest_joints, const double* extri, const double* intri,
+                                 const float* keypoints, double* joints3d) {
+    if (!c) return MVFIT_E_ARG;
+    if (B <= 0 || !rest_joints || !extri || !intri || !keypoints || !joints3d)
+        return fail(c, MVFIT_E_ARG, "mvfit_depth_guess: bad argument (B=%d)", B);
+    HIP_OK(c, hipSetDevice(c->device));
+    hipError_t e = launch_depth_guess(rest_joints, extri, intri, keypoints, B, NKP, joints3d, c->stream);
+    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "depth guess launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
 

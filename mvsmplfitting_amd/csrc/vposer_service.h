@@ -190,7 +190,9 @@ __device__ __attribute__((noinline)) void vposer_helper(const VpTiles& T, const 
                 const unsigned long long g0 = vps_load(rq + l), g1 = vps_load(rq + 64 + l);
                 const unsigned long long g2 = l < VPS_GRAN - 128 ? vps_load(rq + 128 + l) : 0ull;
                 const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)vps_tag(g0));
-                if ((t0 >> 2) == expect[k]) {
+                // (a BYE may carry any number from the expected one on: a problem that gave up on a late answer numbers it
+                // past the request it no longer waits for)
+                if ((t0 >> 2) == expect[k] || ((t0 & 3u) == VPS_BYE && (t0 >> 2) > expect[k])) {
                     const unsigned kind = t0 & 3u;
                     bool ok = true;
                     if (kind == VPS_FWD) ok = l >= 32 || vps_tag(g0) == t0;

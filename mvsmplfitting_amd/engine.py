@@ -6,6 +6,7 @@ every number is produced by the HIP kernels in mvsmplfitting_amd/csrc.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -221,8 +222,18 @@ class MvFit:
         self._check(rc)
         st4 = (C.c_uint32 * 4)()
         self._check(self._lib.mvfit_fit_stats(self._ctx, st4))
-        return x, dict(final_loss=final, n_closure=ncl, n_iter=nit,
-                       passes=dict(run=int(st4[0]), skipped=int(st4[1]), missed=int(st4[2]), timed_out=int(st4[3])))
+        stats = dict(final_loss=final, n_closure=ncl, n_iter=nit,
+                     passes=dict(run=int(st4[0]), skipped=int(st4[1]), missed=int(st4[2]), timed_out=int(st4[3])))
+        if any(int(dict(s).get('flags', 0)) & _lib.F_VPOSER for s in stages):
+            # decoder helpers (vposer_service.h): an answer that timed out makes that problem decode in its own workgroup
+            # from then on - another summation order, i.e. last-bit differences from run to run.  Never silent.
+            dec = self.decoder_stats()
+            stats['decoder'] = dec
+            if dec['answers_timed_out'] or dec['helpers_gave_up']:
+                warnings.warn('VPoser decoder helpers degraded in this fit (%d answers timed out, %d helpers gave up): the '
+                              'affected problems decoded locally (results differ in the last bits; is the GPU shared?)'
+                              % (dec['answers_timed_out'], dec['helpers_gave_up']), RuntimeWarning)
+        return x, stats
 
     def decoder_stats(self):
         """Counters of the VPoser decoder helpers of the last fit (include/mvfit.h:mvfit_decoder_stats): launches that
@@ -297,6 +308,28 @@ class MvFit:
         out = torch.empty(B, 17, 3, dtype=torch.float64, device=self.device)
         self._check(self._lib.mvfit_triangulate(self._ctx, B, V, kp.data_ptr(), K.data_ptr(), E.data_ptr(), out.data_ptr()))
         return out
+
+    def depth_guess(self, rest_joints, extri, intri, keypoints):
+        """joints3d [B,17,3] float64 for frames seen by ONE camera (include/mvfit.h:mvfit_depth_guess; reference
+        init_guess.py:54-74): rest_joints [17,3] float64, extri [4,4], intri [3,3] float64, keypoints [B,17,3]
+        (u, v, confidence)."""
+        kp = self._dev(keypoints)
+        if kp.dim() != 3 or kp.shape[1] != 17 or kp.shape[2] != 3:
+            raise MvFitError('keypoints must be [B, 17, 3]')
+        f64 = lambda a, shape: self._f64(a, shape)
+        R_, E_, K_ = f64(rest_joints, (17, 3)), f64(extri, (4, 4)), f64(intri, (3, 3))
+        B = int(kp.shape[0])
+        out = torch.empty(B, 17, 3, dtype=torch.float64, device=self.device)
+        self._check(self._lib.mvfit_depth_guess(self._ctx, B, R_.data_ptr(), E_.data_ptr(), K_.data_ptr(), kp.data_ptr(),
+                                                out.data_ptr()))
+        return out
+
+    def _f64(self, a, shape):
+        t = torch.as_tensor(np.asarray(a, np.float64) if not isinstance(a, torch.Tensor) else a, dtype=torch.float64,
+                            device=self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise MvFitError('expected shape %s, got %s' % (tuple(shape), tuple(t.shape)))
+        return t
 
     def umeyama(self, src, dst, estimate_scale=True):
         """The reference's similarity alignment + cv2.Rodrigues (include/mvfit.h:mvfit_umeyama): src [npts,3],

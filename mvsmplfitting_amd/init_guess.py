@@ -5,6 +5,7 @@
   umeyama(joints, joints3d, est_scale)        code/utils/umeyama.py:16-109      -> mvfit_umeyama
   cv2.Rodrigues(rot)                          init_guess.py:96                   -> mvfit_umeyama (rvec)
   rest-pose keypoints of the model            init_guess.py:38-52                -> mvfit_vertices at zero parameters
+  single-view depth guess                      init_guess.py:54-74                -> mvfit_depth_guess
 
 ``recompute3D`` keeps the reference's argument meaning (``keypoints`` a list over views of [1, 17, 3] arrays
 (u, v, confidence)); ``init_guess_batch`` takes [B, V, 17, 3]; one view selects the single-view depth guess
@@ -43,30 +44,13 @@ def rest_keypoints(engine: MvFit, scale: float = 1.0) -> torch.Tensor:
     return joints[0].to(torch.float64)
 
 
-def single_view_joints3d(rest, extri, intri, keypoints) -> torch.Tensor:
-    """The depth guess for single-view input (init_guess.py:54-72), batched over frames: the rest-pose keypoints pushed
-    along the camera's z axis by est_d = fx * (torso height in 3-D) / (torso height in the image), where the 3-D height
-    is the mean of the two shoulder-hip distances and the 2-D one - as the reference computes it (:65) - the LEFT
-    shoulder-hip distance taken twice, over the (u, v, confidence) rows.  rest [17,3] float64 tensor, extri [4,4], intri
-    [3,3], keypoints [B,17,3]
-    -> [B,17,3] float64 on rest's device."""
-    dev = rest.device
-    E = torch.as_tensor(np.asarray(extri, np.float64), dtype=torch.float64, device=dev)
-    fx = float(np.asarray(intri, np.float64)[0, 0])
-    kp = torch.as_tensor(np.asarray(keypoints, np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints,
-                         dtype=torch.float32, device=dev)
-    rest_h = torch.cat([rest.to(torch.float64), torch.ones(rest.shape[0], 1, dtype=torch.float64, device=dev)], 1)   # [17,4]
-    cam = E @ rest_h.T                                                          # [4,17] camera coordinates of the rest pose
-    t3 = cam[:3, list(TORSO)].T                                                 # [4,3]
-    h3 = 0.5 * ((t3[0] - t3[2]).norm() + (t3[1] - t3[3]).norm())
-    # rows (u, v, confidence) like :58 - the confidence difference is in the norm - and in float32 like the reference's
-    # keypoint arrays; the mean of the same distance twice (:65-66) is that distance
-    d2 = kp[:, TORSO[0], :] - kp[:, TORSO[2], :]
-    h2 = torch.sqrt(d2[:, 0] * d2[:, 0] + d2[:, 1] * d2[:, 1] + d2[:, 2] * d2[:, 2]).to(torch.float64)
-    est_d = fx * (h3 / h2)                                                      # [B]
-    camb = cam.unsqueeze(0).repeat(kp.shape[0], 1, 1)
-    camb[:, 2, :] += est_d[:, None]
-    return (torch.linalg.inv(E) @ camb).transpose(1, 2)[:, :, :3].contiguous()
+def single_view_joints3d(engine: MvFit, rest, extri, intri, keypoints) -> torch.Tensor:
+    """The depth guess for single-view input (init_guess.py:54-74), batched over frames, behind the C ABI
+    (mvfit_depth_guess): the rest-pose keypoints pushed along the camera's z axis by est_d = fx * (torso height in 3-D)
+    / (torso height in the image), where the 3-D height is the mean of the two shoulder-hip distances and the 2-D one -
+    as the reference computes it (:65) - the LEFT shoulder-hip distance taken twice, over the (u, v, confidence) rows.
+    rest [17,3] float64, extri [4,4], intri [3,3], keypoints [B,17,3] -> [B,17,3] float64 on the engine's device."""
+    return engine.depth_guess(rest, extri, intri, keypoints)
 
 
 def init_guess_batch(engine: MvFit, extris, intris, keypoints, est_scale=True, fixed_scale=None, use_torso=True,
@@ -98,7 +82,7 @@ def init_guess_batch(engine: MvFit, extris, intris, keypoints, est_scale=True, f
             idx = torch.as_tensor(sel, device=engine.device)
             sub = kp_t[torch.as_tensor(sel)][:, torch.as_tensor(vs)]
             if vs.size == 1:
-                j3[idx] = single_view_joints3d(rest, extris[vs[0]], intris[vs[0]], sub[:, 0])
+                j3[idx] = single_view_joints3d(engine, rest, extris[vs[0]], intris[vs[0]], sub[:, 0].contiguous())
             else:
                 j3[idx] = engine.triangulate(sub.contiguous(), intris[vs], extris[vs])
     idx = list(TORSO) if use_torso else list(range(17))

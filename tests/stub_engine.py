@@ -142,6 +142,13 @@ class StubMvFit:
         kp = np.asarray(keypoints)
         return torch.tensor(np.stack([tn.recompute3d(extris, intris, kp[b]) for b in range(kp.shape[0])]))
 
+    def depth_guess(self, rest_joints, extri, intri, keypoints):
+        from oracle import init_guess_np as ign
+        kp = np.asarray(keypoints.cpu().numpy() if isinstance(keypoints, torch.Tensor) else keypoints, np.float32)
+        rest = np.asarray(rest_joints.cpu().numpy() if isinstance(rest_joints, torch.Tensor) else rest_joints, np.float64)
+        return torch.as_tensor(np.stack([ign.single_view_joints3d(rest, extri, intri, kp[b]) for b in range(kp.shape[0])]),
+                               dtype=torch.float64)
+
     def umeyama(self, src, dst, estimate_scale=True):
         from oracle import umeyama_np as un
         src = np.asarray(src.cpu().numpy() if isinstance(src, torch.Tensor) else src, np.float64)

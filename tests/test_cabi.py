@@ -1,6 +1,8 @@
 """CPU: the C-ABI library loads and exports every symbol include/mvfit.h declares."""
 import os
 import re
+import shutil
+import subprocess
 
 from mvsmplfitting_amd import _lib
 
@@ -15,6 +17,18 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_library_exports_nothing_but_the_declared_symbols():
+    """The drop-in boundary is the C ABI and nothing else (csrc/libmvfit.map): no kernel host stubs, no weak STL
+    instantiations that could interpose with the host's, no runtime-internal __hip_* symbols."""
+    hdr = open(os.path.join(ROOT, 'include', 'mvfit.h')).read()
+    declared = set(re.findall(r'\b(mvfit_[a-z0-9_]+)\s*\(', hdr)) - {'mvfit_ctx'}
+    so = os.path.join(ROOT, 'mvsmplfitting_amd', 'libmvfit.so')
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-D', '--defined-only', so], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_header_constants_match_binding():

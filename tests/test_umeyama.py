@@ -131,19 +131,23 @@ def test_gpu_umeyama_equals_the_restatement_with_numpys_signs():
     eng.close()
 
 
+@pytest.mark.gpu
 def test_single_view_depth_guess_equals_its_restatement():
-    """init_guess.single_view_joints3d (batched, torch) against the line-by-line NumPy restatement of
-    init_guess.py:54-72 on the demo's first camera and keypoints."""
+    """mvfit_depth_guess (through init_guess.single_view_joints3d, batched) against the line-by-line NumPy restatement of
+    init_guess.py:54-74 on the demo's first camera and keypoints."""
     import os
     import torch
     from mvsmplfitting_amd.init_guess import single_view_joints3d
     from oracle import init_guess_np as ig
-    from tests.helpers import GOLD
+    from tests.gpu_helpers import make_engine
+    from tests.helpers import GOLD, body_model
     g = dict(np.load(os.path.join(GOLD, 'demo_fit_smpl.npz')))
     rest = g['init_joints_rest']
     kp = g['keypoints'].reshape(6, 17, 3)
-    frames = np.stack([kp[0], kp[0] * np.array([0.9, 1.1, 1.0], np.float32), kp[2]])
-    out = single_view_joints3d(torch.as_tensor(rest, dtype=torch.float64), g['extris'][0], g['intris'][0], frames).numpy()
+    frames = np.stack([kp[0], kp[0] * np.array([0.9, 1.1, 1.0], np.float32), kp[2]]).astype(np.float32)
+    eng = make_engine(body_model())
+    out = single_view_joints3d(eng, torch.as_tensor(rest, dtype=torch.float64), g['extris'][0], g['intris'][0], frames).cpu().numpy()
+    eng.close()
     for b in range(3):
         ref = ig.single_view_joints3d(rest, g['extris'][0], g['intris'][0], frames[b])
         assert np.abs(out[b] - ref).max() < 1e-9 * np.abs(ref).max()
