@@ -125,9 +125,14 @@ __global__ void depth_guess_kernel(const double* __restrict__ rest, const double
     const double h3 = (dl + dr) / 2.0;                                                     // :63
     const float* k5 = kps + ((size_t)b * J + 5) * 3;
     const float* k11 = kps + ((size_t)b * J + 11) * 3;
-    const float d0 = k5[0] - k11[0], d1 = k5[1] - k11[1], d2 = k5[2] - k11[2];             // :65, float32 rows
-    const float n2 = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
-    const float h2 = __fdiv_rn(__fadd_rn(n2, n2), 2.0f);                                    // :66: mean of the same value twice
+    float h2;
+    {
+#pragma clang fp contract(off)                             // NumPy's float32 expression tree: no fused multiply-adds
+        const float d0 = k5[0] - k11[0], d1 = k5[1] - k11[1], d2 = k5[2] - k11[2];         // :65, float32 rows
+        const float q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+        const float n2 = sqrtf((q0 + q1) + q2);                                             // (IEEE square root: hipcc's default)
+        h2 = (n2 + n2) / 2.0f;                                                              // :66: mean of the same value twice
+    }
     const double est_d = intri[0] * (h3 / (double)h2);                                      // :68
     double c4[4];
     cam(j, c4);
