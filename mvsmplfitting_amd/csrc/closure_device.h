@@ -23,6 +23,7 @@
 //   E7  wave 0: chain adjoint; waves 1-7: stream pd_subT (g_coef partials)      [overlapped]
 //   E8  g_R assembly, g_J, g_beta; E9 Rodrigues adjoint + pose priors; flat gradient
 #pragma once
+#include <cstddef>
 #include "mvfit_device.h"
 
 namespace mvfit {
@@ -52,6 +53,7 @@ struct PoseBlock {                  // everything pose_prep + the chain derive f
 struct OptBlock {                   // optimiser state that survives between closure rounds
     float x[DPAD];                  // current trial point, flat parameter layout
     float lb_ro[104];               // ro = 1/(y.s) per history slot
+    float lb_ys[104];               // y.s per history slot (the diagonal of the compact form, lbfgs_device.h)
     LbState lbS;
     float lbV[LB_NVEC][LB_D];
 };
@@ -101,10 +103,23 @@ struct ClosureLds {
     double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
     __attribute__((aligned(16))) float grad[DPAD];
-    // scratch for k-split partial sums: max(8 * nc_pad, 8 * KROWS)
-    __attribute__((aligned(16))) float scratch[8 * NC_MAX];
-    // VPoser activations (decoder fwd/bwd)
-    // what the decoder adjoint needs from the forward: handed from launch to launch as one block (VpBlock)
+    // scratch for k-split partial sums: max(8 * nc_pad, 8 * KROWS) - closure phases only; the optimiser's work area
+    // (direction computation) shares the bytes: the two never overlap in time
+    union {
+        __attribute__((aligned(16))) float scratch[8 * NC_MAX];
+        __attribute__((aligned(16))) LbWork<float> lbW;
+    };
+    // GMM
+    float gmm_d[72];
+    float gmm_t[8][72];
+    float gmm_ll[8];
+    // per-stage weights and optimiser options: read from LDS inside the round loop so that they do not
+    // pin ~100 SGPRs across it
+    DevWeights sw[MVFIT_MAX_STAGES];
+    __attribute__((aligned(16))) LbOpts opts;
+    // VPoser activations (decoder fwd/bwd) - LAST: a single-launch fit without VPoser lays its L-BFGS history over them
+    // (persistent_tail_offset).  What the decoder adjoint needs from the forward is handed from launch to launch as one
+    // block (VpBlock = vp_pre1 .. vp_cpad)
     __attribute__((aligned(16))) float vp_pre1[512];
     float vp_pre2[512];
     float vp_cache[23][25];
@@ -113,16 +128,9 @@ struct ClosureLds {
     float vp_g[512];
     float vp_o[144];
     float vp_go[144];
-    // GMM
-    float gmm_d[72];
-    float gmm_t[8][72];
-    float gmm_ll[8];
-    // per-stage weights and optimiser options: read from LDS inside the round loop so that they do not
-    // pin ~100 SGPRs across it; in the single-launch fit the (s, y) ring follows this struct.
-    DevWeights sw[MVFIT_MAX_STAGES];
-    __attribute__((aligned(16))) LbOpts opts;
-    __attribute__((aligned(16))) LbWork<float> lbW;
 };
+static_assert(sizeof(LbWork<float>) <= 8 * NC_MAX * 4, "the optimiser's work area lives in the closure's scratch bytes");
+static_assert(offsetof(ClosureLds, vp_pre1) % 16 == 0, "history tail alignment");
 
 // Kernel prologue: the LDS image blocks as 16-byte-word copies, all loads of a thread in flight before
 // the first wait.  Null pointers skip a block; x_g (flat parameters, DV floats) fills L.opt.x.

@@ -95,35 +95,39 @@ constexpr int LB_NVEC = 7;
 // ring wrap; LB_PD pad rows on both sides keep the prefetch in bounds.
 template <typename T>
 struct LbHist {
-    T* dirs;       // [LB_HIST][LB_D]
-    T* stps;       // [LB_HIST][LB_D]
+    T* dirs;       // [LB_HIST][ld]
+    T* stps;       // [LB_HIST][ld]
     T* ro;         // [LB_HIST]
-    T* grow;       // [LB_GROWS][LB_GS]
+    T* grow;       // [LB_GROWS][LB_GS]   (two-loop form only)
     T* gcol;       // [LB_GROWS][LB_GS]
-    // compact form (lb_direction_compact): by history slot, float64
-    //   rinv[i][j] = (R^-1)_ij, R_ij = s_i . y_j for i not newer than j ; rinvT = its transpose ; yyg[i][j] = y_i . y_j
-    double* rinv = nullptr;
-    double* rinvT = nullptr;
-    double* yyg = nullptr;
+    // compact form (lb_direction_compact):
+    //   ys[i]   = s_i . y_i by history slot (the diagonal D of the compact representation; ro = 1 / ys)
+    //   rinv    = R^-1, R_ij = s_i . y_j for pair i not newer than pair j (upper triangular in age order), stored by SLOT in
+    //             packed symmetric form: the entry of the unordered slot pair {r, c} lives at tri(max) + min and holds
+    //             (R^-1)_(older, newer).  Exactly one of the two orders is live for any two live pairs, whatever the ring
+    //             head: neither accepting a pair (its column overwrites the evicted pair's star) nor evicting one moves data.
+    T* ys = nullptr;
+    T* rinv = nullptr;
+    int ld = LB_D;  // row stride of dirs / stps
 };
-
-// scratch of lb_direction_compact (LDS): inputs of the small algebra by age index
-template <typename T>
-struct LbCompactWs {
-    T p[LB_HIST + 4], q[LB_HIST + 4], u[LB_HIST + 4], yy[LB_HIST + 4];
-    double w[LB_HIST + 4], z[LB_HIST + 4], a[LB_HIST + 4], c[LB_HIST + 4];
-};
+constexpr int LB_RPACK = (LB_HIST * (LB_HIST + 1) / 2 + 3) / 4 * 4;        // elements of the packed R^-1 (5052)
+__device__ __forceinline__ int lb_tri(int r, int c) { const int hi = max(r, c), lo = min(r, c); return ((hi * (hi + 1)) >> 1) + lo; }
 
 // LDS scratch of the block-wide direction computation
 template <typename T>
 struct LbWork {
-    T qv[LB_D];            // -g, then r_0 = H q_0
+    T qv[LB_D];            // -g, then (two-loop form) r_0 = H q_0
     T dv[LB_D];            // direction
-    T bvec[128];           // b_i, then e_i (by age index: 0 = oldest)
-    T alpha[128];
-    T cvec[128];
-    T part[8][LB_D];
-    T gnew[LB_HIST + 4];   // s_a . y_new by slot (insert pass)
+    T tv[LB_D];            // compact form: t = Y^T w - q
+    T bvec[128];           // two-loop: b_i, then e_i by age ; compact: p = S q by slot
+    T alpha[128];          // two-loop: al_i by age          ; compact: w = R^-1 p by slot
+    T cvec[128];           // two-loop: c_i by age           ; compact: a = R^-T z by slot
+    T gnew[128];           // s_a . y_new by slot (insert pass; compact: u)
+    T zv[128];             // compact: z = D w + gamma Y t by slot
+    union {
+        T part[8][LB_D];       // per-wave partial sums of the history mat-vecs
+        T part2[2][4][128];    // compact: partial sums of the two triangular products, [w | u][column group][slot]
+    };
     int n, head, ins_slot, need_dir;
     T Hdiag;
 };
@@ -174,12 +178,12 @@ __device__ void lb_row_dots(const LbHist<T>& Hh, LbWork<T>& W, int which, int ti
     for (int e = 0; e < 6; ++e) { qv[e] = W.qv[6 * l16 + e]; yn[e] = (T)0; }
     if (two) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) yn[e] = Hh.dirs[ins * LB_D + 6 * l16 + e];
+        for (int e = 0; e < 6; ++e) yn[e] = Hh.dirs[ins * Hh.ld + 6 * l16 + e];
     }
     for (int a = tid >> 4; a < n; a += NT / 16) {
         int slot = head + a;
         slot = slot >= LB_HIST ? slot - LB_HIST : slot;
-        const T* row = (which == 0 ? Hh.stps : Hh.dirs) + slot * LB_D + 6 * l16;
+        const T* row = (which == 0 ? Hh.stps : Hh.dirs) + slot * Hh.ld + 6 * l16;
         T d0 = (T)0, d1 = (T)0;
 #pragma unroll
         for (int e = 0; e < 6; ++e) { const T v = row[e]; d0 = fma(v, qv[e], d0); d1 = fma(v, yn[e], d1); }
@@ -343,156 +347,248 @@ __device__ void lb_recurrence(const LbHist<T>& Hh, LbWork<T>& W, int lane, const
     if (k1 < n) out[k1] = x1;
 }
 
-// d = H (-g) in the compact (Byrd-Nocedal-Schnabel 1994, eq. 3.1) form of the same L-BFGS matrix the two-loop
-// recursion applies (lbfgs_ls.py:336-358), H_0 = gamma I:
+// ---------------------------------------------------------------------------------------------------------
+// d = H (-g) in the compact (Byrd-Nocedal-Schnabel 1994, eq. 3.1) form of the same L-BFGS matrix the two-loop recursion
+// applies (lbfgs_ls.py:336-358), H_0 = gamma I, q = -g:
 //     H q = gamma q + S a - gamma Y w,   w = R^-1 S^T q,   a = R^-T ((D + gamma Y^T Y) w - gamma Y^T q)
-// with R_ij = s_i . y_j (i not newer than j), D = diag(s_i . y_i).  R^-1 is maintained explicitly, one bordered
-// column per accepted pair ([R u; 0 rho]^-1 = [R^-1, -R^-1 u / rho; 0, 1/rho]); evicting the oldest pair drops the
-// first row and column, which leaves the inverse of the remaining block untouched.  The two triangular recurrences of
-// the two-loop form - 2 m dependent steps on one wave - become three m x m mat-vecs for the whole workgroup, and the
-// history is read twice instead of four times.  The m x m algebra runs in float64 (m <= 100: it is the conditioning
-// of R, not the flop count, that matters); the inputs are the same float dot products the two-loop form takes.
-// Same direction as the two-loop recursion up to rounding (tests: float64 instantiation follows the reference
-// optimiser's trajectories to 1e-7).
-template <typename T, int NT>
-__device__ void lb_direction_compact(const LbHist<T>& Hh, LbWork<T>& W, LbCompactWs<T>& C, int tid) {
-    const int n = W.n, head = W.head, t = W.ins_slot;
-    const bool ins = t >= 0;
-    const int nE = ins ? n - 1 : n;                      // pairs already represented in the matrices
-    const int l16 = tid & 15;
-    auto slot_of = [&](int age) { int sl = head + age; return sl >= LB_HIST ? sl - LB_HIST : sl; };
-    constexpr int HS = LB_HIST;                          // row stride of the matrices
-    // ---- pass 1 over the history: p = S^T q, q = Y^T q (+ u = S^T y_new, yy = Y^T y_new) ----
-    {
-        T qv[6], yn[6];
+// with R_ij = s_i . y_j (i not newer than j), D = diag(s_i . y_i).  With t = Y w - q this is
+//     p = S^T q ;  w = R^-1 p ;  t = Y w - q ;  z = D w + gamma Y^T t ;  a = R^-T z ;  d = S a - gamma t
+// - four passes over the history and two triangular mat-vecs, every one of them parallel over the whole workgroup; the
+// two-loop form's 2 m dependent steps on one wave are gone.  R^-1 is maintained explicitly (LbHist::rinv): accepting a pair
+// borders it with one column, [R u; 0 rho]^-1 = [R^-1, -R^-1 u / rho; 0, 1 / rho], which is the same triangular product
+// with u = S^T y_new as right-hand side; evicting the oldest pair drops its row and column and leaves the rest untouched.
+// Same direction as the two-loop recursion up to rounding: the float64 instantiation follows the reference optimiser's
+// trajectories to 1e-7 (tests/test_gpu_lbfgs.py, form 'compact'); in float32 on the real objective the two forms are
+// equally far from each other as from their own float64 runs (tools/lbfgs_direction_study.py).
+// All sums have a fixed association (independent of timing; of the launch geometry only through NT).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lb_age(int slot, int head) { const int a = slot - head; return a < 0 ? a + LB_HIST : a; }
+
+// (All four primitives are written branch-free with clamped addresses and zeroed coefficients: every load of a thread is
+// issued before the first use - a phase costs one LDS round trip plus its instruction count, ~8 cycles per instruction and
+// thread with the 8 waves of a workgroup on 4 SIMDs - instead of one round trip per row / column.)
+
+// history rows . vector: 4 lanes per row (interleaved 4-element chunks), all LB_HIST slots in NT / 4 rows per pass.
+//   FIRST: p[slot] = s_slot . q  and, with a freshly inserted pair t, u[slot] = s_slot . y_t (0 for slot t)
+//   else : z[slot] = ys[slot] w[slot] + gamma (y_slot . t)
+template <typename T, int NT, bool FIRST>
+__device__ __forceinline__ void lb_cmp_rowdots(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+    const int n = W.n, head = W.head, t = W.ins_slot, ld = Hh.ld;
+    const bool two = FIRST && t >= 0;
+    const int q4 = tid & 3, nch = ld >> 2;
+    constexpr int NCH = (LB_D / 4 + 3) / 4;               // 4-element chunks per lane (ld <= LB_D)
+    T vv[NCH][4], yn[NCH][4];
+    int cc[NCH];
+    const T* vec = FIRST ? W.qv : W.tv;
+    const T* ynew = Hh.dirs + max(t, 0) * ld;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) { qv[e] = W.qv[6 * l16 + e]; yn[e] = ins ? Hh.dirs[t * LB_D + 6 * l16 + e] : (T)0; }
-        for (int a = tid >> 4; a < n; a += NT / 16) {
-            const int sl = slot_of(a);
-            const T* sr = Hh.stps + sl * LB_D + 6 * l16;
-            const T* yr = Hh.dirs + sl * LB_D + 6 * l16;
-            T d0 = (T)0, d1 = (T)0, d2 = (T)0, d3 = (T)0;
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = q4 + 4 * k;
+        const bool ok = ch < nch;
+        cc[k] = 4 * min(ch, nch - 1);                      // clamped chunk: the surplus lanes re-read the last chunk with zero coefficients
 #pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                const T sv = sr[e], yv = yr[e];
-                d0 = fma(sv, qv[e], d0); d1 = fma(yv, qv[e], d1); d2 = fma(sv, yn[e], d2); d3 = fma(yv, yn[e], d3);
-            }
-            d0 = row16_sum(d0); d1 = row16_sum(d1);
-            if (ins) { d2 = row16_sum(d2); d3 = row16_sum(d3); }
-            if (l16 == 0) { C.p[a] = d0; C.q[a] = d1; C.u[a] = d2; C.yy[a] = d3; }
+        for (int j = 0; j < 4; ++j) {
+            const T v = vec[cc[k] + j], y = FIRST ? ynew[cc[k] + j] : (T)0;
+            vv[k][j] = ok ? v : (T)0;
+            yn[k][j] = (ok && two) ? y : (T)0;
         }
     }
+    const T* rows = FIRST ? Hh.stps : Hh.dirs;
+    for (int r0 = tid >> 2; r0 < 128; r0 += NT / 4) {
+        const int r = min(r0, LB_HIST - 1);
+        const bool live = r0 < LB_HIST && lb_age(r, head) < n;
+        const T* row = rows + r * ld;
+        T rv[NCH][4];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[k][j] = row[cc[k] + j];
+        T a0 = (T)0, a1 = (T)0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0 = fma(rv[k][j], vv[k][j], a0); if (FIRST) a1 = fma(rv[k][j], yn[k][j], a1); }
+        a0 += dpp_mov<DPP_XOR1>(a0); a0 += dpp_mov<DPP_XOR2>(a0);
+        if (FIRST) { a1 += dpp_mov<DPP_XOR1>(a1); a1 += dpp_mov<DPP_XOR2>(a1); }
+        const T ysw = FIRST ? (T)0 : Hh.ys[r] * W.alpha[r];
+        if (q4 == 0 && r0 < LB_HIST) {
+            if (FIRST) { W.bvec[r] = live ? a0 : (T)0; W.gnew[r] = (live && two && r != t) ? a1 : (T)0; }
+            else W.zv[r] = live ? fma(W.Hdiag, a0, ysw) : (T)0;
+        }
+    }
+}
+
+// one triangular product over the packed R^-1, in AGE space (row age a = lane, column age b uniform per wave), partial sums
+// per column group g (columns b = g, g + 4, ...: every group gets a quarter of the LIVE columns, whatever the history length):
+//   FWD : part2[0][g][slot(a)] = sum_{b in group g, b >= a, b < nE} rinv{a,b} p_b           (w = R^-1 p; nE excludes a pair that is
+//         part2[1][g][slot(a)] = the same sum with u_b                                        being inserted: its column is -R^-1 u / rho)
+//   else: part2[0][g][slot(a)] = sum_{b in group g, b <= a} rinv{a,b} z_b                    (a = R^-T z)
+// Per-lane tables (slot of age, its triangle offset, the vector element), two ages per lane; the column's entries of the
+// tables arrive by v_readlane, its use mask (lanes a <= b, resp. a >= b) as a scalar bit field.
+template <typename T, int NT, bool FWD>
+__device__ __forceinline__ void lb_cmp_tri(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+    const int n = __builtin_amdgcn_readfirstlane(W.n), head = __builtin_amdgcn_readfirstlane(W.head);
+    const int t = FWD ? __builtin_amdgcn_readfirstlane(W.ins_slot) : -1;
+    const int nE = (FWD && t >= 0) ? n - 1 : n;            // live columns of this product (the inserted pair is the newest)
+    const int lane = tid & 63;
+    const T* xv = FWD ? W.bvec : W.zv;
+    // tables by age: ages lane and lane + 64
+    int sl[2], tr[2];
+    T xa[2], ua[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int sgl = head + min(lane + 64 * h, LB_HIST - 1);
+        sgl = sgl >= LB_HIST ? sgl - LB_HIST : sgl;
+        sl[h] = sgl; tr[h] = (sgl * (sgl + 1)) >> 1;
+        xa[h] = xv[sgl]; ua[h] = FWD ? W.gnew[sgl] : (T)0;
+    }
+    for (int item = tid; item < 4 * 128; item += NT) {
+        const int g = __builtin_amdgcn_readfirstlane(item >> 7), hb = __builtin_amdgcn_readfirstlane((item >> 6) & 1);   // (NT is a multiple of 64)
+        const int A0 = 64 * hb;                                            // the wave's rows: ages A0 .. A0 + 63
+        const int a = A0 + lane;
+        const int sa = hb ? sl[1] : sl[0], tsa = hb ? tr[1] : tr[0];
+        // columns of this wave: b = g + 4 k, restricted to the part of the triangle its rows can see
+        const int blo = FWD ? max(A0, 0) : 0, bhi = FWD ? nE : min(n, A0 + 64);
+        int k0 = (blo - g + 3) >> 2;                                       // first k with g + 4 k >= blo
+        k0 = k0 < 0 ? 0 : k0;
+        T s0 = (T)0, s1 = (T)0;
+        // columns below age 64 come from the first table register, the others from the second: two runs of chunks of 8 (the
+        // table is a compile-time choice inside a run: a run-time choice per column would be compiled to branches)
+        auto run = [&](auto hi_tag, int kbeg, int kend) {
+            constexpr int HI = decltype(hi_tag)::value;
+            const int slt = sl[HI], trt = tr[HI];
+            const T xt_ = xa[HI], ut_ = ua[HI];
+            for (int kb = kbeg; kb < kend; kb += 8) {                      // uniform trip count
+                T m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int bq = min(g + 4 * (kb + j), HI ? LB_HIST - 1 : 63);          // uniform (clamped: surplus columns are masked below)
+                    const int sb = __builtin_amdgcn_readlane(slt, bq & 63), tb = __builtin_amdgcn_readlane(trt, bq & 63);
+                    m[j] = Hh.rinv[sb <= sa ? tsa + sb : tb + sa];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int b = g + 4 * (kb + j), bq = min(b, HI ? LB_HIST - 1 : 63);
+                    const bool use = kb + j < kend && (FWD ? a <= b : (a >= b && a < n));
+                    const T mk = use ? m[j] : (T)0;
+                    s0 = fma(mk, lane_read(xt_, bq & 63), s0);
+                    if (FWD) s1 = fma(mk, lane_read(ut_, bq & 63), s1);
+                }
+            }
+        };
+        const int kall = (bhi - g + 3) >> 2;                               // columns g + 4 k < bhi  <=>  k < kall
+        run(std::integral_constant<int, 0>{}, k0, min(kall, 16));
+        run(std::integral_constant<int, 1>{}, max(k0, 16), kall);
+        if (a < n) {
+            W.part2[0][g][sa] = s0;
+            if (FWD) W.part2[1][g][sa] = s1;
+        }
+    }
+}
+
+// sum_j coef[j] rows_j (a D-vector): 32 lanes per row (4-element chunks), NT / 32 rows per pass, halves of a wave
+// combined by v_permlane32_swap, per-wave partials in W.part (the caller sums them after a barrier)
+template <typename T, int NT>
+__device__ __forceinline__ void lb_cmp_matvec(const T* rows, int ld, const T* coef, LbWork<T>& W, int tid) {
+    const int n = W.n, head = W.head;
+    const int cl = tid & 31, c = 4 * min(cl, (ld >> 2) - 1);
+    const bool cok = 4 * cl < ld;
+    constexpr int NWV = (NT / 64) < 8 ? (NT / 64) : 8;     // waves that write W.part: the rows no wave writes are zeroed (the caller adds 8)
+    if (NWV < 8) { for (int i = tid; i < (8 - NWV) * LB_D; i += NT) (&W.part[NWV][0])[i] = (T)0; }
+    constexpr int RP = NT / 32, NIT = (LB_HIST + RP - 1) / RP;
+    T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+    for (int i0 = 0; i0 < NIT; i0 += 8) {
+        T cf[8], rv[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = (tid >> 5) + (i0 + i) * RP, r = min(r0, LB_HIST - 1);
+            const bool ok = (i0 + i) < NIT && r0 < LB_HIST && lb_age(r, head) < n && cok;
+            const T cv = coef[r];
+            cf[i] = ok ? cv : (T)0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[i][j] = rows[r * ld + c + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fma(cf[i], rv[i][j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { T lo, hi; swap_pair<true>(acc[j], lo, hi); acc[j] = lo + hi; }
+    if ((tid & 32) == 0 && 4 * cl < LB_D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) W.part[(tid >> 6) & 7][4 * cl + j] = acc[j];
+    }
+}
+
+// In: W.qv = -g, W.n / head / ins_slot / Hdiag, history rows, ys, ro incl. the freshly inserted pair.  Out: W.dv.
+template <typename T, int NT>
+__device__ __forceinline__ void lb_direction_compact(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
+    const int t = W.ins_slot, head = W.head, n = W.n;
+    // ---- p = S^T q (+ u = S^T y_new) ----
+    lb_cmp_rowdots<T, NT, true>(Hh, W, tid);
     __syncthreads();
     PH_T(16);
-    const double gam = (double)W.Hdiag;
-    const double rho = ins ? 1.0 / (double)Hh.ro[t] : 1.0;
-    // The three m x m mat-vecs: 8 lanes per matrix row, every lane's (up to 13) elements requested before the first
-    // FMA - a phase is one L2 round trip, not one per stripe of the row.
-    constexpr int RL = 8, NK = (LB_HIST + RL - 1) / RL;      // lanes per row, elements per lane
-    const int l8 = tid & (RL - 1);
-    auto row8_sum = [](double v) {                            // 8-lane butterfly (lanes of a group are DPP neighbours)
-        v += dpp_mov<DPP_XOR1>(v);
-        v += dpp_mov<DPP_XOR2>(v);
-        v += dpp_mov<DPP_HALF_MIRROR>(v);
-        return v;
-    };
-    // ---- rows of R^-1: c = -R^-1 u / rho (new column) and w = R^-1 p ----
-    for (int i = tid / RL; i < nE; i += NT / RL) {
-        const int si = slot_of(i);
-        const double* row = Hh.rinv + (size_t)si * HS;
-        double rv[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { const int j = min(i + l8 + RL * k, LB_HIST - 1); rv[k] = row[slot_of(min(j, n - 1))]; }
-        double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int j = i + l8 + RL * k;
-            if (j < nE) { d1 = fma(rv[k], (double)C.u[j], d1); d2 = fma(rv[k], (double)C.p[j], d2); }
-        }
-        d1 = row8_sum(d1); d2 = row8_sum(d2);
-        if (l8 == 0) {
-            double wi = d2;
-            if (ins) {
-                const double ci = -d1 / rho;
-                C.c[i] = ci;
-                wi = fma(ci, (double)C.p[n - 1], wi);
-                Hh.rinv[(size_t)si * HS + t] = ci;
-                Hh.rinvT[(size_t)t * HS + si] = ci;
-                const double yi = (double)C.yy[i];
-                Hh.yyg[(size_t)si * HS + t] = yi;
-                Hh.yyg[(size_t)t * HS + si] = yi;
+    // ---- w = R^-1 p ; new column of R^-1 ----
+    lb_cmp_tri<T, NT, true>(Hh, W, tid);
+    __syncthreads();
+    for (int r = tid; r < 128; r += NT) {
+        T wr = (T)0;
+        if (r < LB_HIST && lb_age(r, head) < n) {
+            if (r == t) {
+                wr = Hh.ro[t] * W.bvec[t];
+                Hh.rinv[lb_tri(t, t)] = Hh.ro[t];
+            } else {
+                wr = ((W.part2[0][0][r] + W.part2[0][1][r]) + W.part2[0][2][r]) + W.part2[0][3][r];
+                if (t >= 0) {
+                    const T cr = -(((W.part2[1][0][r] + W.part2[1][1][r]) + W.part2[1][2][r]) + W.part2[1][3][r]) * Hh.ro[t];
+                    Hh.rinv[lb_tri(r, t)] = cr;
+                    wr = fma(cr, W.bvec[t], wr);
+                }
             }
-            C.w[i] = wi;
         }
-    }
-    if (ins && tid == NT - 1) {
-        C.w[n - 1] = (double)C.p[n - 1] / rho;
-        C.c[n - 1] = 1.0 / rho;
-        Hh.rinv[(size_t)t * HS + t] = 1.0 / rho;
-        Hh.rinvT[(size_t)t * HS + t] = 1.0 / rho;
-        Hh.yyg[(size_t)t * HS + t] = (double)C.yy[n - 1];
+        W.alpha[r] = wr;
     }
     __syncthreads();
     PH_T(17);
-    // ---- z = (D + gamma Y^T Y) w - gamma q ----
-    for (int i = tid / RL; i < n; i += NT / RL) {
-        const int si = slot_of(i);
-        const double* row = Hh.yyg + (size_t)si * HS;
-        double rv[NK];
+    // ---- t = Y w - q ----
+    lb_cmp_matvec<T, NT>(Hh.dirs, Hh.ld, W.alpha, W, tid);
+    __syncthreads();
+    for (int e = tid; e < LB_D; e += NT) {
+        T sacc = W.part[0][e];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) rv[k] = row[slot_of(min(l8 + RL * k, n - 1))];
-        double d = 0.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { const int j = l8 + RL * k; if (j < n) d = fma(rv[k], C.w[j], d); }
-        d = row8_sum(d);
-        if (l8 == 0) C.z[i] = C.w[i] / (double)Hh.ro[si] + gam * (d - (double)C.q[i]);
+        for (int k = 1; k < 8; ++k) sacc += W.part[k][e];
+        W.tv[e] = e < Hh.ld ? sacc - W.qv[e] : (T)0;
     }
     __syncthreads();
     PH_T(18);
-    // ---- a = R^-T z: rows of the transposed copy; the newest pair's column is still in C.c ----
-    for (int j = tid / RL; j < n; j += NT / RL) {
-        const bool fresh = ins && j == n - 1;
-        const double* row = Hh.rinvT + (size_t)slot_of(j) * HS;
-        double rv[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { const int i = min(l8 + RL * k, n - 1); rv[k] = fresh ? C.c[i] : row[slot_of(i)]; }
-        double d = 0.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) { const int i = l8 + RL * k; if (i <= j) d = fma(rv[k], C.z[i], d); }
-        d = row8_sum(d);
-        if (l8 == 0) C.a[j] = d;
-    }
+    // ---- z = D w + gamma Y^T t ----
+    lb_cmp_rowdots<T, NT, false>(Hh, W, tid);
     __syncthreads();
     PH_T(19);
-    // ---- pass 2 over the history: d = gamma q + S a - gamma Y w ----
-    {
-        constexpr int NW = NT / 64;
-        const int wave = tid >> 6, lane = tid & 63;
-        if (LB_EPL * lane < LB_D) {
-            T a0 = (T)0, a1 = (T)0;
-            for (int j = wave; j < n; j += NW) {
-                const int sl = slot_of(j);
-                const T ca = (T)C.a[j], cw = (T)(-gam * C.w[j]);
-                a0 = fma(ca, Hh.stps[sl * LB_D + 2 * lane], a0);     a1 = fma(ca, Hh.stps[sl * LB_D + 2 * lane + 1], a1);
-                a0 = fma(cw, Hh.dirs[sl * LB_D + 2 * lane], a0);     a1 = fma(cw, Hh.dirs[sl * LB_D + 2 * lane + 1], a1);
-            }
-            W.part[wave][2 * lane] = a0;
-            W.part[wave][2 * lane + 1] = a1;
-        }
-        __syncthreads();
-        for (int e = tid; e < LB_D; e += NT) {
-            T sacc = (T)0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sacc += W.part[w][e];
-            W.dv[e] = fma((T)gam, W.qv[e], sacc);
-        }
-        __syncthreads();
-    }
+    // ---- a = R^-T z ----
+    lb_cmp_tri<T, NT, false>(Hh, W, tid);
+    __syncthreads();
+    for (int r = tid; r < 128; r += NT)
+        W.cvec[r] = (r < LB_HIST && lb_age(r, head) < n) ? ((W.part2[0][0][r] + W.part2[0][1][r]) + W.part2[0][2][r]) + W.part2[0][3][r] : (T)0;
+    __syncthreads();
     PH_T(20);
+    // ---- d = S a - gamma t ----
+    lb_cmp_matvec<T, NT>(Hh.stps, Hh.ld, W.cvec, W, tid);
+    __syncthreads();
+    for (int e = tid; e < LB_D; e += NT) {
+        T sacc = W.part[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sacc += W.part[k][e];
+        W.dv[e] = e < Hh.ld ? fma(-W.Hdiag, W.tv[e], sacc) : (T)0;
+    }
+    __syncthreads();
+    PH_T(21);
 }
 
 // d = -H g (lbfgs_ls.py:336-358) by the whole workgroup (NT threads, wave 0 = the optimiser wave).
 // In: W.qv = -g, W.n/head/ins_slot/Hdiag, history rows incl. the freshly inserted pair.  Out: W.dv.
+// (two-loop form: the history rows have stride LB_D here)
 template <typename T, int NT>
 __device__ __forceinline__ void lb_direction_block(const LbHist<T>& Hh, LbWork<T>& W, int tid, LbGramLds GL = LbGramLds{nullptr, 0, 0}) {
     // the window was requested before the optimiser advanced: it is usable if the ring head is where it was (or one
@@ -564,6 +660,7 @@ __device__ __forceinline__ int lbfgs_advance(LbState& S, LbVecs<T>& V, const LbH
     S.n = 0;
 
 L_iter:
+    PH_T(51);
     S.n += 1;
     S.n_iter += 1;
     S.n_lbfgs += 1;
@@ -586,14 +683,14 @@ L_iter:
             if (S.hist_len == O.history) S.hist_head = (S.hist_head + 1) % LB_HIST;
             else S.hist_len += 1;
             const int slot = (S.hist_head + S.hist_len - 1) % LB_HIST;
-            if (LB_EPL * lane < LB_D) {
+            if (LB_EPL * lane < Hh.ld) {                      // (elements past D are zero; ld is even)
 #pragma unroll
                 for (int e = 0; e < LB_EPL; ++e) {
-                    Hh.dirs[slot * LB_D + LB_EPL * lane + e] = y[e];
-                    Hh.stps[slot * LB_D + LB_EPL * lane + e] = s[e];
+                    Hh.dirs[slot * Hh.ld + LB_EPL * lane + e] = y[e];
+                    Hh.stps[slot * Hh.ld + LB_EPL * lane + e] = s[e];
                 }
             }
-            if (lane == 0) Hh.ro[slot] = (T)1 / ys;
+            if (lane == 0) { Hh.ro[slot] = (T)1 / ys; if (Hh.ys) Hh.ys[slot] = ys; }
             S.H = (double)(ys / vdot<T>(y, y));
             S.ins_slot = slot;
         }
@@ -605,6 +702,7 @@ L_iter:
             }
             if (lane == 0) { W.n = S.hist_len; W.head = S.hist_head; W.ins_slot = S.ins_slot; W.Hdiag = (T)S.H; }
             S.phase = PH_DIRECTION;
+            PH_T(52);
             return 1;
         }
 #pragma unroll
@@ -612,6 +710,7 @@ L_iter:
     }
     goto L_after_direction;
 L_have_direction:
+    PH_T(53);
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) V.d[e] = (LB_EPL * lane < LB_D) ? W.dv[LB_EPL * lane + e] : (T)0;
 L_after_direction:
@@ -637,6 +736,7 @@ L_after_direction:
     goto L_emit_trial;
 
 L_ls_first:
+    PH_T(48);
     S.ls_evals = 1;
     gtd_new = (double)vdot<T>(gnew, V.d);
     S.t_prev = 0.0; S.f_prev = S.f0; S.gtd_prev = S.gtd;
@@ -749,6 +849,7 @@ L_ls_zoom:                                                            // :130-16
     goto L_zoom_check;
 
 L_ls_return:                                                          // :163-167, :393-399
+    PH_T(50);
     {
         int l = S.low;
         S.loss = LB_SEL(S, bf, l);
@@ -815,6 +916,7 @@ L_step_return:
     }
 
 L_emit_trial:                                                         // _directional_evaluate :249-254
+    PH_T(54);
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) xt[e] = fma((T)S.t, V.d[e], V.x[e]);
     return 0;

@@ -53,6 +53,8 @@ struct FitBuffers {
     float* stps;         // [B][100][LB_D]
     float* grow;         // [B][LB_GSIZE] pre-scaled Gram matrices (lbfgs_device.h:LbHist)
     float* gcol;         // [B][LB_GSIZE]
+    float* rinv;         // [B][LB_RPACK] packed R^-1 of the compact direction form: the single-launch fit keeps it in LDS and parks
+                         // it here only when a launch ends at its round cap
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
     int* n_done;         // [2]: problems finished | problems that left the asynchronous phase (finished or paused at a stage boundary)
     VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // LEAN: the stage flags carry none of VPoser / GMM / 3-D term (the host checks) - said to the compiler as a fact about
 // the flag word, which lets it drop those branches from the round: 13 KB less code to stream through the instruction
 // cache every round (86 -> 73 KB), 1.2-1.6 % per fit (speed only: the result does not depend on it)
-template <bool REMOTE = false, bool REUSE = false, bool LEAN = false>
+template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false>
 __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
@@ -297,7 +299,10 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
     lbfgs_round<float, STEP_NT, REUSE>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
         PH_T(10);
-        lb_direction_block<float, STEP_NT>(H, L.lbW, tid, GL);
+        // the single-launch fit takes the direction in compact form (history and R^-1 in LDS, every phase on all waves);
+        // the chained step kernel keeps the two-loop form over its Gram matrices in global memory
+        if constexpr (COMPACT) lb_direction_compact<float, STEP_NT>(H, L.lbW, tid);
+        else lb_direction_block<float, STEP_NT>(H, L.lbW, tid, GL);
         PH_T(11); PH_ADD(15, 1);
     });
     if (tid < 64) {
@@ -314,6 +319,19 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     PH_T(12);
     return L.sh_status != 0;
 }
+
+// LDS layout of the single-launch fit behind the closure workspace: [s ring | y ring | packed R^-1].  Without VPoser the
+// tail starts over the decoder's arrays (the last members of ClosureLds) and a row holds the 86 active parameters; with
+// VPoser the active dimension is 49.
+constexpr int kHistLdFull = 88, kHistLdVp = 52;
+__host__ __device__ constexpr int persistent_hist_ld(bool vp) { return vp ? kHistLdVp : kHistLdFull; }
+__host__ __device__ constexpr size_t persistent_tail_offset(bool vp) {
+    return vp ? ((sizeof(ClosureLds) + 15) & ~(size_t)15) : offsetof(ClosureLds, vp_pre1);
+}
+__host__ __device__ constexpr size_t persistent_lds_bytes(bool vp) {
+    return persistent_tail_offset(vp) + ((size_t)2 * LB_HIST * persistent_hist_ld(vp) + LB_RPACK) * sizeof(float);
+}
+static_assert(persistent_lds_bytes(false) <= 160 * 1024 && persistent_lds_bytes(true) <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 
 __device__ __forceinline__ size_t step_lds_dev() { return (sizeof(ClosureLds) + 15) & ~(size_t)15; }
 
@@ -388,7 +406,12 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         return;
     }
     ClosureLds& L = *reinterpret_cast<ClosureLds*>(smem_raw);
-    float* hist = reinterpret_cast<float*>(smem_raw + ((sizeof(ClosureLds) + 15) & ~(size_t)15));   // [2][100][LB_D]
+    // behind (or, without VPoser, over the decoder's arrays at the end of) the closure workspace: the (s, y) ring, row
+    // stride = the active dimension rounded up, and the packed R^-1 of the compact direction form
+    const bool vp_mode = (SW.w[0].flags & MVFIT_F_VPOSER) != 0;                        // (flags are the same in all stages)
+    const int ldh = LEAN ? kHistLdFull : persistent_hist_ld(vp_mode);
+    float* hist = reinterpret_cast<float*>(smem_raw + (LEAN ? persistent_tail_offset(false) : persistent_tail_offset(vp_mode)));   // [2][100][ldh]
+    float* rinv = hist + 2 * LB_HIST * ldh;                                              // [LB_RPACK]
     const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + nprob): one sub-batch of mvfit_fit
     prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid);
     opts_in(L, SW, O, tid);
@@ -401,11 +424,20 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     if (tid == 64 * PUBLISH_WAVE) L.sh_pass_done = 0u;
     float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
     float* gs = F.stps + (size_t)b * LB_HIST * LB_D;
+    float* gr = F.rinv + (size_t)b * LB_RPACK;
     const bool resume = L.opt.lbS.n_closure > 0;          // relaunch after a round cap: restore the ring
-    if (resume)
-        for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { hist[i] = gd[i]; hist[LB_HIST * LB_D + i] = gs[i]; }
-    LbHist<float> H{hist, hist + LB_HIST * LB_D, L.opt.lb_ro, F.grow + (size_t)b * LB_GSIZE,
-                    F.gcol + (size_t)b * LB_GSIZE};
+    if (resume) {
+        for (int i = tid; i < LB_HIST * ldh; i += STEP_NT) {
+            const int r = i / ldh, e = i - r * ldh;
+            hist[i] = gd[r * LB_D + e]; hist[LB_HIST * ldh + i] = gs[r * LB_D + e];
+        }
+        for (int i = tid; i < LB_RPACK; i += STEP_NT) rinv[i] = gr[i];
+    } else {
+        // dead history rows / R^-1 entries are read with zero coefficients (branch-free phases): they must hold finite values
+        for (int i = tid; i < 2 * LB_HIST * ldh + LB_RPACK; i += STEP_NT) hist[i] = 0.f;
+    }
+    LbHist<float> H{hist, hist + LB_HIST * ldh, L.opt.lb_ro, nullptr, nullptr};
+    H.ys = L.opt.lb_ys; H.rinv = rinv; H.ld = ldh;
     __syncthreads();
     bool done = false, paused = false;
     for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
@@ -413,7 +445,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round<REMOTE, REUSE, LEAN>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
+        done = fit_round<REMOTE, REUSE, LEAN, true>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring.tag ? &ring : nullptr, (int)blockIdx.x);      // ring slots: sub-batch-relative problem index
         if (done) break;                                  // block-uniform
@@ -431,8 +463,13 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
             if (left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (!done)
-        for (int i = tid; i < LB_HIST * LB_D; i += STEP_NT) { gd[i] = hist[i]; gs[i] = hist[LB_HIST * LB_D + i]; }
+    if (!done) {
+        for (int i = tid; i < LB_HIST * ldh; i += STEP_NT) {
+            const int r = i / ldh, e = i - r * ldh;
+            gd[r * LB_D + e] = hist[i]; gs[r * LB_D + e] = hist[LB_HIST * ldh + i];
+        }
+        for (int i = tid; i < LB_RPACK; i += STEP_NT) gr[i] = rinv[i];
+    }
     if (REMOTE && L.vp_remote) {
         // goodbye to the helpers; the pose of the final point is decoded here (with the pre-activations the chained
         // rounds of a two-phase fit expect from their predecessor)
@@ -508,7 +545,6 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
     __shared__ double xs[LB_D], gs[LB_D];
     __shared__ double fsh;
     __shared__ LbWork<double> W;
-    __shared__ LbCompactWs<double> CW;
     const bool compact = (kind & 0x100) != 0;              // direction in compact form (lb_direction_compact)
     kind &= 0xff;
     const int lane = threadIdx.x;
@@ -517,7 +553,7 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
     S.phase = PH_STEP_START; S.H = 1.0;
     LbVecs<double> V;
     LbHist<double> H{dirs, stps, ro, grow, gcol};
-    H.rinv = cmat; H.rinvT = cmat + LB_HIST * LB_HIST; H.yyg = cmat + 2 * LB_HIST * LB_HIST;
+    H.rinv = cmat; H.ys = cmat + LB_RPACK;                // compact form: packed R^-1 and the diagonal y.s
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) {
         const int i = LB_EPL * lane + e;
@@ -545,7 +581,7 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
         for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
         lbfgs_round<double, 64, false>(S, V, H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
-            if (compact) lb_direction_compact<double, 64>(H, W, CW, lane);
+            if (compact) lb_direction_compact<double, 64>(H, W, lane);
             else lb_direction_block<double, 64>(H, W, lane);
         });
         if (S.status) break;
@@ -640,7 +676,7 @@ static T* dev_upload(mvfit_ctx* c, const std::vector<T>& h) {
 
 static size_t step_lds() { return (sizeof(ClosureLds) + 15) & ~(size_t)15; }
 static size_t step_gram_lds() { return step_lds() + LB_GW_BYTES; }       // fit_step_kernel: + the staged Gram window
-static size_t persistent_lds() { return step_lds() + (size_t)2 * LB_HIST * LB_D * sizeof(float); }
+static size_t persistent_lds(bool vp) { return std::max(persistent_lds_bytes(vp), sizeof(VpHelperLds)); }
 
 static void drop_graph(mvfit_ctx* c) {
     if (c->round_graph) { hipGraphExecDestroy(c->round_graph); c->round_graph = nullptr; }
@@ -669,7 +705,8 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     M.ntiles = (nv + TILE_V - 1) / TILE_V;
     M.nv_pad = M.ntiles * TILE_V;
     if (m->parents[0] >= 0) return fail(c, MVFIT_E_ARG, "parents[0] must be -1");
-    if (persistent_lds() > 160 * 1024) return fail(c, MVFIT_E_UNSUPPORTED, "LDS budget exceeded (%zu B)", persistent_lds());
+    if (persistent_lds(false) > 160 * 1024 || persistent_lds(true) > 160 * 1024)
+        return fail(c, MVFIT_E_UNSUPPORTED, "LDS budget exceeded (%zu / %zu B)", persistent_lds(false), persistent_lds(true));
     static_assert(sizeof(VpHelperLds) <= sizeof(ClosureLds), "the decoder helpers share the fit kernel's dynamic LDS");
 
     // ---- blendshape basis, re-tiled in MFMA B-operand order: [tile][coord][group][lane][4] ----
@@ -1046,7 +1083,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                           reinterpret_cast<const void*>(fit_persistent_kernel<false, true, false>),
                           reinterpret_cast<const void*>(fit_persistent_kernel<false, true, true>),
                           reinterpret_cast<const void*>(fit_persistent_kernel<true, true, false>)})
-        HIP_OK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persistent_lds()));
+        HIP_OK(c, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(persistent_lds(false), persistent_lds(true))));
     HIP_OK(c, hipHostMalloc(&c->h_done, 8));
     HIP_OK(c, hipDeviceSynchronize());
     return MVFIT_OK;
@@ -1056,7 +1093,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     drop_graph(c);
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
-                  c->F.grow, c->F.gcol, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
+                  c->F.grow, c->F.gcol, c->F.rinv, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
                   c->d_sdf_adj, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
     {
@@ -1128,6 +1165,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->F.pose, (size_t)B * sizeof(PoseBlock)));
         HIP_OK(c, hipMalloc(&c->F.dirs, (size_t)B * LB_HIST * LB_D * 4));
         HIP_OK(c, hipMalloc(&c->F.stps, (size_t)B * LB_HIST * LB_D * 4));
+        HIP_OK(c, hipMalloc(&c->F.rinv, (size_t)B * LB_RPACK * 4));
         HIP_OK(c, hipMalloc(&c->F.grow, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.gcol, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMemset(c->F.grow, 0, (size_t)B * LB_GSIZE * 4));
@@ -1523,7 +1561,7 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
     auto kern = M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true, false> : fit_persistent_kernel<true, false, false>)
                 : O.reuse_outer ? (lean ? fit_persistent_kernel<false, true, true> : fit_persistent_kernel<false, true, false>)
                 : lean ? fit_persistent_kernel<false, false, true> : fit_persistent_kernel<false, false, false>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds(), c->stream, M,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds((SW.w[0].flags & MVFIT_F_VPOSER) != 0), c->stream, M,
                        (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage);
     HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
@@ -1805,13 +1843,19 @@ extern "C" int mvfit_fit_trace(mvfit_ctx* c, float* trace, int max_closures) {
 }
 
 #ifdef MVFIT_TIMING
-extern "C" int mvfit_debug_timing(long long* out32, int reset) {
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing(long long* out32, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out32, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 32);
     if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z)); }
     return 0;
 }
-extern "C" int mvfit_debug_timing_helpers(long long* out16, int reset) {       // g_dbg[32..47]: decoder helper (set 0, slice 0)
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing_adv(long long* out16, int reset) {           // g_dbg[48..63]: inside lbfgs_advance
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16, sizeof(long long) * 48);
+    if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z), sizeof(long long) * 48); }
+    return 0;
+}
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing_helpers(long long* out16, int reset) {       // g_dbg[32..47]: decoder helper (set 0, slice 0)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16, sizeof(long long) * 32);
     if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z), sizeof(long long) * 32); }

@@ -1073,7 +1073,7 @@ hipError_t vertex_pass_configure() {
 }  // namespace mvfit
 
 #ifdef MVFIT_TIMING
-extern "C" int mvfit_debug_vp(long long* out16) {
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_vp(long long* out16) {
     (void)hipDeviceSynchronize();
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_vp), sizeof(long long) * 16);
 }

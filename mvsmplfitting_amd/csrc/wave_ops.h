@@ -11,7 +11,7 @@ namespace mvfit {
 
 // developer build (-DMVFIT_TIMING): per-phase shader-clock accumulation of workgroup 0
 #ifdef MVFIT_TIMING
-static __device__ long long g_dbg[48];
+static __device__ long long g_dbg[64];
 static __device__ long long g_dbg_last;
 #define PH_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_dbg[k] += now_ - g_dbg_last; g_dbg_last = now_; } } while (0)
 #define PH_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_last = clock64(); } while (0)
@@ -99,6 +99,20 @@ __device__ __forceinline__ void swap_pair(double v, double& a, double& b) {
     else { swap16((unsigned)bits, la, lb); swap16((unsigned)(bits >> 32), ha, hb); }
     a = __builtin_bit_cast(double, ((unsigned long long)ha << 32) | la);
     b = __builtin_bit_cast(double, ((unsigned long long)hb << 32) | lb);
+}
+
+// A value that IS the same in every lane (a whole-wave reduction, a broadcast read) but that the compiler cannot prove
+// uniform: through v_readfirstlane it becomes a scalar, and every branch that depends on it a scalar branch instead of
+// an exec-masked region with its phi copies (the L-BFGS state machine is wave-uniform control flow on one wave).
+__device__ __forceinline__ float wave_uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double wave_uniform(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 
 // whole-wave total, bit-identical in every lane: 4 DPP steps inside the rows, then rows, then halves

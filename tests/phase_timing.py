@@ -2,7 +2,13 @@
 import sys, os, ctypes as C, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-subprocess.run('cd %s/mvsmplfitting_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include -DMVFIT_TIMING -shared vertex_pass.hip sdf_voxelize.hip sdf_term.hip init_guess.hip project.hip mvfit_api.hip -o ../libmvfit.so' % ROOT, shell=True, check=True)
+# the timing build: prebuilt in the build container (make -C mvsmplfitting_amd/csrc OUT=../libmvfit_timing.so OBJDIR=build_timing
+# EXTRA=-DMVFIT_TIMING; it travels with the snapshot), else compiled here
+TLIB = os.path.join(ROOT, 'mvsmplfitting_amd', 'libmvfit_timing.so')
+if not os.path.isfile(TLIB):
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'mvsmplfitting_amd', 'csrc'), '-j8', 'OUT=../libmvfit_timing.so', 'OBJDIR=build_timing',
+                    'EXTRA=-DMVFIT_TIMING'], check=True)
+os.environ['MVFIT_LIBRARY'] = TLIB
 import numpy as np, torch
 from mvsmplfitting_amd import _lib, synthetic as syn
 from mvsmplfitting_amd.engine import MvFit, stage_weights
@@ -18,9 +24,11 @@ gt, conf = syn.make_observations(joints.cpu().numpy(), cams); eng.set_problems(c
 x0 = np.zeros((B,118), np.float32); x0[:,85]=1
 buf = (C.c_longlong*32)()
 hb = (C.c_longlong*16)()
+ab = (C.c_longlong*16)()
 for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS), ('vposer_sparse_helpers_off', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
     os.environ['MVFIT_VP_HELPERS'] = '0' if name.endswith('off') else '1'
     lib.mvfit_debug_timing_helpers(hb, 1)
+    lib.mvfit_debug_timing_adv(ab, 1)
     lib.mvfit_debug_timing(buf, 1)
     xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
     lib.mvfit_debug_timing(buf, 1)
@@ -31,6 +39,8 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     print('    step-kernel prologue=%.0f epilogue (state store + pose/chain of next x + publish)=%.0f' % (buf[24]/n, buf[25]/n))
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
     print('    vposer (helpers: request sent / answers in / summed ; adjoint: joints / answers in / summed): L1=%.0f L2=%.0f out=%.0f | (GS+quat in pose_prep rest) | bwd: joints=%.0f W3T=%.0f W2T=%.0f (W1T in E9 rest)' % tuple(buf[i]/n for i in (26,27,28,29,30,31)))
+    lib.mvfit_debug_timing_adv(ab, 1)
+    print('    inside advance (cycles per round): ' + ' | '.join('%s=%.0f' % (nm, ab[i]/n) for i, nm in enumerate(['entry->ls_first', 'gtd dot', 'wolfe checks->ls_return', 'ls_return->iter', 'iter->insert done', 'dir end->resume', 'resume->emit'])))
     lib.mvfit_debug_timing_helpers(hb, 1)
     if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
     if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
