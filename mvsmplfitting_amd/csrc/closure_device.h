@@ -55,7 +55,7 @@ struct OptBlock {                   // optimiser state that survives between clo
     float lb_ro[104];               // ro = 1/(y.s) per history slot
     float lb_ys[104];               // y.s per history slot (the diagonal of the compact form, lbfgs_device.h)
     LbState lbS;
-    float lbV[LB_NVEC][LB_D];
+    LbVecs<float> lbV[LB_LANES];    // the optimiser's working vectors, lane-major (lbfgs_device.h)
 };
 struct VpBlock {                    // VPoser decoder state of the current trial point (image of ClosureLds::vp_pre1..vp_cpad)
     float pre1[512];
@@ -140,7 +140,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
                                          const VpBlock* vp_g = nullptr) {
     constexpr int n16 = sizeof(ModelLds) / 16;
     constexpr int nobs = sizeof(ObsBlock) / 16, npose = sizeof(PoseBlock) / 16, nopt = sizeof(OptBlock) / 16;
-    static_assert(n16 <= 3 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
+    static_assert(n16 <= 4 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
     const int4* src = reinterpret_cast<const int4*>(M.mlds);
     const int4 zi = make_int4(0, 0, 0, 0);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -148,6 +148,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     const int4 m0 = src[min(tid, n16 - 1)];
     const int4 m1 = src[min(tid + STEP_NT, n16 - 1)];
     const int4 m2 = src[min(tid + 2 * STEP_NT, n16 - 1)];
+    const int4 m3 = src[min(tid + 3 * STEP_NT, n16 - 1)];
     (void)zi;
     const float4 vobs = (obs_g && tid < nobs) ? reinterpret_cast<const float4*>(obs_g)[tid] : z;
     const float4 vpose = (pose_g && tid < npose) ? reinterpret_cast<const float4*>(pose_g)[tid] : z;
@@ -162,6 +163,7 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     if (tid < n16) dst[tid] = m0;
     if (tid + STEP_NT < n16) dst[tid + STEP_NT] = m1;
     if (tid + 2 * STEP_NT < n16) dst[tid + 2 * STEP_NT] = m2;
+    if (tid + 3 * STEP_NT < n16) dst[tid + 3 * STEP_NT] = m3;
     if (obs_g && tid < nobs) reinterpret_cast<float4*>(&L.obs)[tid] = vobs;
     if (pose_g) { if (tid < npose) reinterpret_cast<float4*>(&L.pose)[tid] = vpose; }
     else if (tid >= 256 && tid < 256 + 8 * 12) (&L.pose.Mj[NJ][0])[tid - 256] = 0.f;     // "no child" rows
@@ -538,44 +540,6 @@ __device__ __forceinline__ void vposer_backward(const DevModel& M, ClosureLds& L
 
 constexpr int FWD_SLICES = 8, FWD_RPS = KROWS / FWD_SLICES;      // 28 basis rows per k-slice of the forward contraction
 
-// The same stream split in two: the loads do not depend on the trial point (pd_sub is a model constant), so the fit
-// kernels request a thread's 28 rows BEFORE the pose phase and run the FMAs once the coefficients exist - the stream
-// (186 KB through one CU: ~5 k cycles) then flies under Rodrigues / J(beta) / the relative transforms instead of
-// standing in front of the skinning.  One item per thread (true for every keypoint set up to 56 vertices); with more
-// items than threads the caller keeps contraction_forward.
-struct FwdPrefetch { float4 v[FWD_RPS]; int cq, ks; bool on; };
-
-__device__ __forceinline__ bool fwd_prefetch_fits(const ClosureLds& L) { return (L.M.nc_pad >> 2) * FWD_SLICES <= STEP_NT - 64; }
-
-__device__ __forceinline__ void contraction_forward_issue(const DevModel& M, int nc_pad, int tid, FwdPrefetch& F) {
-    const int ncq = nc_pad >> 2, item = tid - 64;
-    F.on = item >= 0 && item < ncq * FWD_SLICES;
-    const int it = F.on ? item : 0;
-    F.cq = it % ncq;
-    F.ks = (it / ncq + (int)blockIdx.x) & (FWD_SLICES - 1);
-    if (F.on) {
-        const float4* src = reinterpret_cast<const float4*>(M.pd_sub) + (size_t)(F.ks * FWD_RPS) * ncq + F.cq;
-#pragma unroll
-        for (int r = 0; r < FWD_RPS; ++r) F.v[r] = src[(size_t)r * ncq];
-    }
-}
-
-__device__ __forceinline__ void contraction_forward_finish(ClosureLds& L, const FwdPrefetch& F) {
-    if (!F.on) return;
-    const int nc_pad = L.M.nc_pad;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-#pragma unroll
-    for (int r = 0; r < FWD_RPS; r += 2) {
-        const float c0 = L.coef[F.ks * FWD_RPS + r], c1 = L.coef[F.ks * FWD_RPS + r + 1];
-        acc0.x = fmaf(c0, F.v[r].x, acc0.x); acc0.y = fmaf(c0, F.v[r].y, acc0.y);
-        acc0.z = fmaf(c0, F.v[r].z, acc0.z); acc0.w = fmaf(c0, F.v[r].w, acc0.w);
-        acc1.x = fmaf(c1, F.v[r + 1].x, acc1.x); acc1.y = fmaf(c1, F.v[r + 1].y, acc1.y);
-        acc1.z = fmaf(c1, F.v[r + 1].z, acc1.z); acc1.w = fmaf(c1, F.v[r + 1].w, acc1.w);
-    }
-    float4* dst = reinterpret_cast<float4*>(L.scratch + F.ks * nc_pad + 4 * F.cq);
-    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
-}
-
 // ---------------------------------------------------------------------------------------------
 // E1: x -> theta, R, J, blendshape coefficients, relative transforms.   lbs.py:183-195,269-348
 // Every thread derives what it needs straight from x (Rodrigues is recomputed per output element)
@@ -806,18 +770,11 @@ __device__ __forceinline__ void keypoints_from_xs(ClosureLds& L, int tid) {
 // E2 + E3: chain || forward contraction, then v_posed, T rows (lbs.py:209-213) and skinned positions.
 // from_pass: L.vposed / L.xs of the selected vertices were written by the kernel prologue from the
 // vertex pass's side outputs (full mode); run_chain = false when the pose block (G, A) is already in LDS.
-__device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass, int tid, bool run_chain = true,
-                               const FwdPrefetch* pf = nullptr) {
+__device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L, bool from_pass, int tid, bool run_chain = true) {
     const int nc = L.M.nc, nc_pad = L.M.nc_pad;
     const int nks = fwd_slices(nc_pad, STEP_NT - 64);
-    if (pf) {
-        // basis rows already in registers (requested before the pose phase): the FMAs, then the chain by the whole
-        // workgroup in pointer-jumping form (4 steps instead of the one wave's 9 dependent passes - with the stream out
-        // of the way the chain is what this phase waits for); its barriers also publish the partial sums
-        contraction_forward_finish(L, *pf);
-        PH_T(22);
-        chain_forward_block(L, tid);
-    } else if (run_chain || !from_pass) {
+    if (run_chain || !from_pass) {
+        // wave 0: the kinematic chain; waves 1-7: the forward basis stream (k-split partial sums) - overlapped
         if (tid < 64) { if (run_chain) chain_forward_wave(L, tid); PH_T(22); }
         else if (!from_pass) contraction_forward(M, L, tid - 64, STEP_NT - 64);
         __syncthreads();
@@ -1115,61 +1072,6 @@ __device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, in
     }
 }
 
-// The transposed stream split like the forward one: pd_subT is a constant, so a thread's (up to) 36 column words are
-// requested at the top of the adjoint and multiplied in E7 - the 186 KB then arrive under E5 and E6 instead of next to
-// the chain adjoint (which is what E7 then waits for).  56 row groups x 8 slices = 448 items = the threads of
-// waves 1-7, always one item per thread.
-struct BwdPrefetch { float4 v[BWD_CPS]; };
-#ifdef MVFIT_NO_BWD_PREFETCH            // developer A/B switches (tests/quick_async.py with MVFIT_LIBRARY)
-constexpr bool kBwdPrefetch = false;
-#else
-constexpr bool kBwdPrefetch = true;
-#endif
-#ifdef MVFIT_NO_FWD_PREFETCH
-constexpr bool kFwdPrefetch = false;
-#else
-constexpr bool kFwdPrefetch = true;
-#endif
-
-__device__ __forceinline__ void contraction_backward_issue(const DevModel& M, int nc_pad, int tid, BwdPrefetch& F) {
-    constexpr int npq = KROWS >> 2;
-    if (tid < 64) return;
-    const int item = tid - 64;
-    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;
-    const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
-    const int c0 = cs * cps;
-    const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
-#pragma unroll
-    for (int r = 0; r < BWD_CPS; ++r) {
-        const int c = min(c0 + r, nc_pad - 1);
-        if (r < cps) F.v[r] = src[(size_t)c * npq];
-    }
-}
-
-__device__ __forceinline__ void contraction_backward_finish(ClosureLds& L, int tid, const BwdPrefetch& F) {
-    constexpr int npq = KROWS >> 2;
-    if (tid < 64) return;
-    const int item = tid - 64;
-    const int nc_pad = L.M.nc_pad;
-    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;
-    const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
-    const int c0 = cs * cps;
-    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-#pragma unroll
-    for (int r = 0; r < BWD_CPS; r += 2) {
-        if (r < cps) {
-            const float g0 = (c0 + r < nc_pad) ? L.gvp[c0 + r] : 0.f;
-            const float g1 = (c0 + r + 1 < nc_pad) ? L.gvp[c0 + r + 1] : 0.f;
-            acc0.x = fmaf(g0, F.v[r].x, acc0.x); acc0.y = fmaf(g0, F.v[r].y, acc0.y);
-            acc0.z = fmaf(g0, F.v[r].z, acc0.z); acc0.w = fmaf(g0, F.v[r].w, acc0.w);
-            acc1.x = fmaf(g1, F.v[r + 1].x, acc1.x); acc1.y = fmaf(g1, F.v[r + 1].y, acc1.y);
-            acc1.z = fmaf(g1, F.v[r + 1].z, acc1.z); acc1.w = fmaf(g1, F.v[r + 1].w, acc1.w);
-        }
-    }
-    float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
-    *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward).
 // Ends with __syncthreads; L.grad holds the flat gradient.
@@ -1180,9 +1082,6 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
     __syncthreads();                  // L.gkp (view sums) and L.gtau are written after E4's last barrier
     const float sdf_fac = L.sdf_fac;
-    // the transposed basis stream of E7 is requested here: it flies under E5 and E6 (two light phases)
-    BwdPrefetch pbk;
-    if (kBwdPrefetch) contraction_backward_issue(M, nc_pad, tid, pbk);
     // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
     if (tid < nc_pad) {
         float v = 0.f;
@@ -1247,8 +1146,9 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     __syncthreads();
     PH_T(5);
     // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
+    // (measured: the two overlap - the one-wave walk up the tree, 5 k cycles, hides the 186 KB stream; the whole-workgroup
+    // form of the adjoint, chain_backward_block, is shorter alone but runs behind the stream: +0.7-1.1 us per round)
     if (tid < 64) { chain_backward_wave(L, tid); PH_T(23); }
-    else if (kBwdPrefetch) contraction_backward_finish(L, tid, pbk);
     else contraction_backward(M, L, tid - 64, STEP_NT - 64);
     const int ncs = bwd_slices(STEP_NT - 64);
     __syncthreads();

@@ -377,37 +377,37 @@ __device__ __forceinline__ void lb_cmp_rowdots(const LbHist<T>& Hh, LbWork<T>& W
     const bool two = FIRST && t >= 0;
     const int q4 = tid & 3, nch = ld >> 2;
     constexpr int NCH = (LB_D / 4 + 3) / 4;               // 4-element chunks per lane (ld <= LB_D)
-    T vv[NCH][4], yn[NCH][4];
-    int cc[NCH];
+    constexpr int HB = NCH / 2;                            // two batches of chunks: half the registers of one batch of six
+    static_assert(NCH % 2 == 0, "two batches");
     const T* vec = FIRST ? W.qv : W.tv;
     const T* ynew = Hh.dirs + max(t, 0) * ld;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = q4 + 4 * k;
-        const bool ok = ch < nch;
-        cc[k] = 4 * min(ch, nch - 1);                      // clamped chunk: the surplus lanes re-read the last chunk with zero coefficients
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T v = vec[cc[k] + j], y = FIRST ? ynew[cc[k] + j] : (T)0;
-            vv[k][j] = ok ? v : (T)0;
-            yn[k][j] = (ok && two) ? y : (T)0;
-        }
-    }
     const T* rows = FIRST ? Hh.stps : Hh.dirs;
     for (int r0 = tid >> 2; r0 < 128; r0 += NT / 4) {
         const int r = min(r0, LB_HIST - 1);
         const bool live = r0 < LB_HIST && lb_age(r, head) < n;
         const T* row = rows + r * ld;
-        T rv[NCH][4];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[k][j] = row[cc[k] + j];
         T a0 = (T)0, a1 = (T)0;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k)
+        for (int hb = 0; hb < 2; ++hb) {
+            T vv[HB][4], yn[HB][4], rv[HB][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a0 = fma(rv[k][j], vv[k][j], a0); if (FIRST) a1 = fma(rv[k][j], yn[k][j], a1); }
+            for (int k = 0; k < HB; ++k) {
+                const int ch = q4 + 4 * (hb * HB + k);
+                const bool ok = ch < nch;
+                const int cc = 4 * min(ch, nch - 1);           // clamped chunk: the surplus lanes re-read the last chunk with zero coefficients
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const T v = vec[cc + j], y = FIRST ? ynew[cc + j] : (T)0;
+                    vv[k][j] = ok ? v : (T)0;
+                    yn[k][j] = (ok && two) ? y : (T)0;
+                    rv[k][j] = row[cc + j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a0 = fma(rv[k][j], vv[k][j], a0); if (FIRST) a1 = fma(rv[k][j], yn[k][j], a1); }
+        }
         a0 += dpp_mov<DPP_XOR1>(a0); a0 += dpp_mov<DPP_XOR2>(a0);
         if (FIRST) { a1 += dpp_mov<DPP_XOR1>(a1); a1 += dpp_mov<DPP_XOR2>(a1); }
         const T ysw = FIRST ? (T)0 : Hh.ys[r] * W.alpha[r];
@@ -922,6 +922,143 @@ L_emit_trial:                                                         // _direct
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The optimiser state lives in MEMORY between closure rounds (LDS in the fit kernels): LbState + the seven working
+// vectors, LANE-MAJOR - lane l's two elements of x, d, g, pg, gprev, bg0, bg1 are one LbVecs<T> (14 words) - so that the
+// state machine can work on the memory image IN PLACE: lbfgs_advance(S, V, ...) takes references, and with references
+// into LDS it holds nothing but temporaries in registers (as register copies the 60 + 14 words of state, carried
+// through its control-flow graph, cost more spills than the rest of the kernel together).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LB_LANES = 64;
+
+// The two transitions that make up three quarters of all rounds, as straight-line code on the state in memory - the same
+// arithmetic, in the same order, as the walk of lbfgs_advance through the same labels (the general machine carries its 60
+// words of state and 14 vector registers through a control-flow graph of ~2000 instructions; a round through it costs
+// ~9 k cycles on its one wave).  Nothing is modified unless the transition applies; -1 = not applicable, the caller runs
+// lbfgs_advance on the untouched state.  A -DMVFIT_LB_CHECK build runs both and compares every word (lbfgs_round).
+//
+// (1) the first trial point of a line search satisfies the strong Wolfe conditions and no stopping test fires: accept
+//     (lbfgs_ls.py:54-69, 163-167, 393-434), open the next iteration, accept the curvature pair (:318-335) and hand the
+//     two-loop recursion to the workgroup.  Returns 1 (direction needed) like lbfgs_advance.
+template <typename T>
+__device__ __forceinline__ int lb_fast_accept(LbState* Sm, LbVecs<T>* Vl, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
+                                              double f_new, const T* gnew, int lane) {
+    if (wave_uniform(Sm->phase) != PH_LS_FIRST) return -1;
+    const double c1 = 1e-4, c2 = 0.9;
+    const bool in = LB_EPL * lane < LB_D;
+    const int i0 = in ? LB_EPL * lane : 0;
+    LbVecs<T>& V = Vl[lane];                                  // (lanes past the vector hold zeros)
+    T x[LB_EPL], d[LB_EPL], g[LB_EPL];
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) { x[e] = V.x[e]; d[e] = V.d[e]; g[e] = V.g[e]; }
+    const double t = Sm->t, gtd = Sm->gtd, f0 = Sm->f0, prev_loss = Sm->prev_loss, d_norm = Sm->d_norm;
+    const int n = Sm->n, cur = Sm->cur_evals + 1, hist_len0 = Sm->hist_len, head0 = Sm->hist_head;
+    const double gtd_new = (double)vdot<T>(gnew, d);
+    bool ok = !(f_new > (f0 + c1 * t * gtd)) && (fabs(gtd_new) <= -c2 * gtd);                  // :56, :63
+    ok = ok && n != O.max_iter && cur < O.max_eval;                                                // :419-423
+    ok = ok && !(vmaxabs(gnew) <= O.tol_grad);                                                     // :425
+    ok = ok && !(d_norm * fabs(t) <= O.tol_change) && !(fabs(f_new - prev_loss) < O.tol_change);   // :428-434
+    // the curvature pair of the next iteration (:318-335; g - prev_g with prev_g == the gradient the search started from)
+    T y[LB_EPL], sv[LB_EPL];
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) { y[e] = gnew[e] - g[e]; sv[e] = d[e] * (T)t; }
+    const T ys = vdot<T>(y, sv);
+    const bool acc_pair = ys > (T)1e-10;
+    int hist_len = hist_len0, head = head0;
+    if (acc_pair) {
+        if (hist_len == O.history) head = (head + 1) % LB_HIST; else hist_len += 1;
+    }
+    ok = ok && hist_len > 0;
+    if (!wave_uniform((int)ok)) return -1;
+    // ---- commit ----
+    int slot = -1;
+    double Hn = Sm->H;
+    if (acc_pair) {
+        slot = (head + hist_len - 1) % LB_HIST;
+        if (LB_EPL * lane < Hh.ld) {
+#pragma unroll
+            for (int e = 0; e < LB_EPL; ++e) {
+                Hh.dirs[slot * Hh.ld + LB_EPL * lane + e] = y[e];
+                Hh.stps[slot * Hh.ld + LB_EPL * lane + e] = sv[e];
+            }
+        }
+        if (lane == 0) { Hh.ro[slot] = (T)1 / ys; if (Hh.ys) Hh.ys[slot] = ys; }
+        Hn = (double)(ys / vdot<T>(y, y));
+    }
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) {
+        V.gprev[e] = g[e];                                                  // gprev = g                  (:46 of the search)
+        V.bg0[e] = gnew[e];                                                 // bracket_g[0]
+        V.g[e] = gnew[e];                                                   // flat_grad = g_new          (:397)
+        V.x[e] = fma((T)t, d[e], x[e]);                                     // x += t d                   (:398)
+        if (in) W.qv[i0 + e] = -gnew[e];
+    }
+    if (lane == 0) {
+        Sm->n_closure += 1;
+        Sm->ls_evals = 1; Sm->t_prev = 0.0; Sm->f_prev = f0; Sm->gtd_prev = gtd; Sm->ls_it = 0;
+        Sm->br0 = t; Sm->bf0 = f_new; Sm->bgtd0 = gtd_new; Sm->nbr = 1; Sm->ls_done = 1;
+        Sm->insuf = 0; Sm->low = 0; Sm->high = 1;
+        Sm->loss = f_new; Sm->t = t; Sm->cur_evals = cur;
+        Sm->n = n + 1; Sm->n_iter += 1; Sm->n_lbfgs += 1;
+        Sm->ins_slot = slot; Sm->hist_len = hist_len; Sm->hist_head = head; Sm->H = Hn;
+        Sm->phase = PH_DIRECTION;
+        W.n = hist_len; W.head = head; W.ins_slot = slot; W.Hdiag = (T)Hn;
+    }
+    return 1;
+}
+
+// (2) behind the direction: the next search starts (lbfgs_ls.py:360-380, 43-53) unless the directional derivative says
+//     stop.  Returns 0 (trial point emitted into xt) like lbfgs_advance.
+template <typename T>
+__device__ __forceinline__ int lb_fast_resume(LbState* Sm, LbVecs<T>* Vl, LbWork<T>& W, const LbOpts& O, T* xt, int lane) {
+    if (wave_uniform(Sm->phase) != PH_DIRECTION) return -1;
+    const bool in = LB_EPL * lane < LB_D;
+    const int i0 = in ? LB_EPL * lane : 0;
+    LbVecs<T>& V = Vl[lane];
+    T x[LB_EPL], d[LB_EPL], g[LB_EPL];
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) { x[e] = V.x[e]; d[e] = in ? W.dv[i0 + e] : (T)0; g[e] = V.g[e]; }
+    const double loss = Sm->loss, t = O.lr;                                  // (n_iter > 1 behind a direction: t = lr, :372-373)
+    const double gtd = (double)vdot<T>(g, d);
+    if (wave_uniform((int)(gtd > -O.tol_change))) return -1;               // :379-380 -> the general machine ends the step
+    const double d_norm = vmaxabs(d);
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) { V.d[e] = d[e]; V.pg[e] = g[e]; }
+    if (lane == 0) {
+        Sm->prev_loss = loss; Sm->t = t; Sm->gtd = gtd; Sm->d_norm = d_norm; Sm->f0 = loss; Sm->ls_evals = 0;
+        Sm->phase = PH_LS_FIRST;
+    }
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) xt[e] = fma((T)t, d[e], x[e]);
+    return 0;
+}
+
+#ifdef MVFIT_LB_CHECK
+static __device__ unsigned g_lb_check[4];      // [0] fast transitions checked, [1] mismatching words, [2] first mismatching word index + 1
+template <typename T>
+__device__ __forceinline__ void lb_check_compare(const LbState& Sa, const LbVecs<T>& Va, const LbState* Sm, const LbVecs<T>* Vl, int lane) {
+    unsigned bad = 0, first = 0;
+    const unsigned* a = reinterpret_cast<const unsigned*>(&Sa);
+    const unsigned* b = reinterpret_cast<const unsigned*>(Sm);
+    for (int i = 0; i < (int)(sizeof(LbState) / 4); ++i) {
+        // pad words and the reuse flag the fast path does not touch are compared too: both start from the same image
+        if (a[i] != b[i]) { bad += 1; if (!first) first = (unsigned)i + 1; }
+    }
+    const LbVecs<T> Vb = Vl[lane];
+    unsigned vb = 0;
+#pragma unroll
+    for (int e = 0; e < LB_EPL; ++e) {
+        vb += (Va.x[e] != Vb.x[e]) + (Va.d[e] != Vb.d[e]) + (Va.g[e] != Vb.g[e]) + (Va.pg[e] != Vb.pg[e]) +
+              (Va.gprev[e] != Vb.gprev[e]) + (Va.bg0[e] != Vb.bg0[e]) + (Va.bg1[e] != Vb.bg1[e]);
+    }
+    vb = (unsigned)wave64_sum((float)vb);
+    if (lane == 0) {
+        atomicAdd(&g_lb_check[0], 1u);
+        if (bad + vb) { atomicAdd(&g_lb_check[1], bad + vb); if (first) atomicMax(&g_lb_check[2], first); else atomicMax(&g_lb_check[2], 1000u); }
+    }
+}
+#endif
+
 // One optimiser round, shared by every kernel that drives the state machine (fit_step_kernel, fit_persistent_kernel,
 // lbfgs_kat_kernel): consume (f_new, gnew) of the closure just evaluated; when the machine asks for a search
 // direction, run `direction()` with the whole workgroup and resume WITH THE SAME (f_new, gnew) - the resumed call may
@@ -930,16 +1067,40 @@ L_emit_trial:                                                         // _direct
 // optimiser wave; S, V, gnew, xt are meaningful in wave 0 only).  On return xt = the next trial point.
 // REUSE: the instantiation for O.reuse_outer (MVFIT_F_REUSE_OUTER_VALUE); without it the round is the plain two-call form.
 template <typename T, int NT, bool REUSE, typename DirFn>
-__device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
+__device__ __forceinline__ void lbfgs_round(LbState* Sm, LbVecs<T>* Vl, const LbHist<T>& Hh, LbWork<T>& W, const LbOpts& O,
                                             double f_new, const T* gnew, T* xt, int tid, double* stage_final,
                                             DirFn&& direction) {
+    // one call of the state machine on the state in memory: the fast transitions first, else the general walk IN PLACE
+    // (nothing of the state is live in registers across direction()).  which: 0 = a closure was evaluated, 1 = resumed
+    // behind a direction.
+    auto call = [&](int which, double fv, const T* gv, bool virt) -> int {
+        const int lane = tid;
+#ifdef MVFIT_LB_CHECK
+        LbState S0 = *Sm;
+        LbVecs<T> V0 = Vl[lane];
+#endif
+        int need = -1;
+        if (which == 1) need = lb_fast_resume<T>(Sm, Vl, W, O, xt, lane);
+        else if (!virt) need = lb_fast_accept<T>(Sm, Vl, Hh, W, O, fv, gv, lane);
+#ifdef MVFIT_LB_CHECK
+        if (need >= 0) {           // the general machine on the snapshot must arrive at the same words (it rewrites the same history row / work vectors)
+            T xt2[LB_EPL];
+            const int need2 = lbfgs_advance<T>(S0, V0, Hh, W, O, fv, gv, xt2, lane, stage_final, virt);
+            lb_check_compare(S0, V0, Sm, Vl, lane);
+            if (lane == 0 && need2 != need) atomicAdd(&g_lb_check[1], 1000000u);
+            if (which == 1) { unsigned d_ = 0; for (int e = 0; e < LB_EPL; ++e) d_ += xt2[e] != xt[e]; if (d_) atomicAdd(&g_lb_check[1], 100000u); }
+        }
+#endif
+        if (need < 0) need = lbfgs_advance<T>(*Sm, Vl[lane], Hh, W, O, fv, gv, xt, lane, stage_final, virt);      // wave-uniform branch
+        return need;
+    };
     if constexpr (!REUSE) {
-        // advance; if it asks for a direction: direction, advance again - written as a two-trip loop that is NOT unrolled,
-        // so that the state machine is in the kernel once (~10 KB less code per round to stream through the instruction cache)
+        // call; if it asks for a direction: direction, call again - written as a two-trip loop that is NOT unrolled, so that
+        // the state machine is in the kernel once (~10 KB less code per round to stream through the instruction cache)
 #pragma nounroll
         for (int trip = 0; trip < 2; ++trip) {
             if (tid < 64) {
-                const int need = lbfgs_advance<T>(S, V, Hh, W, O, f_new, gnew, xt, tid, stage_final);
+                const int need = call(trip, f_new, gnew, false);
                 if (tid == 0 && trip == 0) W.need_dir = need;
             }
             if (trip == 1) break;
@@ -951,8 +1112,8 @@ __device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHi
     }
     // Opt-in reuse (O.reuse_outer, a kernel argument: uniform): while the machine sits at a step start whose opening
     // closure call would return what it already holds, (loss, g) are fed back without an evaluation - further passes of
-    // the same loop, so that the state machine stays inlined at two call sites.  Bounded: every pass either emits a
-    // line-search trial point (a real closure follows) or ends a step / stage.
+    // the same loop.  Bounded: every pass either emits a line-search trial point (a real closure follows) or ends a
+    // step / stage.
     T gv[LB_EPL];
     double fv = f_new;
     if (tid < 64) {
@@ -962,24 +1123,25 @@ __device__ __forceinline__ void lbfgs_round(LbState& S, LbVecs<T>& V, const LbHi
     bool virt = false;
     for (int guard = 0; guard < 64; ++guard) {
         if (tid < 64) {
-            const int need = lbfgs_advance<T>(S, V, Hh, W, O, fv, gv, xt, tid, stage_final, virt);
+            const int need = call(0, fv, gv, virt);
             if (tid == 0) W.need_dir = need;
         }
         __syncthreads();
         if (W.need_dir) {                                  // block-uniform
             direction();
-            if (tid < 64) lbfgs_advance<T>(S, V, Hh, W, O, fv, gv, xt, tid, stage_final, virt);
+            if (tid < 64) call(1, fv, gv, virt);
         }
         __syncthreads();
-        if (tid == 0) W.need_dir = (S.phase == PH_STEP_START && S.reuse_ok && !S.status) ? 1 : 0;
+        if (tid == 0) W.need_dir = (Sm->phase == PH_STEP_START && Sm->reuse_ok && !Sm->status) ? 1 : 0;
         __syncthreads();
         if (!W.need_dir) return;                           // block-uniform
         if (tid < 64) {
 #pragma unroll
-            for (int e = 0; e < LB_EPL; ++e) gv[e] = V.g[e];
-            fv = S.loss;
-            S.reuse_ok = 0;
+            for (int e = 0; e < LB_EPL; ++e) gv[e] = Vl[tid].g[e];
+            fv = Sm->loss;
         }
+        __syncthreads();                                   // (every lane has read the flag / the loss)
+        if (tid == 0) Sm->reuse_ok = 0;
         virt = true;
         __syncthreads();                                   // W.need_dir is rewritten by the next pass
     }

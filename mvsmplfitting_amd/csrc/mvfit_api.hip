@@ -176,28 +176,6 @@ __global__ __launch_bounds__(64) void joints_kernel(DevModel M, const float* __r
     }
 }
 
-__device__ __forceinline__ void lb_load(LbVecs<float>& V, const float* base, int lane) {
-#pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) {
-        const int i = LB_EPL * lane + e;
-        const bool in = i < LB_D;
-        V.x[e] = in ? base[0 * LB_D + i] : 0.f; V.d[e] = in ? base[1 * LB_D + i] : 0.f;
-        V.g[e] = in ? base[2 * LB_D + i] : 0.f; V.pg[e] = in ? base[3 * LB_D + i] : 0.f;
-        V.gprev[e] = in ? base[4 * LB_D + i] : 0.f; V.bg0[e] = in ? base[5 * LB_D + i] : 0.f;
-        V.bg1[e] = in ? base[6 * LB_D + i] : 0.f;
-    }
-}
-__device__ __forceinline__ void lb_store(const LbVecs<float>& V, float* base, int lane) {
-#pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) {
-        const int i = LB_EPL * lane + e;
-        if (i < LB_D) {
-            base[0 * LB_D + i] = V.x[e]; base[1 * LB_D + i] = V.d[e]; base[2 * LB_D + i] = V.g[e];
-            base[3 * LB_D + i] = V.pg[e]; base[4 * LB_D + i] = V.gprev[e]; base[5 * LB_D + i] = V.bg0[e];
-            base[6 * LB_D + i] = V.bg1[e];
-        }
-    }
-}
 __device__ __forceinline__ void opts_in(ClosureLds& L, const StageWeights& SW, const LbOpts& O, int tid) {
     constexpr int nsw = sizeof(StageWeights) / 4, nop = sizeof(LbOpts) / 4;
     if (tid < nsw) reinterpret_cast<int*>(&L.sw[0])[tid] = reinterpret_cast<const int*>(&SW)[tid];
@@ -218,7 +196,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
     for (int i = tid; i < (int)(sizeof(OptBlock) / 4); i += STEP_NT) reinterpret_cast<float*>(&L.opt)[i] = 0.f;
     __syncthreads();
     if (tid < DPAD) L.opt.x[tid] = xv;
-    if (tid < LB_D) L.opt.lbV[0][tid] = xc;
+    if (tid < LB_D) L.opt.lbV[tid / LB_EPL].x[tid % LB_EPL] = xc;
     if (tid == 0) { L.opt.lbS.phase = PH_STEP_START; L.opt.lbS.H = 1.0; }
     if (tid < MVFIT_MAX_STAGES) F.stage_final[(size_t)b * MVFIT_MAX_STAGES + tid] = (double)NAN;
     __syncthreads();
@@ -253,17 +231,12 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     PH_T0();
     // have_pose: the previous launch left the pose block of this x (and, with VPoser, the decoder state the
     // adjoint needs - the VpBlock)
-    // the two 186 KB streams of the objective-vertex basis do not depend on the trial point: each thread's share is
-    // requested a phase or more ahead of its use (closure_device.h: FwdPrefetch / BwdPrefetch)
-    FwdPrefetch pf;
-    const bool pre_f = kFwdPrefetch && !from_pass && !have_pose && fwd_prefetch_fits(L);          // block-uniform
     if (!have_pose) {
-        pose_prep_decode<REMOTE>(M, L, W.flags, tid);
-        if (pre_f) contraction_forward_issue(M, L.M.nc_pad, tid, pf);
+        pose_prep_decode_inl<REMOTE>(M, L, W.flags, tid);
         pose_prep_elems(M, L, W.flags, tid);
     }
     PH_T(0);
-    sparse_forward(M, L, from_pass, tid, !have_pose, pre_f ? &pf : nullptr);
+    sparse_forward(M, L, from_pass, tid, !have_pose);
     PH_T(2);
     // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
@@ -282,13 +255,9 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     closure_backward<REMOTE>(M, L, nviews, W, tid);
     if (ring) publish_tag(*ring, a_slot, pb, a_round, tid);                // the stores have long drained by now
     PH_T(8);
-    LbState S;
-    LbVecs<float> V;
     float gnew[LB_EPL], xt[LB_EPL];
     const int D = dact(use_vp);
     if (tid < 64) {
-        S = L.opt.lbS;
-        lb_load(V, &L.opt.lbV[0][0], tid);
         PH_T(9);
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) {
@@ -296,8 +265,9 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
             gnew[e] = i < D ? L.grad[cmap(i, use_vp)] : 0.f;
         }
     }
+    // the optimiser state stays in LDS (L.opt.lbS, L.opt.lbV): lbfgs_round works on it in place
     // the reference reads the loss as a float32 tensor (float(closure()), lbfgs_ls.py:251,281)
-    lbfgs_round<float, STEP_NT, REUSE>(S, V, H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
+    lbfgs_round<float, STEP_NT, REUSE>(&L.opt.lbS, &L.opt.lbV[0], H, L.lbW, O, (double)(float)total, gnew, xt, tid, stage_final, [&]() {
         PH_T(10);
         // the single-launch fit takes the direction in compact form (history and R^-1 in LDS, every phase on all waves);
         // the chained step kernel keeps the two-loop form over its Gram matrices in global memory
@@ -311,9 +281,8 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
             const int i = LB_EPL * tid + e;
             if (i < D) L.opt.x[cmap(i, use_vp)] = xt[e];
         }
-        lb_store(V, &L.opt.lbV[0][0], tid);
-        if (tid == 0) { L.opt.lbS = S; L.sh_stage = min(S.stage, O.num_stages - 1); L.sh_status = S.status; }
-        PH_ADD(13, 1); PH_ADD(14, S.hist_len);
+        if (tid == 0) { L.sh_stage = min(L.opt.lbS.stage, O.num_stages - 1); L.sh_status = L.opt.lbS.status; }
+        PH_ADD(13, 1); PH_ADD(14, L.opt.lbS.hist_len);
     }
     __syncthreads();
     PH_T(12);
@@ -477,7 +446,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         if (tid == 0) { vps_store(vps_request_slot(M.vps), 0.f, (L.vp_seq + 1u) << 2 | VPS_BYE); L.vp_remote = 0; }
         __syncthreads();
     }
-    pose_and_chain<true>(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
+    pose_and_chain<false>(M, L, __builtin_amdgcn_readfirstlane(L.sw[L.sh_stage].flags), tid);
     publish_pose(L, P, b, tid);
     if (paused) {
         // what the chained rounds' step kernel expects from its predecessor: the pose block of the trial point (+ the
@@ -548,21 +517,28 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
     const bool compact = (kind & 0x100) != 0;              // direction in compact form (lb_direction_compact)
     kind &= 0xff;
     const int lane = threadIdx.x;
-    LbState S;
-    memset(&S, 0, sizeof(S));
-    S.phase = PH_STEP_START; S.H = 1.0;
-    LbVecs<double> V;
+    // the state in memory, like the fit kernels keep it (lbfgs_round works on it in place)
+    __shared__ LbState S;
+    __shared__ LbVecs<double> Vm[LB_LANES];
+    if (lane == 0) {
+        memset(&S, 0, sizeof(S));
+        S.phase = PH_STEP_START; S.H = 1.0;
+    }
     LbHist<double> H{dirs, stps, ro, grow, gcol};
     H.rinv = cmat; H.ys = cmat + LB_RPACK;                // compact form: packed R^-1 and the diagonal y.s
+    double xt[LB_EPL];
 #pragma unroll
     for (int e = 0; e < LB_EPL; ++e) {
         const int i = LB_EPL * lane + e;
-        V.x[e] = i < D ? x_io[i] : 0.0;
-        V.d[e] = V.g[e] = V.pg[e] = V.gprev[e] = V.bg0[e] = V.bg1[e] = 0.0;
+        xt[e] = i < D ? x_io[i] : 0.0;
     }
-    double xt[LB_EPL];
+    {
+        LbVecs<double> z;
 #pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) xt[e] = V.x[e];
+        for (int e = 0; e < LB_EPL; ++e) { z.x[e] = xt[e]; z.d[e] = z.g[e] = z.pg[e] = z.gprev[e] = z.bg0[e] = z.bg1[e] = 0.0; }
+        Vm[lane] = z;
+    }
+    __syncthreads();
     int ncl = 0;
     for (int round = 0; round < 100000; ++round) {
 #pragma unroll
@@ -580,14 +556,15 @@ __global__ __launch_bounds__(64) void lbfgs_kat_kernel(int kind, int D, LbOpts O
 #pragma unroll
         for (int e = 0; e < LB_EPL; ++e) gnew[e] = (LB_EPL * lane + e < D) ? gs[LB_EPL * lane + e] : 0.0;
         __syncthreads();
-        lbfgs_round<double, 64, false>(S, V, H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
+        lbfgs_round<double, 64, false>(&S, &Vm[0], H, W, O, f, gnew, xt, lane, final_loss, [&]() {   // the production round
             if (compact) lb_direction_compact<double, 64>(H, W, lane);
             else lb_direction_block<double, 64>(H, W, lane);
         });
+        __syncthreads();
         if (S.status) break;
     }
 #pragma unroll
-    for (int e = 0; e < LB_EPL; ++e) if (LB_EPL * lane + e < D) x_io[LB_EPL * lane + e] = V.x[e];
+    for (int e = 0; e < LB_EPL; ++e) if (LB_EPL * lane + e < D) x_io[LB_EPL * lane + e] = Vm[lane].x[e];
     if (lane == 0) *n_closure = ncl;
 }
 
@@ -1842,6 +1819,15 @@ extern "C" int mvfit_fit_trace(mvfit_ctx* c, float* trace, int max_closures) {
     return MVFIT_OK;
 }
 
+#ifdef MVFIT_LB_CHECK
+// check build: [0] fast optimiser transitions cross-checked against the general state machine, [1] mismatches, [2] first word
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_lb_check(unsigned* out4, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out4, HIP_SYMBOL(mvfit::g_lb_check), sizeof(unsigned) * 4);
+    if (reset) { unsigned z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_lb_check), z, sizeof(z)); }
+    return 0;
+}
+#endif
 #ifdef MVFIT_TIMING
 extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing(long long* out32, int reset) {
     hipDeviceSynchronize();

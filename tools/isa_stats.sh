@@ -23,7 +23,7 @@ for name, priv, sg, sgs, vg, vgs in meta:
     cnt = lambda pat: sum(1 for l in body if re.search(pat, l))
     ins = sum(1 for l in body if l.startswith('\t') and not l.startswith('\t.') and not l.startswith('\t;'))
     short = re.sub(r'_ZN5mvfit\d+', '', name)[:44]
-    print('%-44s vgpr %3s sgpr-spill %3s scratch %4s B | instr %5d barriers %2d scratch ld/st %3d/%3d global ld %3d lds r/w %3d/%3d f64 %3d exec-branch %3d'
-          % (short, vg, sgs, priv, ins, cnt(r's_barrier'), cnt(r'scratch_load'), cnt(r'scratch_store'), cnt(r'global_load'),
+    print('%-44s vgpr %3s sgpr-spill %3s vgpr-spill %3s scratch %4s B | instr %5d barriers %2d scratch ld/st %3d/%3d global ld %3d lds r/w %3d/%3d f64 %3d exec-branch %3d'
+          % (short, vg, sgs, vgs, priv, ins, cnt(r's_barrier'), cnt(r'scratch_load'), cnt(r'scratch_store'), cnt(r'global_load'),
              cnt(r'ds_read|ds_load'), cnt(r'ds_write|ds_store'), cnt(r'_f64'), cnt(r's_cbranch_exec')))
 PY
