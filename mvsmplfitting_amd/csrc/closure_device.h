@@ -142,23 +142,23 @@ __device__ __forceinline__ void prologue(ClosureLds& L, const DevModel& M, const
     constexpr int nobs = sizeof(ObsBlock) / 16, npose = sizeof(PoseBlock) / 16, nopt = sizeof(OptBlock) / 16;
     static_assert(n16 <= 4 * STEP_NT && nobs <= STEP_NT && npose <= STEP_NT && nopt <= STEP_NT, "one word per thread");
     const int4* src = reinterpret_cast<const int4*>(M.mlds);
-    const int4 zi = make_int4(0, 0, 0, 0);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     // (clamped indices instead of predicated loads: the surplus words are simply not stored)
     const int4 m0 = src[min(tid, n16 - 1)];
     const int4 m1 = src[min(tid + STEP_NT, n16 - 1)];
     const int4 m2 = src[min(tid + 2 * STEP_NT, n16 - 1)];
     const int4 m3 = src[min(tid + 3 * STEP_NT, n16 - 1)];
-    (void)zi;
-    const float4 vobs = (obs_g && tid < nobs) ? reinterpret_cast<const float4*>(obs_g)[tid] : z;
-    const float4 vpose = (pose_g && tid < npose) ? reinterpret_cast<const float4*>(pose_g)[tid] : z;
-    const float4 vopt = (opt_g && tid < nopt) ? reinterpret_cast<const float4*>(opt_g)[tid] : z;
-    const float4 vvps = (vposed_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(vposed_g)[tid] : z;
-    const float4 vxss = (xs_g && tid < NC_MAX / 4) ? reinterpret_cast<const float4*>(xs_g)[tid] : z;
+    // (plain conditional loads into zero-initialised values: a select between a loaded word and a zero CONSTANT OBJECT would
+    // put that object - 16 bytes of scratch - on the stack)
+    float4 vobs = make_float4(0.f, 0.f, 0.f, 0.f), vpose = vobs, vopt = vobs, vvps = vobs, vxss = vobs, vvp = vobs;
+    if (obs_g && tid < nobs) vobs = reinterpret_cast<const float4*>(obs_g)[tid];
+    if (pose_g && tid < npose) vpose = reinterpret_cast<const float4*>(pose_g)[tid];
+    if (opt_g && tid < nopt) vopt = reinterpret_cast<const float4*>(opt_g)[tid];
+    if (vposed_g && tid < NC_MAX / 4) vvps = reinterpret_cast<const float4*>(vposed_g)[tid];
+    if (xs_g && tid < NC_MAX / 4) vxss = reinterpret_cast<const float4*>(xs_g)[tid];
     const float xv = (x_g && tid < DV) ? x_g[tid] : 0.f;
     constexpr int nvp = sizeof(VpBlock) / 16;
     static_assert(nvp <= STEP_NT, "one word per thread");
-    const float4 vvp = (vp_g && tid < nvp) ? reinterpret_cast<const float4*>(vp_g)[tid] : z;
+    if (vp_g && tid < nvp) vvp = reinterpret_cast<const float4*>(vp_g)[tid];
     int4* dst = reinterpret_cast<int4*>(&L.M);
     if (tid < n16) dst[tid] = m0;
     if (tid + STEP_NT < n16) dst[tid + STEP_NT] = m1;

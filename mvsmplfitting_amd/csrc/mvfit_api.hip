@@ -219,7 +219,7 @@ template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPA
 __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
-                          const AsyncRing* ring = nullptr, int pb = 0) {
+                          const AsyncRing& ring = AsyncRing{}, bool use_ring = false, int pb = 0) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     if constexpr (LEAN) {
@@ -240,9 +240,9 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     PH_T(2);
     // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
-    const unsigned a_round = ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
-    const int a_slot = ring ? (int)(a_round % (unsigned)ring->nslots) : 0;
-    if (ring) publish_pose_async(L, *ring, a_slot, a_round, pb, tid);
+    const unsigned a_round = use_ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
+    const int a_slot = use_ring ? (int)(a_round % (unsigned)ring.nslots) : 0;
+    if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, tid);
     const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
     PH_T(3);
     if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
@@ -253,7 +253,7 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
         }
     }
     closure_backward<REMOTE>(M, L, nviews, W, tid);
-    if (ring) publish_tag(*ring, a_slot, pb, a_round, tid);                // the stores have long drained by now
+    if (use_ring) publish_tag(ring, a_slot, pb, a_round, tid);             // the stores have long drained by now
     PH_T(8);
     float gnew[LB_EPL], xt[LB_EPL];
     const int D = dact(use_vp);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         asm volatile("" : "+v"(t));
         done = fit_round<REMOTE, REUSE, LEAN, true>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
-                         ring.tag ? &ring : nullptr, (int)blockIdx.x);      // ring slots: sub-batch-relative problem index
+                         ring, ring.tag != nullptr, (int)blockIdx.x);       // ring slots: sub-batch-relative problem index
         if (done) break;                                  // block-uniform
         // two-phase fit (stages without the SDF term run here, the rest in chained rounds): leave at the stage boundary -
         // the trial point in L.opt.x is the first one of the next stage, the optimiser is fresh (non_linear_solver.py:172)
