@@ -90,11 +90,21 @@ def load_serial_joints3d(frames, person=0):
 
 def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, image_height=1536.0, is_seq=False,
                pose_format='lsp14', use_hip=True, use_3d=False, fix_scale=None, fix_shape=None, save_meshes=False,
-               mesh_folder=None, device=0, stages=None, engine: MvFit | None = None):
+               mesh_folder=None, device=0, stages=None, engine: MvFit | None = None, timing: dict | None = None):
     """Fits every frame under keyp_root and writes the reference's result files.  Returns
     {serial: dict(frames, params [F,118], final_loss [F], n_closure [F], files [F], init [F,118], restarted [F]:
     frames fitted from their own initial guess - all of them unless is_seq, used_3d [F]: frames fitted with the 3-D joint
-    term, views_per_frame [F])}."""
+    term, views_per_frame [F])}.  ``timing``: a dict that receives the wall-clock seconds of the four steps of the pipeline
+    (read = directory walk + keypoint / camera files, init_guess, fit, write = decoded pose + result files [+ meshes]),
+    summed over the serials - the end-to-end figure next to the reference's only timer (code/main.py:27,91-94)."""
+    import time as _time
+
+    def _tick(key, t0):
+        if timing is not None:
+            torch.cuda.synchronize(eng.device)
+            timing[key] = timing.get(key, 0.0) + (_time.time() - t0)
+        return _time.time()
+    _t = _time.time()
     extris, intris = iof.load_camera_para(cam_file)
     use_vposer = vposer is not None
     flags = _lib.F_VPOSER if use_vposer else 0
@@ -110,6 +120,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
         jw[11] = jw[12] = 0.0
     results = {}
     try:
+        _t = _tick('read', _t)
         for serial, cams, frames in list_frames(keyp_root):
             V, F = len(cams), len(frames)
             if F == 0 or V < 1:
@@ -126,6 +137,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
             gt_xy = kp[..., :2].copy()
             conf = kp[..., 2] * jw[None, None, :]
             eng.set_problems(rig, gt_xy, conf)
+            _t = _tick('read', _t)
             # 3-D joint targets (non_linear_solver.py:86-99) and the initial alignment to them instead of the triangulation
             # (init_guess.py:84-85) - decided PER FRAME like the reference (:68-69): frames with an annotation are fitted with
             # the 3-D term, the others without it (two batched fits when a serial mixes both)
@@ -153,6 +165,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                     guess[k][idx] = g3[k]
                 eng.set_problems(rig, gt_xy, conf)
             x0 = initial_params(guess, use_vposer, fixed_shape=fix_shape)
+            _t = _tick('init_guess', _t)
 
             def stages_for(with_3d):
                 if user_stages is None:
@@ -191,6 +204,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
                 if has.any() and not has.all():
                     eng.set_problems(rig, gt_xy, conf)
                 restarted = np.ones(F, bool)
+            _t = _tick('fit', _t)
             full = eng.full_pose(xf, flags=flags & ~_lib.F_USE_3D).cpu().numpy()
             xf_h, final_h = xf.cpu().numpy(), final.cpu().numpy()
             res = [iof.result_dict(xf_h[f], loss=final_h[f], body_pose_decoded=full[f, 3:] if use_vposer else None)
@@ -209,6 +223,7 @@ def fit_folder(model: dict, keyp_root, cam_file, result_folder, *, vposer=None, 
             results[serial] = dict(frames=[fr[0] for fr in frames], params=xf_h, final_loss=final_h,
                                    n_closure=ncl.cpu().numpy(), files=files, init=x0.cpu().numpy(), restarted=restarted,
                                    used_3d=has.copy(), views_per_frame=vmask.sum(1))
+            _t = _tick('write', _t)
     finally:
         if own:
             eng.close()
