@@ -663,6 +663,11 @@ def main():
                                         closures_fp32=int(g['fit_ncl32'].sum()), closures_fp64=int(g['fit_ncl64'].sum()),
                                         final_loss_spread_fp32=[float(v) for v in g['fit_spread32']],
                                         note='the reference itself on these inputs in the build container (oracle/make_golden_demo.py)')
+        if os.environ.get('MVFIT_SDF_STATS_REPORT'):            # developer: work counters of the all-faces term (libmvfit_sdfstats.so)
+            import ctypes as C
+            st = (C.c_ulonglong * 8)()
+            eng._lib.mvfit_debug_sdf_stats(st, 0)
+            print('sdf stats', [int(v) for v in st], file=sys.stderr)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

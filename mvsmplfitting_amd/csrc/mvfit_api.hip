@@ -30,7 +30,12 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
 hipError_t vertex_pass_configure();
 hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
-                           int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream);
+                           int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
+                           void* cull);
+size_t sdf_cull_bytes(int B, int num_faces);
+size_t sdf_cull_zero_offset(int B, int num_faces);
+size_t sdf_cull_zero_bytes(int B);
+int sdf_cull_min_faces();
 size_t sdf_work_bytes(int B, int nv);
 size_t sdf_ticket_offset(int B, int nv);
 hipError_t launch_triangulate(const float* kps, const double* intris, const double* extris, int B, int V, int J, double* out,
@@ -622,6 +627,7 @@ struct mvfit_ctx {
     float4* d_sdf_samp = nullptr;      // [B][nv]
     void* d_sdf_entries = nullptr;     // [B][nv] entry list
     SdfAdj* d_sdf_adj = nullptr;       // [B]
+    void* d_sdf_cull = nullptr;        // face lists of the all-faces term (sdf_term.hip), sized for (B, sdf_num_faces)
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
@@ -1071,7 +1077,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.rinv, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
-                  c->d_sdf_adj, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
+                  c->d_sdf_adj, c->d_sdf_cull, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
     {
         void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats, c->ring.pass_done};
@@ -1085,7 +1091,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     c->P = DevPose{};
     c->d_verts = nullptr;
     c->F = FitBuffers{};
-    c->d_sdf_box = nullptr; c->d_sdf_samp = nullptr; c->d_sdf_entries = nullptr; c->d_sdf_adj = nullptr;
+    c->d_sdf_box = nullptr; c->d_sdf_samp = nullptr; c->d_sdf_entries = nullptr; c->d_sdf_adj = nullptr; c->d_sdf_cull = nullptr;
 }
 
 extern "C" void mvfit_destroy(mvfit_ctx* c) {
@@ -1188,6 +1194,7 @@ extern "C" int mvfit_set_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, 
     HIP_OK(c, hipStreamSynchronize(c->stream));
     drop_graph(c);
     if (c->d_sdf_faces) { hipFree(c->d_sdf_faces); c->d_sdf_faces = nullptr; }
+    if (c->d_sdf_cull) { hipFree(c->d_sdf_cull); c->d_sdf_cull = nullptr; }          // sized by the face count
     c->sdf_num_faces = 0; c->sdf_grid = 0;
     if (!faces || num_faces == 0) return MVFIT_OK;                 // term switched off
     if (num_faces < 0 || grid_size < 2 || grid_size > 1024)
@@ -1217,6 +1224,16 @@ extern "C" int mvfit_sdf_term_read(mvfit_ctx* c, float* samples, float* sums) {
 
 // work buffers of the SDF term for the current batch
 static int ensure_sdf_buffers(mvfit_ctx* c) {
+    // all faces (or any list too long for the staged walk): the per-round face lists of sdf_term.hip.  MVFIT_SDF_CULL=0
+    // keeps the brute-force kernel (the check of the culled one).
+    if (!c->d_sdf_cull && c->sdf_num_faces >= sdf_cull_min_faces()) {
+        const char* e = getenv("MVFIT_SDF_CULL");
+        if (!(e && e[0] == '0')) {
+            HIP_OK(c, hipMalloc(&c->d_sdf_cull, sdf_cull_bytes(c->B, c->sdf_num_faces)));
+            HIP_OK(c, hipMemset(reinterpret_cast<unsigned char*>(c->d_sdf_cull) + sdf_cull_zero_offset(c->B, c->sdf_num_faces), 0,
+                                sdf_cull_zero_bytes(c->B)));
+        }
+    }
     if (c->d_sdf_adj) return MVFIT_OK;
     HIP_OK(c, hipMalloc(&c->d_sdf_box, (size_t)c->B * sizeof(SdfBox)));
     HIP_OK(c, hipMalloc(&c->d_sdf_samp, (size_t)c->B * c->nv * sizeof(float4)));
@@ -1228,7 +1245,7 @@ static int ensure_sdf_buffers(mvfit_ctx* c) {
 
 static int run_sdf_term(mvfit_ctx* c, const float* verts, const int* gate, hipStream_t st) {
     hipError_t e = launch_sdf_term(c->M, c->P, verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, gate, c->d_sdf_box,
-                                   c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, st);
+                                   c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, st, c->d_sdf_cull);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf term launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
 }
@@ -1421,7 +1438,7 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
             e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, cs);
             if (e == hipSuccess && c->F.sdf_adj)
                 e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
-                                    c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs);
+                                    c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs, c->d_sdf_cull);
             hipLaunchKernelGGL(O.reuse_outer ? fit_step_kernel<true> : fit_step_kernel<false>, dim3(c->B), dim3(STEP_NT), step_gram_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                c->P, c->F);
         }

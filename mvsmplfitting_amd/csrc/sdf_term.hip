@@ -62,10 +62,11 @@ __device__ __forceinline__ u64 wave64_key(u64 v) {
 // fitting.py:282-288 + :356-359.  First-occurrence arg indices (ties: lowest vertex index): the reductions
 // run on keys (ordered value << 32 | index) for the minima and (ordered value << 32 | ~index) for the maxima.
 __global__ __launch_bounds__(512) void sdf_bbox_kernel(const float* __restrict__ verts, int nv, const int* __restrict__ gate,
-                                                       SdfBox* __restrict__ box) {
+                                                       SdfBox* __restrict__ box, int* __restrict__ cull_flag) {
     __shared__ u64 s_k[8][6];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;                       // the problem's current stage has no SDF term (uniform)
+    if (cull_flag && tid == 0) cull_flag[b] = 0;        // "walk all faces" is decided anew by this round's count / scan kernels
     const float* vb = verts + (size_t)b * nv * 3;
     u64 kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
     for (int vbase = 0; vbase < nv; vbase += 512 * 16) {
@@ -219,6 +220,336 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_kernel(const float* __restr
     }
     const float hg = (float)G / 2.f;
     if (live) samp[(size_t)b * nv + v] = make_float4(val, gx * hg, gy * hg, gz * hg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// All faces (sdf_cuda_kernel.cu:258-287 walks every triangle for every voxel): exact culling.
+//
+// Both per-voxel quantities admit it.  Crossing parity: every test segment ends in the one point P = (-1,-1,-1), so the
+// rays form a pencil through P; with q = x - P (all components positive: the mesh is normalised into |x| <= 1/1.2, the
+// voxel centres lie above -1) the map x -> (q_x, q_y) / (q_x + q_y + q_z) sends a whole ray to ONE point of the unit
+// square and a triangle to the triangle of its projected vertices.  Triangles are binned by the bounding box of that
+// footprint - of the triangle thickened by SDF_CULL_DELTA in every direction, which covers by a wide margin the distance
+// at which the floating-point test (sdf_ray_hit) can still call a near miss a hit - into SDF_NB x SDF_NB bins; a voxel
+// tests the triangles of its bin whose nearest vertex (in q_x + q_y + q_z, which grows monotonically from P along a ray)
+// is not beyond the voxel.  A triangle is in a bin at most once, so the count of hits - the parity - is the brute-force one.
+// Minimum distance: triangles are binned by bounding box into SDF_NC^3 cells of [-1, 1]^3.  A corner the term samples
+// belongs to the cell of a mesh vertex v, so |corner - v| bounds the minimum from above (when v is a vertex of a listed
+// face); the triangles of the cells the box corner +- that radius overlaps contain every triangle closer than the radius,
+// the minimum over them is the minimum over all - the same sdf_tri_distance on the same SdfTri, so the same bits.  A
+// corner whose minimum comes out at the radius or above (v in no listed face) walks all triangles, as does a problem whose
+// lists overflow the workspace.
+// One counting sort per problem and round (count, scan, fill) builds both structures in one bin space.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SDF_NB = 256;                         // projective bins per axis (ray structure)
+constexpr int SDF_NC3 = 64;                         // cells per axis (distance structure)
+constexpr int SDF_NBINS = SDF_NB * SDF_NB + SDF_NC3 * SDF_NC3 * SDF_NC3;
+constexpr int SDF_OFFS_LD = SDF_NBINS + 4;           // row of the offsets (NBINS + 1 used), 16-byte aligned
+constexpr int SDF_CULL_CAP = 64;                    // list entries per face the workspace holds
+constexpr float SDF_CULL_DELTA = 2e-3f;
+constexpr int SDF_CULL_MIN_FACES = 4 * SDF_CH;      // below: the staged brute-force kernel
+
+struct SdfCullWs {               // per-problem slices of one allocation
+    SdfTri* tri;                 // [B][F]       pad[0] = min over the vertices of q_x + q_y + q_z
+    int* offs;                   // [B][SDF_OFFS_LD]
+    int* cnt;                    // [B][NBINS]   zero between rounds (count adds, fill takes away)
+    int2* ent;                   // [B][CAP * F]  {face, its pad[0] as bits}
+    int* flag;                   // [B]          1 = lists do not fit / a vertex outside the normalised box: walk all faces
+};
+static size_t cull_align(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t sdf_cull_bytes(int B, int num_faces) {
+    return cull_align((size_t)B * num_faces * sizeof(SdfTri)) + cull_align((size_t)B * SDF_OFFS_LD * 4) +
+           cull_align((size_t)B * SDF_NBINS * 4) + cull_align((size_t)B * SDF_CULL_CAP * num_faces * 8) + cull_align((size_t)B * 4);
+}
+size_t sdf_cull_zero_offset(int B, int num_faces) {          // the part that must be zero before the first round: cnt
+    return cull_align((size_t)B * num_faces * sizeof(SdfTri)) + cull_align((size_t)B * SDF_OFFS_LD * 4);
+}
+size_t sdf_cull_zero_bytes(int B) { return cull_align((size_t)B * SDF_NBINS * 4); }
+int sdf_cull_min_faces() { return SDF_CULL_MIN_FACES; }
+static SdfCullWs cull_views(void* ws, int B, int F) {
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
+    SdfCullWs w;
+    w.tri = reinterpret_cast<SdfTri*>(p); p += cull_align((size_t)B * F * sizeof(SdfTri));
+    w.offs = reinterpret_cast<int*>(p);   p += cull_align((size_t)B * SDF_OFFS_LD * 4);
+    w.cnt = reinterpret_cast<int*>(p);    p += cull_align((size_t)B * SDF_NBINS * 4);
+    w.ent = reinterpret_cast<int2*>(p);   p += cull_align((size_t)B * SDF_CULL_CAP * F * 8);
+    w.flag = reinterpret_cast<int*>(p);
+    return w;
+}
+
+struct SdfBinBox { int a0, a1, b0, b1, c0[3], c1[3]; bool bad; float min_s; };
+__device__ __forceinline__ int sdf_bin2(float a) { return min(SDF_NB - 1, max(0, (int)(a * (float)SDF_NB))); }
+__device__ __forceinline__ int sdf_cell3(float x) { return min(SDF_NC3 - 1, max(0, (int)((x + 1.0f) * (0.5f * (float)SDF_NC3)))); }
+// bins / cells of one triangle from its normalised vertices (the same code in the count and in the fill kernel)
+__device__ __forceinline__ SdfBinBox sdf_tri_bins(const float (&p)[3][3]) {
+    SdfBinBox o;
+    float amin = 2.f, amax = -1.f, bmin = 2.f, bmax = -1.f, smin = 1e30f;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    bool bad = false;
+    const float dl = SDF_CULL_DELTA;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const float qx = p[m][0] + 1.0f, qy = p[m][1] + 1.0f, qz = p[m][2] + 1.0f;
+        const float sq = qx + qy + qz;
+        bad = bad || !(qx > 8.f * dl && qy > 8.f * dl && qz > 8.f * dl && sq < 16.f);          // also catches NaN
+        amin = fminf(amin, (qx - dl) / (sq + dl)); amax = fmaxf(amax, (qx + dl) / (sq - dl));
+        bmin = fminf(bmin, (qy - dl) / (sq + dl)); bmax = fmaxf(bmax, (qy + dl) / (sq - dl));
+        smin = fminf(smin, sq);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[m][a]); hi[a] = fmaxf(hi[a], p[m][a]); }
+    }
+    o.a0 = sdf_bin2(amin); o.a1 = sdf_bin2(amax); o.b0 = sdf_bin2(bmin); o.b1 = sdf_bin2(bmax);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o.c0[a] = sdf_cell3(lo[a]); o.c1[a] = sdf_cell3(hi[a]); }
+    o.bad = bad; o.min_s = smin;
+    return o;
+}
+__device__ __forceinline__ void sdf_tri_points(const float* vb, const SdfBox& bx, const int32_t* faces, int f, float (&p)[3][3]) {
+    for (int m = 0; m < 3; ++m) {
+        const int vi = faces[3 * f + m];
+        for (int a = 0; a < 3; ++a) p[m][a] = (vb[3 * vi + a] - bx.c[a]) / bx.s;     // fitting.py:362-363
+    }
+}
+
+// thread per (problem, face): the face's record and its bin counts
+__global__ __launch_bounds__(256) void sdf_cull_count_kernel(const float* __restrict__ verts, int nv, const SdfBox* __restrict__ box,
+                                                             const int32_t* __restrict__ faces, int F, const int* __restrict__ gate,
+                                                             SdfCullWs W) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (gate && !gate[b]) return;
+    if (f >= F) return;
+    const SdfBox bx = box[b];
+    float p[3][3];
+    sdf_tri_points(verts + (size_t)b * nv * 3, bx, faces, f, p);
+    SdfTri T;
+    sdf_tri_setup(T, p[0], p[1], p[2]);
+    for (int q = 0; q < 3; ++q) { T.d12[q] = 0.f; T.pad[q] = 0.f; }
+    T.m12 = 0.f;
+    const SdfBinBox bb = sdf_tri_bins(p);
+    T.pad[0] = bb.min_s;
+    W.tri[(size_t)b * F + f] = T;
+    if (bb.bad) { atomicOr(&W.flag[b], 1); return; }               // (the flag was cleared by this round's box kernel)
+    int* cnt = W.cnt + (size_t)b * SDF_NBINS;
+    for (int ib = bb.b0; ib <= bb.b1; ++ib)
+        for (int ia = bb.a0; ia <= bb.a1; ++ia) atomicAdd(&cnt[ib * SDF_NB + ia], 1);
+    for (int kz = bb.c0[2]; kz <= bb.c1[2]; ++kz)
+        for (int ky = bb.c0[1]; ky <= bb.c1[1]; ++ky)
+            for (int kx = bb.c0[0]; kx <= bb.c1[0]; ++kx) atomicAdd(&cnt[SDF_NB * SDF_NB + (kz * SDF_NC3 + ky) * SDF_NC3 + kx], 1);
+}
+
+// one workgroup per problem: exclusive scan of the counts; lists that do not fit raise the flag
+constexpr int SDF_SCAN_NT = 1024;
+constexpr int SDF_SCAN_PER = SDF_NBINS / SDF_SCAN_NT;
+static_assert(SDF_NBINS % SDF_SCAN_NT == 0 && SDF_SCAN_PER % 4 == 0, "bins per scan thread");
+__global__ __launch_bounds__(SDF_SCAN_NT) void sdf_cull_scan_kernel(int F, const int* __restrict__ gate, SdfCullWs W) {
+    __shared__ int wsum[SDF_SCAN_NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (gate && !gate[b]) return;
+    const int4* cnt = reinterpret_cast<const int4*>(W.cnt + (size_t)b * SDF_NBINS + (size_t)tid * SDF_SCAN_PER);
+    int* offs = W.offs + (size_t)b * SDF_OFFS_LD + (size_t)tid * SDF_SCAN_PER;
+    int mine = 0;
+#pragma unroll 8
+    for (int k = 0; k < SDF_SCAN_PER / 4; ++k) { const int4 v = cnt[k]; mine += (v.x + v.y) + (v.z + v.w); }
+    int incl = mine;                                     // inclusive scan across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SDF_SCAN_NT / 64; ++w) { const int s = wsum[w]; if (w < wave) base += s; total += s; }
+    int run = base + incl - mine;
+#pragma unroll 8
+    for (int k = 0; k < SDF_SCAN_PER / 4; ++k) {
+        const int4 v = cnt[k];
+        int4 o;
+        o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
+        *reinterpret_cast<int4*>(offs + 4 * k) = o;
+    }
+    if (tid == 0) {
+        W.offs[(size_t)b * SDF_OFFS_LD + SDF_NBINS] = total;
+        if ((long long)total > (long long)SDF_CULL_CAP * F) atomicOr(&W.flag[b], 2);
+    }
+}
+
+// thread per (problem, face): the face's index into the lists of its bins (order within a list: arrival - the
+// results taken from a list, a count and a minimum, do not depend on it)
+__global__ __launch_bounds__(256) void sdf_cull_fill_kernel(const float* __restrict__ verts, int nv, const SdfBox* __restrict__ box,
+                                                            const int32_t* __restrict__ faces, int F, const int* __restrict__ gate,
+                                                            SdfCullWs W) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (gate && !gate[b]) return;
+    if (f >= F) return;
+    const SdfBox bx = box[b];
+    float p[3][3];
+    sdf_tri_points(verts + (size_t)b * nv * 3, bx, faces, f, p);
+    const SdfBinBox bb = sdf_tri_bins(p);
+    if (bb.bad) return;
+    const bool keep = W.flag[b] == 0;
+    int* cnt = W.cnt + (size_t)b * SDF_NBINS;
+    const int* offs = W.offs + (size_t)b * SDF_OFFS_LD;
+    int2* ent = W.ent + (size_t)b * SDF_CULL_CAP * F;
+    const int2 rec = make_int2(f, __builtin_bit_cast(int, bb.min_s));
+    for (int ib = bb.b0; ib <= bb.b1; ++ib)
+        for (int ia = bb.a0; ia <= bb.a1; ++ia) {
+            const int bin = ib * SDF_NB + ia;
+            const int k = atomicSub(&cnt[bin], 1) - 1;
+            if (keep) ent[offs[bin] + k] = rec;
+        }
+    for (int kz = bb.c0[2]; kz <= bb.c1[2]; ++kz)
+        for (int ky = bb.c0[1]; ky <= bb.c1[1]; ++ky)
+            for (int kx = bb.c0[0]; kx <= bb.c1[0]; ++kx) {
+                const int bin = SDF_NB * SDF_NB + (kz * SDF_NC3 + ky) * SDF_NC3 + kx;
+                const int k = atomicSub(&cnt[bin], 1) - 1;
+                if (keep) ent[offs[bin] + k] = rec;
+            }
+}
+
+#ifdef MVFIT_SDF_STATS
+__device__ unsigned long long g_sdf_stats[8];      // corners in range, ray tests, inside corners, distance tests, corners that walked all faces, ray tests skipped by depth
+#define SDF_STAT(k, v) atomicAdd(&g_sdf_stats[k], (unsigned long long)(v))
+#else
+#define SDF_STAT(k, v) do { } while (0)
+#endif
+// The sample kernel on the lists.  A vertex is served by 32 consecutive lanes (half a wave).  Parity: 4 lanes per corner
+// walk the corner's bin, strided.  Distance: the 32 lanes take the vertex' inside corners one after the other and walk the
+// cells around the corner, strided; a cell is left out when its box is farther than the best distance so far (or than the
+// sampled vertex, which bounds the minimum), the corner's own cell goes first.  A count and a minimum do not depend on the
+// order or on which lane met which face.
+constexpr int SDF_VPB = SDF_NT / 32;                // vertices per workgroup
+__device__ __forceinline__ float sdf_group_min32(float v) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+__global__ __launch_bounds__(SDF_NT) void sdf_sample_culled_kernel(const float* __restrict__ verts, int nv, const SdfBox* __restrict__ box,
+                                                                   int F, int G, const int* __restrict__ gate, SdfCullWs W,
+                                                                   float4* __restrict__ samp) {
+    const int b = blockIdx.y, v = blockIdx.x * SDF_VPB + (threadIdx.x >> 5), l = threadIdx.x & 31, cn = l >> 2, sub = l & 3;
+    if (gate && !gate[b]) return;
+    const bool live = v < nv;
+    const SdfBox bx = box[b];
+    const float* vb = verts + (size_t)b * nv * 3;
+    float loc[3] = {0.f, 0.f, 0.f}, fr[3];
+    int i0[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (live) loc[a] = (vb[3 * v + a] - bx.c[a]) / bx.s;
+        const float pix = ((loc[a] + 1.f) * (float)G - 1.f) / 2.f;
+        const float fl = floorf(pix);
+        i0[a] = (int)fl;
+        fr[a] = pix - fl;
+    }
+    const SdfTri* tri = W.tri + (size_t)b * F;
+    const int* offs = W.offs + (size_t)b * SDF_OFFS_LD;
+    const int2* ent = W.ent + (size_t)b * SDF_CULL_CAP * F;
+    const bool walk_all = W.flag[b] != 0;
+    // A box with a non-finite centre or scale (a fit that ran off to infinity) makes one coordinate of EVERY normalised
+    // face vertex NaN: each comparison of sdf_ray_hit then fails, no corner is inside, whatever the walk.  (And a finite box
+    // means finite vertices inside it: the only way to the walk-all flag that is left is a list overflow.)
+    const bool no_hits = !(fabsf(bx.c[0]) < INFINITY && fabsf(bx.c[1]) < INFINITY && fabsf(bx.c[2]) < INFINITY && fabsf(bx.s) < INFINITY) || bx.s == 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { SDF_STAT(6, W.flag[b] & 1); SDF_STAT(4, (W.flag[b] >> 1) & 1); SDF_STAT(7, 1); }
+    // ---- crossing parity of this lane's corner ----
+    bool inside;
+    {
+        const int ix = i0[0] + (cn & 1), iy = i0[1] + ((cn >> 1) & 1), iz = i0[2] + (cn >> 2);
+        const bool inrange = live && ix >= 0 && ix < G && iy >= 0 && iy < G && iz >= 0 && iz < G;
+        const float c[3] = {sdf_voxel_coord(ix, G), sdf_voxel_coord(iy, G), sdf_voxel_coord(iz, G)};
+        int n = 0;
+        if (inrange && !no_hits) {
+            if (!walk_all) {
+                const float qx = c[0] + 1.0f, qy = c[1] + 1.0f, qz = c[2] + 1.0f, sq = qx + qy + qz;
+                const int bin = sdf_bin2(qy / sq) * SDF_NB + sdf_bin2(qx / sq);
+                const float s_lim = sq + 3.f * SDF_CULL_DELTA;
+                const int e0 = offs[bin], e1 = offs[bin + 1];
+                if (sub == 0) SDF_STAT(0, 1);
+                for (int e = e0 + sub; e < e1; e += 4) {
+                    const int2 en = ent[e];
+                    if (__builtin_bit_cast(float, en.y) > s_lim) { SDF_STAT(5, 1); continue; }
+                    SDF_STAT(1, 1);
+                    n += sdf_ray_hit(tri[en.x], c) ? 1 : 0;
+                }
+            } else {
+                for (int f = sub; f < F; f += 4) n += sdf_ray_hit(tri[f], c) ? 1 : 0;
+            }
+        }
+        n += __shfl_xor(n, 1);
+        n += __shfl_xor(n, 2);
+        inside = inrange && (n & 1);
+    }
+    const unsigned long long bal = __ballot(inside && sub == 0);
+    const unsigned half = (unsigned)(bal >> (threadIdx.x & 32));          // this vertex' 32 lanes: bit 4 k = corner k
+    // ---- minimum distance of the inside corners, one corner at a time on the 32 lanes ----
+    float pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pv[k] = 0.f;
+        if (!((half >> (4 * k)) & 1u)) continue;
+        const float c[3] = {sdf_voxel_coord(i0[0] + (k & 1), G), sdf_voxel_coord(i0[1] + ((k >> 1) & 1), G), sdf_voxel_coord(i0[2] + (k >> 2), G)};
+        float md = 1000.f;
+        bool done = false;
+        if (!walk_all) {
+            // the sampled vertex is at most this far away (in the normalised frame the records are in)
+            const float rad = sdf_dist(c, loc) * 1.001f + 1e-6f;
+            float bound = rad;
+            int k0[3], k1[3], kc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { k0[a] = sdf_cell3(c[a] - rad); k1[a] = sdf_cell3(c[a] + rad); kc[a] = sdf_cell3(c[a]); }
+            if (l == 0) SDF_STAT(2, 1);
+            auto cell = [&](int kx, int ky, int kz) {
+                const int bin = SDF_NB * SDF_NB + (kz * SDF_NC3 + ky) * SDF_NC3 + kx;
+                const int e0 = offs[bin], e1 = offs[bin + 1];
+                if (l == 0) SDF_STAT(3, e1 - e0);
+                for (int e = e0 + l; e < e1; e += 32) { const float d = sdf_tri_distance(tri[ent[e].x], c); if (d < md) md = d; }
+                md = sdf_group_min32(md);
+                bound = fminf(bound, md);
+            };
+            cell(kc[0], kc[1], kc[2]);
+            constexpr float hc = 2.0f / (float)SDF_NC3;
+            for (int kz = k0[2]; kz <= k1[2]; ++kz)
+                for (int ky = k0[1]; ky <= k1[1]; ++ky)
+                    for (int kx = k0[0]; kx <= k1[0]; ++kx) {
+                        if (kx == kc[0] && ky == kc[1] && kz == kc[2]) continue;
+                        // distance from the corner to the cell's box (the outermost cells also hold what lies beyond them)
+                        const int kk[3] = {kx, ky, kz};
+                        float d2 = 0.f;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const float lo = -1.0f + (float)kk[a] * hc, hi = lo + hc;
+                            float da = 0.f;
+                            if (c[a] < lo && kk[a] > 0) da = lo - c[a];
+                            if (c[a] > hi && kk[a] < SDF_NC3 - 1) da = c[a] - hi;
+                            d2 += da * da;
+                        }
+                        const float lim = bound * 1.0001f + 2e-6f;
+                        if (d2 > lim * lim) continue;
+                        cell(kx, ky, kz);
+                    }
+            done = md <= rad * 0.9999f;        // everything not examined is farther than rad
+        }
+        if (!done) {
+            if (l == 0) SDF_STAT(4, 1);
+            md = 1000.f;
+            for (int f = l; f < F; f += 32) { const float d = sdf_tri_distance(tri[f], c); if (d < md) md = d; }
+            md = sdf_group_min32(md);
+        }
+        pv[k] = md;
+    }
+    // trilinear interpolation and its coordinate gradient, in the corner order of sdf_sample_kernel
+    float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float p = pv[k];
+        const float wx = (k & 1) ? fr[0] : 1.f - fr[0];
+        const float wy = (k & 2) ? fr[1] : 1.f - fr[1];
+        const float wz = (k & 4) ? fr[2] : 1.f - fr[2];
+        val += p * wx * wy * wz;
+        gx += ((k & 1) ? p : -p) * wy * wz;
+        gy += ((k & 2) ? p : -p) * wx * wz;
+        gz += ((k & 4) ? p : -p) * wx * wy;
+    }
+    const float hg = (float)G / 2.f;
+    if (live && l == 0) samp[(size_t)b * nv + v] = make_float4(val, gx * hg, gy * hg, gz * hg);
 }
 
 // entry list of one problem: the vertices that carry gradient, in ascending vertex order
@@ -474,16 +805,29 @@ size_t sdf_ticket_offset(int B, int nv) { return (sdf_chunk_offset(B, nv) + (siz
 size_t sdf_work_bytes(int B, int nv) { return sdf_ticket_offset(B, nv) + (size_t)B * sizeof(int); }
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
-                           int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream) {
+                           int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
+                           void* cull) {
     static_assert(SDF_ADJ_NT == KROWS + NJ * 12, "thread per output of the pull-back");
     unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
     SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
     SdfChunk* chunks = reinterpret_cast<SdfChunk*>(wk + sdf_chunk_offset(B, M.nv));
     int* tickets = reinterpret_cast<int*>(wk + sdf_ticket_offset(B, M.nv));
     if (M.nv > SDF_NC * 8 * SDF_NIT * 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box);
-    hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
-                       (const SdfBox*)box, faces, num_faces, G, gate, samp);
+    const bool culled = cull && num_faces >= SDF_CULL_MIN_FACES;
+    hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box,
+                       culled ? cull_views(cull, B, num_faces).flag : (int*)nullptr);
+    if (culled) {
+        const SdfCullWs W = cull_views(cull, B, num_faces);
+        const dim3 gf((num_faces + 255) / 256, B);
+        hipLaunchKernelGGL(sdf_cull_count_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
+        hipLaunchKernelGGL(sdf_cull_scan_kernel, dim3(B), dim3(SDF_SCAN_NT), 0, stream, num_faces, gate, W);
+        hipLaunchKernelGGL(sdf_cull_fill_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
+        hipLaunchKernelGGL(sdf_sample_culled_kernel, dim3((M.nv + SDF_VPB - 1) / SDF_VPB, B), dim3(SDF_NT), 0, stream, verts,
+                           M.nv, (const SdfBox*)box, num_faces, G, gate, W, samp);
+    } else {
+        hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
+                           (const SdfBox*)box, faces, num_faces, G, gate, samp);
+    }
     hipLaunchKernelGGL(sdf_entries_kernel, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
                        (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), chunks);
     hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
@@ -492,3 +836,12 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
 }
 
 }  // namespace mvfit
+
+#ifdef MVFIT_SDF_STATS
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_sdf_stats(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(mvfit::g_sdf_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_sdf_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
