@@ -350,6 +350,32 @@ def reuse_variant(eng, _lib, stage_weights, x0_d, steps=3):
     return out
 
 
+def sdf_faces_variants(eng, model, stages, x0_d, grid, steps=2):
+    """the interpenetration term as the reference wires it (faces.reshape(1,-1,3): the op sees ONE
+    triangle, fitting.py:367-368) and on all 13,776 faces (what sdf_cuda_kernel.cu:258-287 does with a proper face list) - the
+    latter on per-round face lists (sdf_term.hip), bit-identical to the walk over every face (tests/test_gpu_sdf_cull.py).
+    With all faces every surface vertex has inside corners, the stage-3/4 penalty is ~1e8 and flat along the search
+    directions, and the strong-Wolfe bracketing phase extrapolates the parameters out to infinity (final losses NaN): the
+    figure is the cost of the term, not a usable fit."""
+    out = {}
+    for name, nf in (('as_wired_one_triangle', 1), ('all_faces', None)):
+        eng.set_sdf(model['faces'], num_faces=nf, grid_size=grid)
+        eng.fit(x0_d, stages)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            xf, st = eng.fit(x0_d, stages)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fl = st['final_loss'].cpu().numpy()
+        out[name] = dict(ms_per_step=round(1e3 * dt / steps, 3), closures_per_fit=int(st['n_closure'].sum().item()),
+                         closure_rounds_per_fit=int(st['n_closure'].max().item()),
+                         closures_per_s=round(int(st['n_closure'].sum().item()) * steps / dt, 1),
+                         problems_with_finite_final_loss=int(np.isfinite(fl).sum()))
+    eng.set_sdf(model['faces'], num_faces=1, grid_size=grid)
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -591,6 +617,9 @@ def main():
                 variants['end_to_end'] = end_to_end(MvFit, syn, frames=32, reps=2)
             except Exception as e:                          # noqa: BLE001 - the headline line must not die on the extra
                 variants['end_to_end'] = {'error': repr(e)}
+        if not args.no_variants and world == 1 and sdf and args.sdf_faces == 'wired' and not demo:
+            variants = dict(variants or {})
+            variants['sdf_faces'] = sdf_faces_variants(eng, model, stages, x0_d, 128)
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.prior != 'gmm':
             cpu_stages = [dict(s) for s in stages]

@@ -61,12 +61,10 @@ __device__ __forceinline__ u64 wave64_key(u64 v) {
 
 // fitting.py:282-288 + :356-359.  First-occurrence arg indices (ties: lowest vertex index): the reductions
 // run on keys (ordered value << 32 | index) for the minima and (ordered value << 32 | ~index) for the maxima.
-__global__ __launch_bounds__(512) void sdf_bbox_kernel(const float* __restrict__ verts, int nv, const int* __restrict__ gate,
-                                                       SdfBox* __restrict__ box, int* __restrict__ cull_flag) {
-    __shared__ u64 s_k[8][6];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (gate && !gate[b]) return;                       // the problem's current stage has no SDF term (uniform)
-    if (cull_flag && tid == 0) cull_flag[b] = 0;        // "walk all faces" is decided anew by this round's count / scan kernels
+// the reductions of one workgroup of 512 threads over all vertices of problem b; the result in *out (LDS or global), valid
+// for the whole workgroup after its next barrier
+__device__ __forceinline__ void sdf_box_reduce(const float* __restrict__ verts, int nv, int b, int tid, u64 (*s_k)[6], SdfBox* out) {
+    const int lane = tid & 63, wave = tid >> 6;
     const float* vb = verts + (size_t)b * nv * 3;
     u64 kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
     for (int vbase = 0; vbase < nv; vbase += 512 * 16) {
@@ -114,8 +112,62 @@ __global__ __launch_bounds__(512) void sdf_bbox_kernel(const float* __restrict__
         o.amax = am;
         o.s = (float)((1 + 0.2) * 0.5) * ext[am];                    // "(1+0.2) * 0.5 * (...)": Python double meets a float tensor
         o.pad = 0;
-        box[b] = o;
+        *out = o;
     }
+}
+
+__global__ __launch_bounds__(512) void sdf_bbox_kernel(const float* __restrict__ verts, int nv, const int* __restrict__ gate,
+                                                       SdfBox* __restrict__ box, int* __restrict__ cull_flag) {
+    __shared__ u64 s_k[8][6];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (gate && !gate[b]) return;                       // the problem's current stage has no SDF term (uniform)
+    if (cull_flag && tid == 0) cull_flag[b] = 0;        // "walk all faces" is decided anew by this round's count / scan kernels
+    sdf_box_reduce(verts, nv, b, tid, s_k, box + b);
+}
+
+// One vertex against a face list staged in LDS (<= SDF_CH faces): the arithmetic of sdf_sample_kernel for that case -
+// parity of every in-range corner over the list, minimum distance of the inside corners, trilinear value and gradient.
+__device__ __forceinline__ float4 sdf_sample_staged(const SdfTri* tri, int nf, int G, const float (&loc)[3], bool live) {
+    float fr[3];
+    int i0[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float pix = ((loc[a] + 1.f) * (float)G - 1.f) / 2.f;
+        const float fl = floorf(pix);
+        i0[a] = (int)fl;
+        fr[a] = pix - fl;
+    }
+    float vc[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { vc[a][0] = sdf_voxel_coord(i0[a], G); vc[a][1] = sdf_voxel_coord(i0[a] + 1, G); }
+    float pv[8];
+#pragma unroll
+    for (int cn = 0; cn < 8; ++cn) {
+        pv[cn] = 0.f;
+        const int ix = i0[0] + (cn & 1), iy = i0[1] + ((cn >> 1) & 1), iz = i0[2] + (cn >> 2);
+        if (!(live && ix >= 0 && ix < G && iy >= 0 && iy < G && iz >= 0 && iz < G)) continue;
+        const float c[3] = {vc[0][cn & 1], vc[1][(cn >> 1) & 1], vc[2][cn >> 2]};
+        int n = 0;
+        for (int t = 0; t < nf; ++t) n += sdf_ray_hit(tri[t], c) ? 1 : 0;
+        if (!(n & 1)) continue;
+        float md = 1000.f;
+        for (int t = 0; t < nf; ++t) { const float d = sdf_tri_distance(tri[t], c); if (d < md) md = d; }
+        pv[cn] = md;
+    }
+    float val = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int cn = 0; cn < 8; ++cn) {
+        const float p = pv[cn];
+        const float wx = (cn & 1) ? fr[0] : 1.f - fr[0];
+        const float wy = (cn & 2) ? fr[1] : 1.f - fr[1];
+        const float wz = (cn & 4) ? fr[2] : 1.f - fr[2];
+        val += p * wx * wy * wz;
+        gx += ((cn & 1) ? p : -p) * wy * wz;
+        gy += ((cn & 2) ? p : -p) * wx * wz;
+        gz += ((cn & 4) ? p : -p) * wx * wy;
+    }
+    const float hg = (float)G / 2.f;
+    return make_float4(val, gx * hg, gy * hg, gz * hg);
 }
 
 // thread per (problem, vertex): samp[b][v] = (phi_v, dphi_v/dloc x, y, z).
@@ -556,8 +608,8 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_culled_kernel(const float* 
 struct SdfEntry { int v; float g[3]; };                                  // vertex, dS/dvertex
 static_assert(sizeof(SdfEntry) == 16, "entry layout");
 
-constexpr int SDF_NC = 8;            // vertex chunks per problem in the entry kernel (one workgroup each)
-constexpr int SDF_NIT = 2;           // 64-vertex rows per wave of a chunk: nv <= SDF_NC * 8 waves * SDF_NIT * 64 = 8192
+constexpr int SDF_NC = 16;           // vertex chunks per problem in the entry kernel (one workgroup each)
+constexpr int SDF_NIT = 1;           // 64-vertex rows per wave of a chunk: nv <= SDF_NC * 8 waves * SDF_NIT * 64 = 8192
 
 // per (problem, vertex chunk): partial sums of S and of the box adjoint, entries written (at the chunk's own offset)
 struct SdfChunk { double S, gc0, gc1, gc2, gs; int cnt, pad; };
@@ -572,17 +624,42 @@ constexpr int SDF_NS = SDF_NS_;      // workgroups (entry slices) per problem in
 // gradient plus the box's arg-min / arg-max vertices - compacted in ascending order at the chunk's offset of the entry
 // buffer, with the gradient of the sampling only (the box adjoint needs the sums of ALL chunks: sdf_pullback_kernel
 // adds it when it loads an entry).
+// FUSED (face lists of at most SDF_CH faces, i.e. the term as the reference wires it): the same workgroups first reduce
+// the problem's box themselves - every chunk the whole vertex list, the same code, hence the same box in all eight - and
+// sample their own vertices against the list staged in LDS: box, sample and entry kernels in one launch (three launches
+// of 6 + 10 + 5 us, mostly latency, became one).  The samples are still written for mvfit_sdf_term_read.
+template <bool FUSED>
 __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const float* __restrict__ verts,
-                                                                 const SdfBox* __restrict__ box, const float4* __restrict__ samp,
+                                                                 SdfBox* __restrict__ box, float4* __restrict__ samp,
                                                                  const int* __restrict__ gate,
-                                                                 SdfEntry* __restrict__ entries, SdfChunk* __restrict__ chunks) {
+                                                                 SdfEntry* __restrict__ entries, SdfChunk* __restrict__ chunks,
+                                                                 const int32_t* __restrict__ faces, int num_faces, int G) {
     __shared__ double sh_d[8][5];
     __shared__ int sh_cnt[8];
+    __shared__ u64 s_k[FUSED ? 8 : 1][6];
+    __shared__ SdfBox sh_box;
+    __shared__ SdfTri tri[FUSED ? SDF_CH : 1];
     const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
-    const SdfBox bx = box[b];
     const float* vb = verts + (size_t)b * nv * 3;
-    const float4* sb = samp + (size_t)b * nv;
+    if constexpr (FUSED) {
+        sdf_box_reduce(verts, nv, b, tid, s_k, &sh_box);
+        __syncthreads();
+    }
+    const SdfBox bx = FUSED ? sh_box : box[b];
+    if constexpr (FUSED) {
+        if (y == 0 && tid == 0) box[b] = bx;
+        for (int t = tid; t < num_faces; t += SDF_ADJ_NT) {
+            float p[3][3];
+            for (int m = 0; m < 3; ++m) {
+                const int vi = faces[3 * t + m];
+                for (int a = 0; a < 3; ++a) p[m][a] = (vb[3 * vi + a] - bx.c[a]) / bx.s;     // fitting.py:362-363
+            }
+            sdf_tri_setup(tri[t], p[0], p[1], p[2]);
+        }
+        __syncthreads();
+    }
+    float4* sb = samp + (size_t)b * nv;
     const int csz = (nv + SDF_NC - 1) / SDF_NC, k0 = y * csz, k1 = min(nv, k0 + csz);
     SdfEntry* eb = entries + (size_t)b * nv + k0;
     // ---- pass A: every wave owns an ascending run of the chunk, 64 vertices per row; everything stays in registers ----
@@ -598,8 +675,14 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
             const int v = c0 + i * 64 + lane;
             const bool in = v < c1;
             const int vc = in ? v : min(k0, nv - 1);      // padding lanes re-read a vertex that exists (small / odd nv: k0 may be >= nv)
-            q[i] = sb[vc];
             px[i] = vb[3 * vc]; py[i] = vb[3 * vc + 1]; pz[i] = vb[3 * vc + 2];
+            if constexpr (FUSED) {
+                const float loc[3] = {(px[i] - bx.c[0]) / bx.s, (py[i] - bx.c[1]) / bx.s, (pz[i] - bx.c[2]) / bx.s};
+                q[i] = sdf_sample_staged(tri, num_faces, G, loc, true);
+                if (in) sb[v] = q[i];
+            } else {
+                q[i] = sb[vc];
+            }
             if (!in) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -683,7 +766,12 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
     __syncthreads();
     const SdfBox bx = box[b];
     const int ntot = sh_pref[SDF_NC];
-    const int lo = (int)((long long)ntot * y / SDF_NS), n = (int)((long long)ntot * (y + 1) / SDF_NS);
+    // a very short list (little more than the six vertices of the box) goes through slice 0 alone, which writes the result
+    // itself - no partials, no ticket.  (Not for the term as wired: the one triangle shadows ~200 vertices, 1 MB of basis
+    // rows per problem - through a single CU the kernel took 25 us instead of 11.)
+    const bool small = ntot <= 16;
+    if (small && y != 0) return;                                     // uniform
+    const int lo = small ? 0 : (int)((long long)ntot * y / SDF_NS), n = small ? ntot : (int)((long long)ntot * (y + 1) / SDF_NS);
     const int csz = (M.nv + SDF_NC - 1) / SDF_NC;
     const SdfEntry* eb = entries + (size_t)b * M.nv;
     if (lo < n) {                                                    // (uniform) an empty slice writes zeros
@@ -769,6 +857,17 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
     // LAST adds the eight partials in slice order (deterministic whoever it is) - the former third kernel, without its
     // launch.  Hand-off as the guide prescribes for other-CU data: agent-scope (sc1) stores, this wave's stores drained
     // before the workgroup barrier in front of the ticket, agent-scope loads on the reading side.
+    if (small) {
+        SdfAdj& R = out[b];
+        if (tid < KROWS) R.gcoef[tid] = acc; else R.gA[tid - KROWS] = acc;
+        if (tid < 3) R.gtau[tid] = gtv;
+        if (tid == 0) {
+            double S = 0.0;
+            for (int c = 0; c < SDF_NC; ++c) S += chunks[(size_t)b * SDF_NC + c].S;
+            R.S = (float)S;
+        }
+        return;
+    }
     SdfAdj& O = part[(size_t)b * SDF_NS + y];
     __hip_atomic_store(tid < KROWS ? &O.gcoef[tid] : &O.gA[tid - KROWS], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 3) __hip_atomic_store(&O.gtau[tid], gtv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,22 +913,27 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
     int* tickets = reinterpret_cast<int*>(wk + sdf_ticket_offset(B, M.nv));
     if (M.nv > SDF_NC * 8 * SDF_NIT * 64) return hipErrorInvalidValue;
     const bool culled = cull && num_faces >= SDF_CULL_MIN_FACES;
-    hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box,
-                       culled ? cull_views(cull, B, num_faces).flag : (int*)nullptr);
-    if (culled) {
-        const SdfCullWs W = cull_views(cull, B, num_faces);
-        const dim3 gf((num_faces + 255) / 256, B);
-        hipLaunchKernelGGL(sdf_cull_count_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
-        hipLaunchKernelGGL(sdf_cull_scan_kernel, dim3(B), dim3(SDF_SCAN_NT), 0, stream, num_faces, gate, W);
-        hipLaunchKernelGGL(sdf_cull_fill_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
-        hipLaunchKernelGGL(sdf_sample_culled_kernel, dim3((M.nv + SDF_VPB - 1) / SDF_VPB, B), dim3(SDF_NT), 0, stream, verts,
-                           M.nv, (const SdfBox*)box, num_faces, G, gate, W, samp);
+    if (num_faces <= SDF_CH) {
+        hipLaunchKernelGGL(sdf_entries_kernel<true>, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, box, samp, gate,
+                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G);
     } else {
-        hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
-                           (const SdfBox*)box, faces, num_faces, G, gate, samp);
+        hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box,
+                           culled ? cull_views(cull, B, num_faces).flag : (int*)nullptr);
+        if (culled) {
+            const SdfCullWs W = cull_views(cull, B, num_faces);
+            const dim3 gf((num_faces + 255) / 256, B);
+            hipLaunchKernelGGL(sdf_cull_count_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
+            hipLaunchKernelGGL(sdf_cull_scan_kernel, dim3(B), dim3(SDF_SCAN_NT), 0, stream, num_faces, gate, W);
+            hipLaunchKernelGGL(sdf_cull_fill_kernel, gf, dim3(256), 0, stream, verts, M.nv, (const SdfBox*)box, faces, num_faces, gate, W);
+            hipLaunchKernelGGL(sdf_sample_culled_kernel, dim3((M.nv + SDF_VPB - 1) / SDF_VPB, B), dim3(SDF_NT), 0, stream, verts,
+                               M.nv, (const SdfBox*)box, num_faces, G, gate, W, samp);
+        } else {
+            hipLaunchKernelGGL(sdf_sample_kernel, dim3((M.nv + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, verts, M.nv,
+                               (const SdfBox*)box, faces, num_faces, G, gate, samp);
+        }
+        hipLaunchKernelGGL(sdf_entries_kernel<false>, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, box, samp, gate,
+                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G);
     }
-    hipLaunchKernelGGL(sdf_entries_kernel, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, (const SdfBox*)box,
-                       (const float4*)samp, gate, reinterpret_cast<SdfEntry*>(entries), chunks);
     hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
                        reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part, tickets, adj);
     return hipGetLastError();
