@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 CONST_BYTES = 82680 + 826800 + 17114760 + 661440      # v_template + shapedirs + posedirs + lbs_weights
 PER_PROBLEM_BYTES = 2032 + 82680                      # (betas, pose_feature, A, transl) in + vertices out
-PMC_JSON = os.path.join(ROOT, 'profiles', 'r3_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
+PMC_JSON = os.path.join(ROOT, 'profiles', 'r4_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
 # the imported reference itself (PyTorch CPU, create_fitting_closure + LBFGSLs + run_fitting) timed in the survey's
 # build container (it cannot travel to the GPU box): closures/s inside L-BFGS, 8 vCPUs
 SURVEY_REFERENCE_CLOSURES_PER_S = (74.0, 125.0)

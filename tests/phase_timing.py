@@ -33,8 +33,8 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
     lib.mvfit_debug_timing(buf, 1)
     n = max(buf[13],1)
-    names = ['pose_prep','chain||stream','T/xs','loss','E5 gx','E6 gA','E7 chainT||streamT','E8 gR/gbeta','E9 rodT+asm(+vpbwd)','lb load','lb advance A','lb direction','lb advance B+store']
-    print(name, 'rounds(block0)=%d avg hist=%.1f two-loops=%d' % (n, buf[14]/n, buf[15]))
+    names = ['pose_prep','chain||stream','T/xs','loss','E5 gx','E6 gA','E7 chainT||streamT','E8 gR/gbeta','E9 rodT+asm(+vpbwd)','lb load','lb advance A','lb direction entry/exit','lb advance B+store']
+    print(name, 'rounds(block0)=%d avg hist=%.1f direction calls=%d' % (n, buf[14]/n, buf[15]))
     print('   ', ' | '.join('%s=%.0f' % (names[i], buf[i]/n) for i in range(13)), '| total=%.0f cycles/round' % (sum(buf[i] for i in range(13))/n))
     print('    step-kernel prologue=%.0f epilogue (state store + pose/chain of next x + publish)=%.0f' % (buf[24]/n, buf[25]/n))
     print('    wave-0 chain fwd=%.0f (rest of slot 1 = waiting for the basis stream) ; chain bwd=%.0f (rest of slot 6 = waiting for the transposed stream)' % (buf[22]/n, buf[23]/n))
@@ -43,8 +43,12 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     print('    inside advance (cycles per round): ' + ' | '.join('%s=%.0f' % (nm, ab[i]/n) for i, nm in enumerate(['entry->ls_first', 'gtd dot', 'wolfe checks->ls_return', 'ls_return->iter', 'iter->insert done', 'dir end->resume', 'resume->emit'])))
     lib.mvfit_debug_timing_helpers(hb, 1)
     if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
-    if buf[15]: print('    direction: %.0f cycles per call, %.1f cycles per history row (x2 loops)' % (buf[11]/buf[15], buf[11]/max(1,2*buf[14]*buf[15]/n)))
-    print('    direction sub-phases per call: ' + ' | '.join('%s=%.0f' % (nm, buf[16+i]/max(1,buf[15])) for i, nm in enumerate(['rowdots b','recur 1','matvec q0','rowdots e','recur 2','matvec d'])))
+    if buf[15]:
+        sub = [buf[16+i]/buf[15] for i in range(6)]
+        print('    compact direction (lb_direction_compact): %.0f cycles per call = ' % (sum(sub) + buf[11]/buf[15]) +
+              ' | '.join('%s=%.0f' % (nm, v) for nm, v in zip(['p,u = S^T(q|y_new)', 'w = R^-1 p (+ new column)', 't = Y w - q', 'z = D w + gamma Y^T t', 'a = R^-T z', 'd = S a - gamma t'], sub)) +
+              ' | entry/exit=%.0f ; per round (x direction calls / rounds): %.0f' % (buf[11]/buf[15], (sum(sub)*buf[15] + buf[11])/n))
+    print('    (cycles = clock64() of workgroup 0, thread 0 - shader clocks, ~2.4 GHz; the build with the marks is slower than the shipped one: relative weights, not absolute times)')
 
 vb = (C.c_longlong*16)()
 lib.mvfit_debug_vp(vb)
