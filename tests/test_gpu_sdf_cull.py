@@ -66,3 +66,38 @@ def test_face_lists_give_the_bits_of_the_walk_over_all_faces(num_faces, G, sprea
     assert inside > 100 or G < 16, 'the case does not exercise the term'
     for u, v, name in zip(a, b, ('samples', 'S', 'loss', 'grad')):
         assert np.array_equal(u.view(np.uint32), v.view(np.uint32)), name
+
+
+def test_a_staged_fit_with_all_faces_is_the_same_fit_on_lists_and_by_the_walk():
+    """The whole staged fit (two leading stages asynchronous, the stages with the term chained: pass -> box -> lists ->
+    samples -> entries -> pull-back -> step) lands on the same parameters, bit for bit, whichever kernel samples."""
+    B, V, G = 3, 4, 32
+    model = syn.make_body_model(0, skin_topk=4)
+    cams = syn.make_camera_ring(V)
+    xgt = _poses(B, 4242, 0.2)
+    res = []
+    for cull in (True, False):
+        old = os.environ.get('MVFIT_SDF_CULL')
+        os.environ['MVFIT_SDF_CULL'] = '1' if cull else '0'
+        try:
+            eng = MvFit(model)
+            eng.set_problems(cams, np.zeros((B, V, 17, 2), np.float32), np.ones((B, V, 17), np.float32))
+            _, joints = eng.vertices(xgt)
+            gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=77)
+            eng.set_problems(cams, gt, conf)
+            eng.set_sdf(model['faces'], num_faces=None, grid_size=G)
+            x0 = np.zeros((B, 118), np.float32)
+            x0[:, 85] = 1
+            stages = stage_weights(1536.0, coll_w=[0.0, 0.0, 0.01, 0.05])       # small weights: the fit stays a fit
+            xf, st = eng.fit(x0, stages)
+            res.append((xf.cpu().numpy(), st['final_loss'].cpu().numpy(), st['n_closure'].cpu().numpy()))
+            eng.close()
+        finally:
+            if old is None:
+                os.environ.pop('MVFIT_SDF_CULL', None)
+            else:
+                os.environ['MVFIT_SDF_CULL'] = old
+    assert np.isfinite(res[0][1]).all()
+    assert np.array_equal(res[0][2], res[1][2])
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
