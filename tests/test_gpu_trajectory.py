@@ -90,3 +90,67 @@ def test_demo_fit_follows_reference_fp32_trajectory():
     # x here is O(10) (translation): scale the absolute tolerance accordingly
     worst = max(max(r[1] / (10 * tol(r[0], 7)), r[2] / tol(r[0], 7)) for r in rows)
     assert worst <= 1.0, [(r[0], float('%.2g' % r[1]), float('%.2g' % r[2]), float('%.2g' % r[3])) for r in rows]
+
+
+@pytest.mark.parametrize('name', ['l2_s3_v6', 'l2_top4_v8'])
+def test_fit_whose_every_round_carries_the_sdf_term_follows_the_reference(name):
+    """Two stages that BOTH carry the interpenetration term (yaml stage-3 / stage-4 weights, coll_loss_weights 1000 / 4500),
+    from a body with a vertex in the first triangle's shadow: every closure of the device fit is a round of the CHAINED
+    structure (vertex pass -> term kernels -> step kernel).  Reference: its own float32 fit with its own
+    SMPLifyLoss(interpenetration=True), every closure call recorded (tests/golden/fit_sdf.npz, oracle/make_golden_sdf_fit.py;
+    float32 is the only precision the reference's term runs in).  Four checks:
+      (a) the device closure at each of the reference's 120 recorded trial points returns the reference's loss (2e-5; 3e-4
+          where the term is non-zero: pen = (1000 S)^2 amplifies the last bits of the vertex positions - measured <= 4e-5);
+      (b) every round of the chained fit returned what the closure call returns at that round's trial point (1e-6) - the
+          chained structure evaluates the function (a) pins, at the point the optimiser asked for;
+      (c) the device trajectory follows the reference's (the tolerance schedule of the tests above) - until the term, which
+          is only piecewise continuous (a vertex entering or leaving the triangle's shadow moves S by tens of per cent; trial
+          points 2e-6 apart give S values 2e-4 apart), has differed between the two runs' trial points by more than 5e-5; it
+          may leave the reference's trajectory only behind such a point (measured: closure 3 and closure 25);
+      (d) the fit ends where the reference's ends (final loss <= 1.05 x; measured 449.2725 vs 449.2715 and 553.49 vs 553.33,
+          closure counts 376 vs 351 and 171 vs 218)."""
+    from tests.helpers import load_case
+    t = dict(np.load(os.path.join(GOLD, 'fit_sdf.npz')))
+    cfg, g, model, vpw, gmm, wts, _ = load_case(name)
+    assert abs(syn.model_checksum(model) - float(t[name + '/model_checksum'])) < 1e-6 * float(t[name + '/model_checksum'])
+    eng = make_engine(model, None, None)
+    cams = tuple(t[name + '/' + k] for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'))
+    eng.set_problems(cams, t[name + '/gt_xy'][None], t[name + '/conf'][None])
+    eng.set_sdf(model['faces'], num_faces=1, grid_size=128)
+    x0 = to118(t[name + '/x0'], False)[None].astype(np.float32)
+    stages = eng_stage_weights(1536.0, coll_w=[0.0, 0.0, float(t['coll_w'][0]), float(t['coll_w'][1])])[2:4]
+    ref = t[name + '/trace32']
+    nref = min(ref.shape[0], int(t[name + '/ncl32'][0]))              # recorded closures of the first stage
+
+    def closure_at(x118):
+        out = eng.closure(x118[None].astype(np.float32), stages[0], want_grad=False)
+        _, S = eng.sdf_term_read()
+        return float(out['loss'][0]), float(S[0])
+
+    # (a)
+    S_ref = np.zeros(nref)
+    for k in range(nref):
+        L, S_ref[k] = closure_at(to118(ref[k, :-1], False))
+        assert abs(L - ref[k, -1]) <= (3e-4 if S_ref[k] > 0 else 2e-5) * abs(ref[k, -1]), (name, k, L, ref[k, -1], S_ref[k])
+    assert (S_ref > 0).sum() >= 3, 'the case does not exercise the term'
+    tr = eng.fit_trace(120)
+    xf, st = eng.fit(x0, stages)
+    tr = tr.cpu().numpy().astype(np.float64)[0]
+    eng.fit_trace(0)
+    ndev = min(120, int(st['n_closure'][0]))
+    # (b)
+    S_dev = np.zeros(ndev)
+    for k in range(ndev):
+        L, S_dev[k] = closure_at(tr[k, :118])
+        assert abs(L - tr[k, 118]) <= 1e-6 * abs(L), (name, k, L, tr[k, 118])
+    # (c)
+    n = min(N_STEP, nref, ndev)
+    ex = np.array([np.abs(from118(tr[k, :118], False) - ref[k, :-1]).max() for k in range(n)])
+    off = [k for k in range(n) if ex[k] > tol(k)]
+    if off:
+        jumps = [k for k in range(off[0]) if abs(S_dev[k] - S_ref[k]) > 5e-5 * max(S_dev[k], S_ref[k], 1e-6)]
+        assert off[0] >= 2 and jumps, (name, off[0], ex[:off[0] + 1], S_dev[:off[0] + 1], S_ref[:off[0] + 1])
+    # (d)
+    final = float(st['final_loss'][0])
+    assert final <= 1.05 * float(t[name + '/final32']), (name, final, float(t[name + '/final32']))
+    eng.close()
