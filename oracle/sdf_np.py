@@ -101,13 +101,17 @@ def ray_hits(orig, dest, v0, v1, v2):
     with np.errstate(divide='ignore', invalid='ignore'):
         inv_det = (1.0 / det.astype(np.float64)).astype(F32)            # "1.0 / det": double division, float result
     tvec = (orig - v0).astype(F32)
-    u = (_dot_macro(tvec, pvec) * inv_det).astype(F32)
-    ok &= ~((u < 0.0) | (u > 1.0))
-    qvec = _cross(tvec, np.broadcast_to(e1, tvec.shape))
-    v = (_dot_macro(dirv, qvec) * inv_det).astype(F32)
-    ok &= ~((v < 0.0) | ((u + v).astype(F32) > 1.0))
-    t = (_dot_macro(np.broadcast_to(e2, qvec.shape), qvec) * inv_det).astype(F32)
-    return ok & (t >= 0)
+    # det == 0 (a ray in the triangle's plane, a degenerate triangle) makes inv_det infinite and u / v / t inf or NaN; those
+    # voxels are already out through the det test above (the kernel returns there, sdf_cuda_kernel.cu:113-114) - every
+    # comparison below is evaluated for them as well only because this is array code: no warnings for arithmetic on them
+    with np.errstate(invalid='ignore', over='ignore'):
+        u = (_dot_macro(tvec, pvec) * inv_det).astype(F32)
+        ok &= ~((u < 0.0) | (u > 1.0))
+        qvec = _cross(tvec, np.broadcast_to(e1, tvec.shape))
+        v = (_dot_macro(dirv, qvec) * inv_det).astype(F32)
+        ok &= ~((v < 0.0) | ((u + v).astype(F32) > 1.0))
+        t = (_dot_macro(np.broadcast_to(e2, qvec.shape), qvec) * inv_det).astype(F32)
+        return ok & (t >= 0)
 
 
 def voxel_centres(G):
