@@ -111,7 +111,7 @@ struct ClosureLds {
     };
     // GMM
     float gmm_d[72];
-    float gmm_t[8][72];
+    __attribute__((aligned(16))) float gmm_t[8][72];
     float gmm_ll[8];
     // per-stage weights and optimiser options: read from LDS inside the round loop so that they do not
     // pin ~100 SGPRs across it
@@ -897,20 +897,50 @@ __device__ __forceinline__ double loss_and_keypoint_grad(const DevModel& M, Clos
         // merged_log_likelihood (prior.py:181-196): min_m 0.5 d^T P_m d - log nll_w_m ; t_m = P_m d_m
         const int Mg = M.gmm_M;
         __syncthreads();
-        // thread per (m, r, quarter): 8*69*... use 16-lane rows: row = (m, r), lanes split the 69 columns
-        const int rowi = tid >> 4, l16 = tid & 15;
-        for (int mr = rowi; mr < Mg * 69; mr += STEP_NT / 16) {
-            const int m = mr / 69, r = mr - m * 69;
-            const float* prow = M.gmm_prec + ((size_t)m * 69 + r) * 72;
-            const float* mu = M.gmm_means + m * 69;
-            float s = 0.f;
-            for (int c = l16; c < 69; c += 16) s = fmaf(prow[c], L.pose.theta[3 + c] - mu[c], s);
-            s = row16_sum(s);
-            if (l16 == 0) L.gmm_t[m][r] = s;
+        // d_m = theta - mu_m (zero-padded to the 72-float rows) into the scratch, which is free between the forward and the
+        // adjoint; then t_m = P_m d_m with 4 lanes per row (m, r): a lane takes the row's 16-byte words q, q + 4, ... and the
+        // words of three passes of 128 rows are requested before the first is used (the 152 KB of the eight precision
+        // matrices are a stream: 18 passes of five dependent loads each cost 8 us per closure)
+        float* dm = L.scratch;
+        for (int i = tid; i < Mg * 72; i += STEP_NT) {
+            const int m = i / 72, c = i - 72 * m;
+            dm[i] = c < 69 ? L.pose.theta[3 + c] - M.gmm_means[m * 69 + c] : 0.f;
+        }
+        __syncthreads();
+        {
+            const int row4 = tid >> 2, q = tid & 3, nrows = Mg * 69;
+            constexpr int RPP = STEP_NT / 4;
+            for (int p0 = 0; p0 * RPP < nrows; p0 += 3) {
+                float4 w[3][5];
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const int mr = min(row4 + (p0 + pp) * RPP, nrows - 1);
+                    const float4* prow = reinterpret_cast<const float4*>(M.gmm_prec + (size_t)mr * 72);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) w[pp][j] = prow[min(q + 4 * j, 17)];
+                }
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const int mr0 = row4 + (p0 + pp) * RPP, mr = min(mr0, nrows - 1);
+                    const int m = mr / 69, r = mr - m * 69;
+                    const float4* dv = reinterpret_cast<const float4*>(dm + m * 72);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        if (j == 4 && q >= 2) continue;                       // a row has 18 words
+                        const float4 d4 = dv[q + 4 * j], w4 = w[pp][j];
+                        acc = fmaf(w4.x, d4.x, acc); acc = fmaf(w4.y, d4.y, acc);
+                        acc = fmaf(w4.z, d4.z, acc); acc = fmaf(w4.w, d4.w, acc);
+                    }
+                    acc += dpp_mov<DPP_XOR1>(acc);
+                    acc += dpp_mov<DPP_XOR2>(acc);
+                    if (q == 0 && mr0 < nrows) L.gmm_t[m][r] = acc;
+                }
+            }
         }
         __syncthreads();
         if (tid < 16 * Mg) {
-            const int m = tid >> 4;
+            const int m = tid >> 4, l16 = tid & 15;
             const float* mu = M.gmm_means + m * 69;
             float qd = 0.f;
             for (int r = l16; r < 69; r += 16) qd = fmaf(L.gmm_t[m][r], L.pose.theta[3 + r] - mu[r], qd);
@@ -1178,14 +1208,29 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     if (!use_vp && (W.flags & MVFIT_F_PRIOR_GMM) && !(L.flags_dropped & 1)) {
         // 0.5 (P d + P^T d) of the selected mixture: P d is gmm_t[m]; P^T d via the transposed copy
         const int m = L.gmm_sel;
-        const int rowi = tid >> 4, l16 = tid & 15;
-        for (int i = rowi; i < 69; i += STEP_NT / 16) {
-            const float* mu = M.gmm_means + m * 69;
-            const float* PT = M.gmm_precT + ((size_t)m * 69 + i) * 72;
-            float s = 0.f;
-            for (int r = l16; r < 69; r += 16) s = fmaf(PT[r], L.pose.theta[3 + r] - mu[r], s);
-            s = row16_sum(s);
-            if (l16 == 0) L.gmm_d[i] = 0.5f * (L.gmm_t[m][i] + s);
+        // d of the selected mixture is staged in a row of gmm_t that is dead by now (another mixture's t)
+        float* dsel = L.gmm_t[m ^ 1];
+        if (tid < 72) dsel[tid] = tid < 69 ? L.pose.theta[3 + tid] - M.gmm_means[m * 69 + tid] : 0.f;
+        __syncthreads();
+        const int row4 = tid >> 2, q = tid & 3;
+        {
+            const int i = min(row4, 68);
+            const float4* prow = reinterpret_cast<const float4*>(M.gmm_precT + ((size_t)m * 69 + i) * 72);
+            float4 w[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) w[j] = prow[min(q + 4 * j, 17)];
+            const float4* dv = reinterpret_cast<const float4*>(dsel);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (j == 4 && q >= 2) continue;
+                const float4 d4 = dv[q + 4 * j], w4 = w[j];
+                acc = fmaf(w4.x, d4.x, acc); acc = fmaf(w4.y, d4.y, acc);
+                acc = fmaf(w4.z, d4.z, acc); acc = fmaf(w4.w, d4.w, acc);
+            }
+            acc += dpp_mov<DPP_XOR1>(acc);
+            acc += dpp_mov<DPP_XOR2>(acc);
+            if (q == 0 && row4 < 69) L.gmm_d[row4] = 0.5f * (L.gmm_t[m][row4] + acc);
         }
     }
     __syncthreads();
