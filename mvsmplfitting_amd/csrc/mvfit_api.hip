@@ -33,6 +33,10 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
                            void* cull);
 size_t sdf_cull_bytes(int B, int num_faces);
+size_t sdf_op_ws_bytes(int B, int num_faces);
+bool sdf_op_uses_lists(int num_faces);
+hipError_t launch_sdf_voxelize_culled(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
+                                      float* phi, void* ws, hipStream_t stream);
 size_t sdf_cull_zero_offset(int B, int num_faces);
 size_t sdf_cull_zero_bytes(int B);
 int sdf_cull_min_faces();
@@ -628,6 +632,8 @@ struct mvfit_ctx {
     void* d_sdf_entries = nullptr;     // [B][nv] entry list
     SdfAdj* d_sdf_adj = nullptr;       // [B]
     void* d_sdf_cull = nullptr;        // face lists of the all-faces term (sdf_term.hip), sized for (B, sdf_num_faces)
+    void* d_sdf_op_ws = nullptr;       // face lists of the stand-alone op (mvfit_sdf), kept between calls of one shape
+    int sdf_op_B = 0, sdf_op_F = 0;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
@@ -1100,6 +1106,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
     if (c->d_sdf_faces) hipFree(c->d_sdf_faces);
+    if (c->d_sdf_op_ws) hipFree(c->d_sdf_op_ws);
     for (void* p : c->allocs) if (p) hipFree(p);
     if (c->h_done) hipHostFree(c->h_done);
     for (hipEvent_t e : c->ev_done) if (e) hipEventDestroy(e);
@@ -1228,7 +1235,10 @@ static int ensure_sdf_buffers(mvfit_ctx* c) {
     // keeps the brute-force kernel (the check of the culled one).
     if (!c->d_sdf_cull && c->sdf_num_faces >= sdf_cull_min_faces()) {
         const char* e = getenv("MVFIT_SDF_CULL");
-        if (!(e && e[0] == '0')) {
+        // (11.6 MB of lists, records and bins per problem at 13,776 faces: a batch whose workspace would not fit keeps the walk)
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(c, hipMemGetInfo(&free_b, &total_b));
+        if (!(e && e[0] == '0') && sdf_cull_bytes(c->B, c->sdf_num_faces) < free_b / 2) {
             HIP_OK(c, hipMalloc(&c->d_sdf_cull, sdf_cull_bytes(c->B, c->sdf_num_faces)));
             HIP_OK(c, hipMemset(reinterpret_cast<unsigned char*>(c->d_sdf_cull) + sdf_cull_zero_offset(c->B, c->sdf_num_faces), 0,
                                 sdf_cull_zero_bytes(c->B)));
@@ -1872,6 +1882,27 @@ extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, cons
     if (!faces || !vertices || !phi || num_faces < 0 || B <= 0 || num_vertices <= 0 || G < 2 || G > 1024)
         return fail(c, MVFIT_E_ARG, "mvfit_sdf: bad argument (num_faces=%d B=%d num_vertices=%d G=%d)", num_faces, B, num_vertices, G);
     HIP_OK(c, hipSetDevice(c->device));
+    // long face lists: exact culling on face lists (sdf_term.hip), bit-identical to the walk; MVFIT_SDF_CULL=0 keeps the walk
+    const char* ev = getenv("MVFIT_SDF_CULL");
+    if (sdf_op_uses_lists(num_faces) && !(ev && ev[0] == '0')) {
+        if (!c->d_sdf_op_ws || c->sdf_op_B != B || c->sdf_op_F != num_faces) {
+            HIP_OK(c, hipStreamSynchronize(c->stream));
+            if (c->d_sdf_op_ws) { hipFree(c->d_sdf_op_ws); c->d_sdf_op_ws = nullptr; }
+            size_t free_b = 0, total_b = 0;
+            HIP_OK(c, hipMemGetInfo(&free_b, &total_b));
+            if (sdf_op_ws_bytes(B, num_faces) < free_b / 2) {
+                HIP_OK(c, hipMalloc(&c->d_sdf_op_ws, sdf_op_ws_bytes(B, num_faces)));
+                HIP_OK(c, hipMemsetAsync(reinterpret_cast<unsigned char*>(c->d_sdf_op_ws) + sdf_cull_zero_offset(B, num_faces), 0,
+                                         sdf_cull_zero_bytes(B), c->stream));
+                c->sdf_op_B = B; c->sdf_op_F = num_faces;
+            }
+        }
+        if (c->d_sdf_op_ws) {
+            hipError_t e = launch_sdf_voxelize_culled(faces, num_faces, vertices, B, num_vertices, G, phi, c->d_sdf_op_ws, c->stream);
+            if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
+            return MVFIT_OK;
+        }
+    }
     hipError_t e = launch_sdf_voxelize(faces, num_faces, vertices, B, num_vertices, G, phi, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
     return MVFIT_OK;

@@ -604,6 +604,115 @@ __global__ __launch_bounds__(SDF_NT) void sdf_sample_culled_kernel(const float* 
     if (live && l == 0) samp[(size_t)b * nv + v] = make_float4(val, gx * hg, gy * hg, gz * hg);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stand-alone op (mvfit_sdf: every voxel of the G^3 grid, sdf_cuda_kernel.cu:242-335) on the same face lists.  The op's
+// vertices arrive normalised by the caller: the lists are built with the identity box (x - 0) / 1 = x.  Parity as in the
+// term; minimum distance of an inside voxel - which may lie deep inside the mesh - by rings of cells around the voxel's
+// cell: ring k (Chebyshev distance k) is visited after ring k - 1, a cell farther than the best distance so far is left
+// out, and the search ends when the best distance is at most k h: everything outside the block of rings 0..k is at least
+// that far away.  A mesh that leaves the box the lists are made for (a vertex within 0.016 of -1 on any axis, or not
+// finite) raises the element's flag and its voxels walk all faces.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void sdf_identity_box_kernel(SdfBox* __restrict__ box, int* __restrict__ flag, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    SdfBox o;
+    for (int a = 0; a < 3; ++a) { o.c[a] = 0.f; o.imin[a] = 0; o.imax[a] = 0; }
+    o.s = 1.f; o.amax = 0; o.pad = 0;
+    box[b] = o;
+    flag[b] = 0;
+}
+
+__global__ __launch_bounds__(SDF_NT) void sdf_voxelize_culled_kernel(int F, int G, SdfCullWs W, float* __restrict__ phi) {
+    const int bn = blockIdx.y;
+    const int nvox = G * G * G;
+    const int vid = blockIdx.x * SDF_NT + threadIdx.x;
+    if (vid >= nvox) return;
+    const int i = vid % G, j = (vid / G) % G, k = (vid / (G * G)) % G;
+    const float c[3] = {sdf_voxel_coord(i, G), sdf_voxel_coord(j, G), sdf_voxel_coord(k, G)};
+    const SdfTri* tri = W.tri + (size_t)bn * F;
+    const int* offs = W.offs + (size_t)bn * SDF_OFFS_LD;
+    const int2* ent = W.ent + (size_t)bn * SDF_CULL_CAP * F;
+    const bool walk_all = W.flag[bn] != 0;
+    int n = 0;
+    if (!walk_all) {
+        const float qx = c[0] + 1.0f, qy = c[1] + 1.0f, qz = c[2] + 1.0f, sq = qx + qy + qz;
+        const int bin = sdf_bin2(qy / sq) * SDF_NB + sdf_bin2(qx / sq);
+        const float s_lim = sq + 3.f * SDF_CULL_DELTA;
+        const int e0 = offs[bin], e1 = offs[bin + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int2 en = ent[e];
+            if (__builtin_bit_cast(float, en.y) > s_lim) continue;
+            n += sdf_ray_hit(tri[en.x], c) ? 1 : 0;
+        }
+    } else {
+        for (int f = 0; f < F; ++f) n += sdf_ray_hit(tri[f], c) ? 1 : 0;
+    }
+    float md = 1000.f;
+    if (n & 1) {
+        if (!walk_all) {
+            constexpr float hc = 2.0f / (float)SDF_NC3;
+            const int kc[3] = {sdf_cell3(c[0]), sdf_cell3(c[1]), sdf_cell3(c[2])};
+            auto visit = [&](int kx, int ky, int kz) {
+                const int kk[3] = {kx, ky, kz};
+                float d2 = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = -1.0f + (float)kk[a] * hc, hi = lo + hc;
+                    float da = 0.f;
+                    if (c[a] < lo && kk[a] > 0) da = lo - c[a];
+                    if (c[a] > hi && kk[a] < SDF_NC3 - 1) da = c[a] - hi;
+                    d2 += da * da;
+                }
+                const float lim = md * 1.0001f + 2e-6f;
+                if (d2 > lim * lim) return;
+                const int bin = SDF_NB * SDF_NB + (kz * SDF_NC3 + ky) * SDF_NC3 + kx;
+                const int e0 = offs[bin], e1 = offs[bin + 1];
+                for (int e = e0; e < e1; ++e) { const float d = sdf_tri_distance(tri[ent[e].x], c); if (d < md) md = d; }
+            };
+            for (int ring = 0; ring < SDF_NC3; ++ring) {
+                const int x0 = max(kc[0] - ring, 0), x1 = min(kc[0] + ring, SDF_NC3 - 1);
+                const int y0 = max(kc[1] - ring, 0), y1 = min(kc[1] + ring, SDF_NC3 - 1);
+                const int z0 = max(kc[2] - ring, 0), z1 = min(kc[2] + ring, SDF_NC3 - 1);
+                for (int kz = z0; kz <= z1; ++kz)
+                    for (int ky = y0; ky <= y1; ++ky) {
+                        const bool shell = (kz - kc[2] == ring) || (kc[2] - kz == ring) || (ky - kc[1] == ring) || (kc[1] - ky == ring);
+                        if (shell) {
+                            for (int kx = x0; kx <= x1; ++kx) visit(kx, ky, kz);
+                        } else {
+                            if (kc[0] - ring >= 0) visit(kc[0] - ring, ky, kz);
+                            if (ring > 0 && kc[0] + ring <= SDF_NC3 - 1) visit(kc[0] + ring, ky, kz);
+                        }
+                    }
+                if (md <= (float)ring * hc * 0.9999f) break;          // nothing outside the visited block is closer
+                if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == SDF_NC3 - 1 && y1 == SDF_NC3 - 1 && z1 == SDF_NC3 - 1) break;
+            }
+        } else {
+            for (int f = 0; f < F; ++f) { const float d = sdf_tri_distance(tri[f], c); if (d < md) md = d; }
+        }
+    }
+    phi[(size_t)bn * nvox + vid] = (n & 1) ? md : 0.f;
+}
+
+size_t sdf_op_ws_bytes(int B, int num_faces) { return sdf_cull_bytes(B, num_faces) + cull_align((size_t)B * sizeof(SdfBox)); }
+bool sdf_op_uses_lists(int num_faces) { return num_faces >= SDF_CULL_MIN_FACES; }
+// ws: sdf_op_ws_bytes(B, num_faces) bytes whose count area (sdf_cull_zero_offset / sdf_cull_zero_bytes) was zeroed once
+hipError_t launch_sdf_voxelize_culled(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
+                                      float* phi, void* ws, hipStream_t stream) {
+    const SdfCullWs W = cull_views(ws, B, num_faces);
+    SdfBox* box = reinterpret_cast<SdfBox*>(reinterpret_cast<unsigned char*>(ws) + sdf_cull_bytes(B, num_faces));
+    hipLaunchKernelGGL(sdf_identity_box_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, box, W.flag, B);
+    const dim3 gf((num_faces + 255) / 256, B);
+    hipLaunchKernelGGL(sdf_cull_count_kernel, gf, dim3(256), 0, stream, vertices, num_vertices, (const SdfBox*)box, faces, num_faces,
+                       (const int*)nullptr, W);
+    hipLaunchKernelGGL(sdf_cull_scan_kernel, dim3(B), dim3(SDF_SCAN_NT), 0, stream, num_faces, (const int*)nullptr, W);
+    hipLaunchKernelGGL(sdf_cull_fill_kernel, gf, dim3(256), 0, stream, vertices, num_vertices, (const SdfBox*)box, faces, num_faces,
+                       (const int*)nullptr, W);
+    const int nvox = G * G * G;
+    hipLaunchKernelGGL(sdf_voxelize_culled_kernel, dim3((nvox + SDF_NT - 1) / SDF_NT, B), dim3(SDF_NT), 0, stream, num_faces, G, W, phi);
+    return hipGetLastError();
+}
+
 // entry list of one problem: the vertices that carry gradient, in ascending vertex order
 struct SdfEntry { int v; float g[3]; };                                  // vertex, dS/dvertex
 static_assert(sizeof(SdfEntry) == 16, "entry layout");

@@ -92,3 +92,46 @@ def test_sdf_matches_reference_kernel_goldens(name):
     flips = int(((phi > 0) != (ref > 0)).sum())
     assert flips == 0, flips
     assert np.array_equal(phi, ref), (np.abs(phi - ref).max(), int((phi != ref).sum()))
+
+
+@pytest.mark.parametrize('case', ['body', 'folded', 'edge'])
+def test_op_on_face_lists_gives_the_bits_of_the_walk(case):
+    """mvfit_sdf with a long face list works on per-call face lists (sdf_term.hip: projective bins for the crossing parity,
+    rings of cells for the minimum distance); MVFIT_SDF_CULL=0 keeps the walk over every face for every voxel.  Same bits,
+    every voxel, G = 128 and all 13,776 faces: a normalised body, a body with folded limbs (self-intersections), and a mesh
+    pushed against the -1 faces of the box (the lists do not cover it: its voxels walk all faces)."""
+    import os
+    import time
+    from mvsmplfitting_amd.engine import MvFit
+    model = syn.make_body_model(0, skin_topk=4)
+    eng = MvFit(model)
+    x = np.zeros((1, 118), np.float32)
+    x[0, 85] = 1
+    if case != 'body':
+        x[0, 13:82] = np.random.default_rng(5).normal(0, 0.5, 69)
+    eng.set_problems(syn.make_camera_ring(2), np.zeros((1, 2, 17, 2), np.float32), np.ones((1, 2, 17), np.float32))
+    v = eng.vertices(x)[0].cpu().numpy()[0]
+    c = 0.5 * (v.max(0) + v.min(0))
+    s = 1.2 * 0.5 * (v.max(0) - v.min(0)).max()
+    vn = ((v - c) / s).astype(np.float32)
+    if case == 'edge':
+        vn = (vn * 1.15 - 0.03).astype(np.float32)                          # min coordinate ~ -0.99: outside the lists' box
+    faces = torch.tensor(model['faces'], device='cuda', dtype=torch.int32)
+    vt = torch.tensor(vn[None], device='cuda')
+    res, ms = [], []
+    for cull in ('1', '0'):
+        os.environ['MVFIT_SDF_CULL'] = cull
+        try:
+            SDF(eng)(faces, vt, grid_size=128)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            phi = SDF(eng)(faces, vt, grid_size=128)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.time() - t0))
+            res.append(phi.cpu().numpy())
+        finally:
+            os.environ.pop('MVFIT_SDF_CULL', None)
+    print('mvfit_sdf, 13,776 faces, G = 128, %s: %.2f ms on lists, %.2f ms by the walk' % (case, ms[0], ms[1]))
+    assert (res[1] > 0).mean() > 0.005
+    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+    eng.close()
