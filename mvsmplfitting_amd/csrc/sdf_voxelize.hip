@@ -32,7 +32,9 @@ __global__ __launch_bounds__(SDF_NT) void sdf_voxelize_kernel(const int32_t* __r
     const int i = vid % G, j = (vid / G) % G, k = (vid / (G * G)) % G;
     const float c[3] = {sdf_voxel_coord(i, G), sdf_voxel_coord(j, G), sdf_voxel_coord(k, G)};
     const float* vb = vertices + (size_t)bn * num_vertices * 3;
-    float min_distance = 1000.f;
+    // two passes over the face list (the reference takes both quantities from one loop, :258-287): the crossing parity of
+    // every voxel first, then the minimum distance only where a voxel of the workgroup is inside - phi is 0 elsewhere, so
+    // a workgroup of 256 consecutive voxels that lies outside the mesh (most of the grid) skips the second walk
     int num_intersect = 0;
     for (int f0 = 0; f0 < num_faces; f0 += SDF_CH) {
         const int nf = min(SDF_CH, num_faces - f0);
@@ -43,14 +45,30 @@ __global__ __launch_bounds__(SDF_NT) void sdf_voxelize_kernel(const int32_t* __r
         }
         __syncthreads();
         if (!live) continue;
-        for (int t = 0; t < nf; ++t) {
-            const SdfTri& T = tri[t];
-            const float distance = sdf_tri_distance(T, c);
-            if (distance < min_distance) min_distance = distance;
-            if (sdf_ray_hit(T, c)) num_intersect++;
+        for (int t = 0; t < nf; ++t)
+            if (sdf_ray_hit(tri[t], c)) num_intersect++;
+    }
+    const bool inside = live && (num_intersect % 2 != 0);
+    float min_distance = 1000.f;
+    if (__syncthreads_or(inside ? 1 : 0)) {
+        for (int f0 = 0; f0 < num_faces; f0 += SDF_CH) {
+            const int nf = min(SDF_CH, num_faces - f0);
+            if (num_faces > SDF_CH) {                    // a single chunk is still staged from the first pass
+                __syncthreads();
+                for (int t = threadIdx.x; t < nf; t += SDF_NT) {
+                    const int a = faces[3 * (f0 + t)], b = faces[3 * (f0 + t) + 1], cc = faces[3 * (f0 + t) + 2];
+                    sdf_tri_setup(tri[t], vb + 3 * a, vb + 3 * b, vb + 3 * cc);
+                }
+                __syncthreads();
+            }
+            if (!inside) continue;
+            for (int t = 0; t < nf; ++t) {
+                const float distance = sdf_tri_distance(tri[t], c);
+                if (distance < min_distance) min_distance = distance;
+            }
         }
     }
-    if (live) phi[(size_t)bn * nvox + vid] = (num_intersect % 2 == 0) ? 0.f : min_distance;
+    if (live) phi[(size_t)bn * nvox + vid] = inside ? min_distance : 0.f;
 }
 
 hipError_t launch_sdf_voxelize(const int32_t* faces, int num_faces, const float* vertices, int B, int num_vertices, int G,
