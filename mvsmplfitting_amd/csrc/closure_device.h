@@ -327,7 +327,7 @@ __device__ __forceinline__ const unsigned long long* vps_answer_slot(const VpSer
 }
 
 // the three layers on the helpers (vposer_service.h): false = no answer, the caller decodes locally from now on
-__device__ bool vposer_layers_remote(const DevModel& M, ClosureLds& L, int tid) {
+__device__ __forceinline__ bool vposer_layers_remote(const DevModel& M, ClosureLds& L, int tid) {
     const VpService& V = M.vps;
     const unsigned seq = L.vp_seq + 1u, tag = seq << 2 | VPS_FWD;
     if (tid < 32) vps_store(vps_request_slot(V) + tid, L.opt.x[X_EMB + tid], tag);
@@ -719,7 +719,7 @@ __device__ __forceinline__ void chain_forward_block(ClosureLds& L, int tid) {
 // before the first FMA: the stream is then limited by bandwidth, not by one L2 round trip per row pair.
 __device__ __forceinline__ int fwd_slices(int, int) { return FWD_SLICES; }
 
-__device__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+__device__ __forceinline__ void contraction_forward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
     const int nc_pad = L.M.nc_pad;
     const int ncq = nc_pad >> 2;                   // float4 column groups
     for (int item = t; item < ncq * FWD_SLICES; item += nthreads) {
@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void chain_backward_wave(ClosureLds& L, int lane) {
 constexpr int BWD_SLICES = 8, BWD_CPS = NC_MAX / BWD_SLICES;     // up to 36 columns per slice
 __device__ __forceinline__ int bwd_slices(int) { return BWD_SLICES; }
 
-__device__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+__device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
     constexpr int npq = KROWS >> 2;                 // 56 float4 row groups
     const int nc_pad = L.M.nc_pad;
     const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;     // columns per slice (multiple of 4)

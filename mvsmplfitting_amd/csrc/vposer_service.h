@@ -146,7 +146,7 @@ struct VpHelperLds {
 struct VpTiles { const float4* tw2; const float4* tw3; const float* w1T; const float* b1; const float* b2; };
 
 // The helper's main loop; returns when every problem of its set has said goodbye (or nothing arrived for 0.2 s).
-__device__ __attribute__((noinline)) void vposer_helper(const VpTiles& T, const VpService& V, unsigned char* smem, int s, int h) {
+__device__ __attribute__((noinline)) void vposer_helper(const VpTiles T, const VpService V, unsigned char* smem, int s, int h) {      // (by value: a reference would pin the kernel argument they are members of to the stack, and the problem workgroups read it from there every round)
     if (V.fault) { if (threadIdx.x == 0) atomicAdd(V.stat + 1, 1u); return; }
     VpHelperLds& S = *reinterpret_cast<VpHelperLds*>(smem);
     const int tid = threadIdx.x, w = tid >> 6;
