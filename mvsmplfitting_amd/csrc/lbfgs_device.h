@@ -425,63 +425,83 @@ __device__ __forceinline__ void lb_cmp_rowdots(const LbHist<T>& Hh, LbWork<T>& W
 //   else: part2[0][g][slot(a)] = sum_{b in group g, b <= a} rinv{a,b} z_b                    (a = R^-T z)
 // Per-lane tables (slot of age, its triangle offset, the vector element), two ages per lane; the column's entries of the
 // tables arrive by v_readlane, its use mask (lanes a <= b, resp. a >= b) as a scalar bit field.
+// Triangular products with R^-1 (packed by slot) in ONE phase, in age space: item = (row age a, quarter q); the four lanes of a
+// row take its live columns with age b = q (mod 4), ascending - so the work is what the live window holds: a row of the
+// typical 40-60 pair history is ~12 columns per lane -, and the row total is ((p0 + p1) + p2) + p3 of the four lanes' sums,
+// taken with quad broadcasts: no partial sums in LDS, no combine phase, no second barrier.  (The grouping by b mod 4 and the
+// order of the four partial sums are those of the round's first version of this product, which ran the four groups on four
+// waves and met in LDS: the same bits.)  The lane with q = 0 finishes the row:
+//   FWD  w = sum_{a <= b < nE} Rinv(a, b) p_b and, when a pair has just been accepted (slot t, age n - 1), the new column of
+//        R^-1: Rinv(a, t) = -ro_t sum_b Rinv(a, b) u_b (u = S y_new), w += Rinv(a, t) p_t; row t itself is (ro_t p_t, ro_t).
+//        Nobody reads column t or row t in this phase (its age is outside nE), and the packed entry {slot(a), t} is the one
+//        the evicted pair's star occupied: written here, read from the next phase on.  Ages n .. 99 are the dead slots: 0.
+//   BWD  c = sum_{b <= a} Rinv(b, a) z_b.
+// Loads are issued four columns at a time before their first use.
 template <typename T, int NT, bool FWD>
 __device__ __forceinline__ void lb_cmp_tri(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
-    const int n = __builtin_amdgcn_readfirstlane(W.n), head = __builtin_amdgcn_readfirstlane(W.head);
-    const int t = FWD ? __builtin_amdgcn_readfirstlane(W.ins_slot) : -1;
+    const int n = W.n, head = W.head;
+    const int t = FWD ? W.ins_slot : -1;
     const int nE = (FWD && t >= 0) ? n - 1 : n;            // live columns of this product (the inserted pair is the newest)
-    const int lane = tid & 63;
     const T* xv = FWD ? W.bvec : W.zv;
-    // tables by age: ages lane and lane + 64
-    int sl[2], tr[2];
-    T xa[2], ua[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int sgl = head + min(lane + 64 * h, LB_HIST - 1);
-        sgl = sgl >= LB_HIST ? sgl - LB_HIST : sgl;
-        sl[h] = sgl; tr[h] = (sgl * (sgl + 1)) >> 1;
-        xa[h] = xv[sgl]; ua[h] = FWD ? W.gnew[sgl] : (T)0;
-    }
+    for (int r = LB_HIST + tid; r < 128; r += NT) (FWD ? W.alpha : W.cvec)[r] = (T)0;      // padding slots
     for (int item = tid; item < 4 * 128; item += NT) {
-        const int g = __builtin_amdgcn_readfirstlane(item >> 7), hb = __builtin_amdgcn_readfirstlane((item >> 6) & 1);   // (NT is a multiple of 64)
-        const int A0 = 64 * hb;                                            // the wave's rows: ages A0 .. A0 + 63
-        const int a = A0 + lane;
-        const int sa = hb ? sl[1] : sl[0], tsa = hb ? tr[1] : tr[0];
-        // columns of this wave: b = g + 4 k, restricted to the part of the triangle its rows can see
-        const int blo = FWD ? max(A0, 0) : 0, bhi = FWD ? nE : min(n, A0 + 64);
-        int k0 = (blo - g + 3) >> 2;                                       // first k with g + 4 k >= blo
-        k0 = k0 < 0 ? 0 : k0;
+        const int a = item >> 2, q = item & 3;
+        const int a0 = __builtin_amdgcn_readfirstlane(a);                   // the wave's first row (NT is a multiple of 64: 16 rows per wave)
+        if (a0 >= LB_HIST) break;                                           // uniform: nothing but padding from here on
+        const bool live = a < n;
+        int sa = head + min(a, LB_HIST - 1);
+        sa = sa >= LB_HIST ? sa - LB_HIST : sa;
         T s0 = (T)0, s1 = (T)0;
-        // columns below age 64 come from the first table register, the others from the second: two runs of chunks of 8 (the
-        // table is a compile-time choice inside a run: a run-time choice per column would be compiled to branches)
-        auto run = [&](auto hi_tag, int kbeg, int kend) {
-            constexpr int HI = decltype(hi_tag)::value;
-            const int slt = sl[HI], trt = tr[HI];
-            const T xt_ = xa[HI], ut_ = ua[HI];
-            for (int kb = kbeg; kb < kend; kb += 8) {                      // uniform trip count
-                T m[8];
+        if (a0 < n) {                                                       // uniform
+            // first column of this lane: the smallest b >= blo with b = q (mod 4); the wave's rows a0 .. a0 + 15 start at
+            // different columns in the forward product, so the uniform trip count is taken from the wave's first row
+            const int blo = FWD ? a : 0, bend = FWD ? nE : a + 1;
+            const int wlo = FWD ? (a0 & ~3) : 0, whi = FWD ? nE : min(a0 + 16, n);      // column range of the whole wave (multiple of 4 at the low end)
+            const int trips = (whi - wlo + 3) >> 2;
+            for (int k0 = 0; k0 < trips; k0 += 4) {                         // uniform trip count
+                T m[4], x[4], u[4];
+                bool use[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int bq = min(g + 4 * (kb + j), HI ? LB_HIST - 1 : 63);          // uniform (clamped: surplus columns are masked below)
-                    const int sb = __builtin_amdgcn_readlane(slt, bq & 63), tb = __builtin_amdgcn_readlane(trt, bq & 63);
-                    m[j] = Hh.rinv[sb <= sa ? tsa + sb : tb + sa];
+                for (int j = 0; j < 4; ++j) {
+                    const int bq = wlo + q + 4 * (k0 + j);
+                    use[j] = live && bq >= blo && bq < bend;
+                    int sb = head + min(max(bq, 0), LB_HIST - 1);
+                    sb = sb >= LB_HIST ? sb - LB_HIST : sb;
+                    const int hi = max(sa, sb), lo = min(sa, sb);
+                    m[j] = Hh.rinv[((hi * (hi + 1)) >> 1) + lo];
+                    x[j] = xv[sb];
+                    if (FWD) u[j] = W.gnew[sb];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int b = g + 4 * (kb + j), bq = min(b, HI ? LB_HIST - 1 : 63);
-                    const bool use = kb + j < kend && (FWD ? a <= b : (a >= b && a < n));
-                    const T mk = use ? m[j] : (T)0;
-                    s0 = fma(mk, lane_read(xt_, bq & 63), s0);
-                    if (FWD) s1 = fma(mk, lane_read(ut_, bq & 63), s1);
+                for (int j = 0; j < 4; ++j) {
+                    const T mk = use[j] ? m[j] : (T)0;
+                    s0 = fma(mk, use[j] ? x[j] : (T)0, s0);
+                    if (FWD) s1 = fma(mk, use[j] ? u[j] : (T)0, s1);
                 }
             }
-        };
-        const int kall = (bhi - g + 3) >> 2;                               // columns g + 4 k < bhi  <=>  k < kall
-        run(std::integral_constant<int, 0>{}, k0, min(kall, 16));
-        run(std::integral_constant<int, 1>{}, max(k0, 16), kall);
-        if (a < n) {
-            W.part2[0][g][sa] = s0;
-            if (FWD) W.part2[1][g][sa] = s1;
+            s0 = ((dpp_mov<0x00>(s0) + dpp_mov<0x55>(s0)) + dpp_mov<0xAA>(s0)) + dpp_mov<0xFF>(s0);
+            if (FWD) s1 = ((dpp_mov<0x00>(s1) + dpp_mov<0x55>(s1)) + dpp_mov<0xAA>(s1)) + dpp_mov<0xFF>(s1);
+        }
+        if (q == 0 && a < LB_HIST) {
+            if (FWD) {
+                T wr = (T)0;
+                if (live) {
+                    if (sa == t) {
+                        wr = Hh.ro[t] * W.bvec[t];
+                        Hh.rinv[lb_tri(t, t)] = Hh.ro[t];
+                    } else {
+                        wr = s0;
+                        if (t >= 0) {
+                            const T cr = -s1 * Hh.ro[t];
+                            Hh.rinv[lb_tri(sa, t)] = cr;
+                            wr = fma(cr, W.bvec[t], wr);
+                        }
+                    }
+                }
+                W.alpha[sa] = wr;
+            } else {
+                W.cvec[sa] = live ? s0 : (T)0;
+            }
         }
     }
 }
@@ -532,24 +552,6 @@ __device__ __forceinline__ void lb_direction_compact(const LbHist<T>& Hh, LbWork
     // ---- w = R^-1 p ; new column of R^-1 ----
     lb_cmp_tri<T, NT, true>(Hh, W, tid);
     __syncthreads();
-    for (int r = tid; r < 128; r += NT) {
-        T wr = (T)0;
-        if (r < LB_HIST && lb_age(r, head) < n) {
-            if (r == t) {
-                wr = Hh.ro[t] * W.bvec[t];
-                Hh.rinv[lb_tri(t, t)] = Hh.ro[t];
-            } else {
-                wr = ((W.part2[0][0][r] + W.part2[0][1][r]) + W.part2[0][2][r]) + W.part2[0][3][r];
-                if (t >= 0) {
-                    const T cr = -(((W.part2[1][0][r] + W.part2[1][1][r]) + W.part2[1][2][r]) + W.part2[1][3][r]) * Hh.ro[t];
-                    Hh.rinv[lb_tri(r, t)] = cr;
-                    wr = fma(cr, W.bvec[t], wr);
-                }
-            }
-        }
-        W.alpha[r] = wr;
-    }
-    __syncthreads();
     PH_T(17);
     // ---- t = Y w - q ----
     lb_cmp_matvec<T, NT>(Hh.dirs, Hh.ld, W.alpha, W, tid);
@@ -568,9 +570,6 @@ __device__ __forceinline__ void lb_direction_compact(const LbHist<T>& Hh, LbWork
     PH_T(19);
     // ---- a = R^-T z ----
     lb_cmp_tri<T, NT, false>(Hh, W, tid);
-    __syncthreads();
-    for (int r = tid; r < 128; r += NT)
-        W.cvec[r] = (r < LB_HIST && lb_age(r, head) < n) ? ((W.part2[0][0][r] + W.part2[0][1][r]) + W.part2[0][2][r]) + W.part2[0][3][r] : (T)0;
     __syncthreads();
     PH_T(20);
     // ---- d = S a - gamma t ----
