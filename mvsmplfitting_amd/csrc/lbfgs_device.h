@@ -371,6 +371,19 @@ __device__ __forceinline__ int lb_age(int slot, int head) { const int a = slot -
 // history rows . vector: 4 lanes per row (interleaved 4-element chunks), all LB_HIST slots in NT / 4 rows per pass.
 //   FIRST: p[slot] = s_slot . q  and, with a freshly inserted pair t, u[slot] = s_slot . y_t (0 for slot t)
 //   else : z[slot] = ys[slot] w[slot] + gamma (y_slot . t)
+// four consecutive elements of a 16-byte aligned row position as ONE LDS read (rows, work vectors and the history stride are
+// 16-byte multiples by construction; the compiler cannot see it through the run-time stride and would emit four reads)
+template <typename T>
+__device__ __forceinline__ void lb_load4(const T* p, T (&o)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = p[j];
+    }
+}
+
 template <typename T, int NT, bool FIRST>
 __device__ __forceinline__ void lb_cmp_rowdots(const LbHist<T>& Hh, LbWork<T>& W, int tid) {
     const int n = W.n, head = W.head, t = W.ins_slot, ld = Hh.ld;
@@ -395,12 +408,14 @@ __device__ __forceinline__ void lb_cmp_rowdots(const LbHist<T>& Hh, LbWork<T>& W
                 const int ch = q4 + 4 * (hb * HB + k);
                 const bool ok = ch < nch;
                 const int cc = 4 * min(ch, nch - 1);           // clamped chunk: the surplus lanes re-read the last chunk with zero coefficients
+                T v4[4], y4[4] = {(T)0, (T)0, (T)0, (T)0};
+                lb_load4(vec + cc, v4);
+                if (FIRST) lb_load4(ynew + cc, y4);
+                lb_load4(row + cc, rv[k]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const T v = vec[cc + j], y = FIRST ? ynew[cc + j] : (T)0;
-                    vv[k][j] = ok ? v : (T)0;
-                    yn[k][j] = (ok && two) ? y : (T)0;
-                    rv[k][j] = row[cc + j];
+                    vv[k][j] = ok ? v4[j] : (T)0;
+                    yn[k][j] = (ok && two) ? y4[j] : (T)0;
                 }
             }
 #pragma unroll
@@ -525,8 +540,7 @@ __device__ __forceinline__ void lb_cmp_matvec(const T* rows, int ld, const T* co
             const bool ok = (i0 + i) < NIT && r0 < LB_HIST && lb_age(r, head) < n && cok;
             const T cv = coef[r];
             cf[i] = ok ? cv : (T)0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[i][j] = rows[r * ld + c + j];
+            lb_load4(rows + r * ld + c, rv[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
