@@ -67,7 +67,7 @@ def _closure_case(num_faces, G, coll_w, nprob, use_vp=False):
     return res
 
 
-@pytest.mark.parametrize('num_faces,G,coll_w', [(1, 128, 40.0), (64, 32, 20.0), (None, 16, 0.5)])
+@pytest.mark.parametrize('num_faces,G,coll_w', [(1, 128, 40.0), (64, 32, 20.0), (300, 16, 5.0), (None, 16, 0.5)])   # one launch for <= 128 faces | box, staged walk, entries for <= 511 | face lists
 def test_closure_with_sdf_term_matches_oracle(num_faces, G, coll_w):
     res = _closure_case(num_faces, G, coll_w, nprob=1 if num_faces is None else 2)   # all faces: 20 s of oracle per problem
     assert any(r['S'] > 0 for r in res), 'test case does not exercise the term'
