@@ -751,20 +751,26 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
     const int b = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
     const float* vb = verts + (size_t)b * nv * 3;
+    float fraw[3][3];                                               // FUSED: the raw vertices of this thread's face (num_faces <= SDF_CH < threads)
     if constexpr (FUSED) {
+        // requested before the box is reduced: the two dependent round trips (indices, then vertices) of the list's setup
+        // then run under the reduction instead of behind it
+        if (tid < num_faces)
+            for (int m = 0; m < 3; ++m) {
+                const int vi = faces[3 * tid + m];
+                for (int a = 0; a < 3; ++a) fraw[m][a] = vb[3 * vi + a];
+            }
         sdf_box_reduce(verts, nv, b, tid, s_k, &sh_box);
         __syncthreads();
     }
     const SdfBox bx = FUSED ? sh_box : box[b];
     if constexpr (FUSED) {
         if (y == 0 && tid == 0) box[b] = bx;
-        for (int t = tid; t < num_faces; t += SDF_ADJ_NT) {
+        if (tid < num_faces) {
             float p[3][3];
-            for (int m = 0; m < 3; ++m) {
-                const int vi = faces[3 * t + m];
-                for (int a = 0; a < 3; ++a) p[m][a] = (vb[3 * vi + a] - bx.c[a]) / bx.s;     // fitting.py:362-363
-            }
-            sdf_tri_setup(tri[t], p[0], p[1], p[2]);
+            for (int m = 0; m < 3; ++m)
+                for (int a = 0; a < 3; ++a) p[m][a] = (fraw[m][a] - bx.c[a]) / bx.s;         // fitting.py:362-363
+            sdf_tri_setup(tri[tid], p[0], p[1], p[2]);
         }
         __syncthreads();
     }
@@ -812,7 +818,10 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
             cnt += __popcll(__ballot(act));
         }
     }
-    S = wave64_sum(S); gc0 = wave64_sum(gc0); gc1 = wave64_sum(gc1); gc2 = wave64_sum(gc2); gs = wave64_sum(gs);
+    S = wave64_sum(S);
+    if (__any(gc0 != 0.0 || gc1 != 0.0 || gc2 != 0.0 || gs != 0.0)) {      // (rare: only vertices next to a non-zero voxel carry these; sums of zeros are zeros)
+        gc0 = wave64_sum(gc0); gc1 = wave64_sum(gc1); gc2 = wave64_sum(gc2); gs = wave64_sum(gs);
+    }
     if (lane == 0) { sh_d[wave][0] = S; sh_d[wave][1] = gc0; sh_d[wave][2] = gc1; sh_d[wave][3] = gc2; sh_d[wave][4] = gs; sh_cnt[wave] = cnt; }
     __syncthreads();
     S = 0.0; gc0 = 0.0; gc1 = 0.0; gc2 = 0.0; gs = 0.0;
