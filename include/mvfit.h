@@ -222,7 +222,10 @@ int mvfit_fit_trace(mvfit_ctx* ctx, float* trace, int max_closures);
  *   faces[num_faces,3] int32 dev ; vertices[B,num_vertices,3] dev, coordinates in [-1,1] ; phi[B,G,G,G] dev out
  *   (phi[b,k,j,i]: i fastest = x).  num_faces is the caller's faces.size(0), exactly as the reference launcher
  *   takes it (sdf_cuda_kernel.cu:314; the reference's own call site passes a [1,F,3] tensor, i.e. ONE triangle).
- * Stand-alone op; the loss term below evaluates the same voxel function without materialising phi. */
+ * Stand-alone op; the loss term below evaluates the same voxel function without materialising phi.
+ * Face lists of 512 faces and more are voxelised on per-call face lists (exact culling: the same bits as the walk
+ * over every face for every voxel, which the environment variable MVFIT_SDF_CULL=0 keeps; the workspace, 11.6 MB per batch
+ * element at 13,776 faces, is kept in the ctx between calls of one shape). */
 int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* vertices, int B,
               int num_vertices, int G, float* phi);
 
@@ -235,7 +238,9 @@ int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* 
  *   full face count for the behaviour its author presumably intended.  grid_size: 128 in the reference (:368).
  *   faces = NULL or num_faces = 0 removes the term.
  * Every problem is one person (the reference asserts batch size 1, :366): boxes, phi and the sum are per problem.
- * The term reads all vertices, so MVFIT_F_SPARSE_VERTS is ignored while it is active. */
+ * The term reads all vertices, so MVFIT_F_SPARSE_VERTS is ignored while it is active.
+ * With 512 faces and more the sampled corners take their values from per-round face lists (same bits as the walk over
+ * every face; MVFIT_SDF_CULL=0 keeps the walk; a batch whose workspace would not fit in half of the free memory keeps it too). */
 int mvfit_set_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, int grid_size);
 
 /* Diagnostics of the last evaluated interpenetration term (after mvfit_closure with coll_loss_weight > 0):
