@@ -784,12 +784,27 @@ __device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L,
     if (tid < nc) {
         const int c = tid, s = c / 3, a = c - 3 * s;
         float4 tr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (L.M.sel_sparse) {
+            // <= 4 non-zero weights per vertex (the SMPL family): the non-zero products of the dense row, ascending joint
+            const float4 w4 = *reinterpret_cast<const float4*>(L.M.selw[s]);
+            const unsigned jj = L.M.selj[s];
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            float4 av[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const float4*>(&L.pose.A[(jj >> (8 * t)) & 255u][4 * a]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                tr.x = fmaf(wv[t], av[t].x, tr.x); tr.y = fmaf(wv[t], av[t].y, tr.y);
+                tr.z = fmaf(wv[t], av[t].z, tr.z); tr.w = fmaf(wv[t], av[t].w, tr.w);
+            }
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < NJ; ++j) {
-            const float w = L.M.wT[j][s];
-            const float4 av = *reinterpret_cast<const float4*>(&L.pose.A[j][4 * a]);
-            tr.x = fmaf(w, av.x, tr.x); tr.y = fmaf(w, av.y, tr.y);
-            tr.z = fmaf(w, av.z, tr.z); tr.w = fmaf(w, av.w, tr.w);
+            for (int j = 0; j < NJ; ++j) {
+                const float w = L.M.wT[j][s];
+                const float4 av = *reinterpret_cast<const float4*>(&L.pose.A[j][4 * a]);
+                tr.x = fmaf(w, av.x, tr.x); tr.y = fmaf(w, av.y, tr.y);
+                tr.z = fmaf(w, av.z, tr.z); tr.w = fmaf(w, av.w, tr.w);
+            }
         }
         *reinterpret_cast<float4*>(&L.T[s][4 * a]) = tr;
         if (!from_pass) {

@@ -848,6 +848,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         G.ns = M.ns; G.nc = M.nc; G.nc_pad = M.nc_pad;
         M.sel_v = dev_upload(c, sel);
         std::vector<float> pds((size_t)KROWS * M.nc_pad, 0.f), pdsT((size_t)M.nc_pad * KROWS, 0.f);
+        int sel_sparse = 1;
         for (int s = 0; s < M.ns; ++s) {
             const int v = sel[s];
             G.sel_v[s] = v;
@@ -862,7 +863,18 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 }
             }
             for (int j = 0; j < NJ; ++j) G.wT[j][s] = m->lbs_weights[(size_t)v * NJ + j];
+            int np = 0;
+            G.selj[s] = 0u;
+            for (int t = 0; t < 4; ++t) G.selw[s][t] = 0.f;
+            for (int j = 0; j < NJ; ++j) {
+                const float w = m->lbs_weights[(size_t)v * NJ + j];
+                if (w == 0.f) continue;
+                if (np < 4) { G.selw[s][np] = w; G.selj[s] |= (unsigned)j << (8 * np); }
+                ++np;
+            }
+            if (np > 4) sel_sparse = 0;
         }
+        G.sel_sparse = sel_sparse;
         M.pd_sub = dev_upload(c, pds);
         M.pd_subT = dev_upload(c, pdsT);
         // selection in CSR form, both ways

@@ -68,6 +68,11 @@ struct ModelLds {
     int anc_tab[5][NJ];
     int n_jump, jpad0, jpad1, jpad2;
     int ns, nc, nc_pad, pad0;
+    // the selected vertices' skinning weights as <= 4 (weight, joint) pairs in ascending joint order, zero-padded (the
+    // non-zero products of the dense row in the same order: the same bits); sel_sparse = 0 when a row has more than 4
+    float selw[NS_MAX][4];
+    unsigned selj[NS_MAX];            // four joint indices, one per byte
+    int sel_sparse, spad0, spad1, spad2;
 };
 static_assert(sizeof(ModelLds) % 16 == 0, "ModelLds is bulk-copied as 16-byte words");
 
