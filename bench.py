@@ -116,6 +116,93 @@ def measure_pmc(B, launches=40, timeout_s=90):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def measure_pmc_resident(B, timeout_s=120):
+    """The same three PMC passes on the RESIDENT pass (tools/pmc_vertex_pass.py drive_resident): one fit's resident launch +
+    three stand-alone resident launches; every dispatch of the kernel summed and divided by the closure rounds they served.
+    Returns dict(traffic_bytes_per_round, mfma_busy_cycles_per_round, rounds_served, dispatches) or None."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None
+    from tools import pmc_vertex_pass as pv
+    out = tempfile.mkdtemp(prefix='mvfit_pmc_')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    tot = {}
+    side = None
+    try:
+        for cn in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
+            d = os.path.join(out, cn)
+            sf = os.path.join(out, cn + '.json')
+            cmd = [exe, '--pmc', cn, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable,
+                   os.path.join(ROOT, 'tools', 'pmc_vertex_pass.py'), 'drive_resident', str(B), sf]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            with open(sf) as f:
+                side = json.load(f)
+            if not side['rounds_served']:
+                return None
+            t = pv.parse(None, ['x=%s' % d]).get('x', {})
+            e = next((v for k, v in t.items() if 'resident' in k), None)
+            if e is None:
+                return None
+            key = cn + ('_KiB_avg' if cn != 'SQ_VALU_MFMA_BUSY_CYCLES' else '_avg')
+            tot[cn] = e[key] * e['launches_' + cn] / side['rounds_served']
+        return dict(traffic_bytes_per_round=round((2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0),
+                    mfma_busy_cycles_per_round=tot['SQ_VALU_MFMA_BUSY_CYCLES'], rounds_served=side['rounds_served'],
+                    dispatches=side['dispatches'])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc):
+    """roofline object of the RESIDENT vertex pass (one launch per fit; csrc/vertex_pass.hip): the "launch duration" of a
+    closure round is its service span stamped inside the kernel during one complete profiled fit - last workgroup's vertex
+    stores acknowledged minus first workgroup saw the round's operands (wall clock, 10 ns) - because a per-round launch no
+    longer exists; next to it the pass ALONE (HIP events around one resident launch that serves 100 rounds back to back:
+    the figure rocprofv3 --kernel-trace shows as that dispatch's duration / 100)."""
+    span_ms = pp['round_span_ms']
+    alone_ms = min(eng.profile_resident_pass_ms(100) for _ in range(3))
+    ach = nbytes / (span_ms * 1e-3) / 1e9
+    # what a round still has to move: the vertices out + the round's operands in (read by every workgroup from L2 / MALL,
+    # once from HBM) - SURVEY 8(d)'s per-problem figure; the 18.2 MB of constants cross the memory system once per FIT
+    moved = PER_PROBLEM_BYTES * B
+    table = measure_pmc_resident(B) if with_pmc else None
+    roof = dict(bound='hbm', kernel='lbs_vertex_pass_resident_kernel<%d>' % pp['tiles_per_workgroup'],
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+                algorithmic_bytes=nbytes, avg_launch_us=round(span_ms * 1e3, 2),
+                avg_launch_note='resident pass: no per-round launch exists; this is the in-fit service span of a closure round '
+                                '(max over workgroups of stores acknowledged - min over workgroups of operands seen), mean over '
+                                'the %d rounds of one complete profiled fit' % pp['rounds_stamped'],
+                workgroup_busy_us=round(pp['workgroup_busy_ms'] * 1e3, 2),
+                alone_per_round_us=round(alone_ms * 1e3, 2),
+                frac_alone=round(nbytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                alone_note='HIP events on the launch stream around ONE resident launch serving 100 rounds from the ring, / 100',
+                workgroups=pp['workgroups'], tiles_per_workgroup=pp['tiles_per_workgroup'],
+                bytes_moved_per_round_algorithmic=moved,
+                frac_of_peak_for_bytes_moved=round(moved / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                bytes_note='algorithmic_bytes is SURVEY 8(d)\'s per-launch figure (constants re-read every round), kept so that the '
+                           'fraction is comparable with the earlier rounds; the resident pass reads the 18.2 MB of constants ONCE '
+                           'per fit, so frac can exceed what the bytes actually moved per round (bytes_moved_per_round_algorithmic) '
+                           'would give - the pass is latency-bound, not bandwidth-bound',
+                traffic=None if table is None else table['traffic_bytes_per_round'],
+                traffic_source=None if table is None else
+                ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes collected in this run on %d '
+                 'dispatches of the resident kernel serving %d closure rounds (2 x FETCH_SIZE + WRITE_SIZE, per round; includes '
+                 'the basis once per dispatch)' % (table['dispatches'], table['rounds_served'])),
+                mfma_util=None if table is None else mfma_util(table['mfma_busy_cycles_per_round'], span_ms * 1e3),
+                mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per round / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',
+                timed_region='every closure round of one complete fit, stamped inside the resident kernel (s_memrealtime) on the pass '
+                             'stream; profiles/: rocprofv3 --kernel-trace of the same command shows the resident dispatch itself',
+                launch_flavour='asynchronous fit: ONE resident launch per fit, basis stationary in registers, operands from the ring '
+                               '(sc1 loads), non-temporal vertex stores, the optimiser kernel on %d other CUs' % min(B, 128),
+                launches_per_fit=1, rounds_per_fit=(passes or {}).get('run'))
+    return roof
+
+
 def mfma_util(busy_cycles, launch_us):
     """Matrix-pipe utilisation of a launch: SQ_VALU_MFMA_BUSY_CYCLES (PMC, summed over the chip's SIMDs) over launch
     duration x 2.4 GHz x 1024 SIMDs.  Small by design: the contraction is the only MFMA work of the path (north_star)."""
@@ -158,6 +245,52 @@ def demo_inputs(syn):
     f = g['x0']                                  # reference order with VPoser: betas go transl scale embedding
     x0[0, 0:10] = f[0:10]; x0[0, 10:13] = f[10:13]; x0[0, 82:85] = f[13:16]; x0[0, 85] = f[16]; x0[0, 86:118] = f[17:49]
     return g, vpw, model, cams, g['gt_xy'][None].astype(np.float32), g['conf'][None].astype(np.float32), x0
+
+
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_reference(model, cams, gt, conf, stages, use_vposer, vpw, budget_s=10.0):
+    """north_star: "the reference timed on the same box's host cores (core count stated) in the same run".  The reference
+    itself - create_fitting_closure + LBFGSLs + run_fitting in the stage loop of non_linear_solver (float32, the frames of this
+    very batch, from the same start) - imported from /root/reference (build container) or from the archive `make -C oracle
+    stage` ships to the GPU box (oracle/_ref/reference_stage.tgz; test infrastructure, see oracle/ref_import.py).  Timed at 1
+    thread and at 8 threads (SURVEY section 6's two settings) for ~budget_s each, plus the raw closure rate.  None when no
+    reference is present."""
+    from oracle import ref_import as ri
+    if not ri.available():
+        return None
+    ncpu = os.cpu_count() or 1
+    runs = {}
+    for threads in (1, min(8, ncpu)):
+        r = ri.time_reference_fits(model, cams, gt, conf, stages, use_vposer=use_vposer, vposer_weights=vpw, threads=threads,
+                                   budget_s=budget_s)
+        raw = ri.time_reference_closure(model, cams, gt[0], conf[0], stages[0], use_vposer=use_vposer, vposer_weights=vpw,
+                                        threads=threads, calls=100)
+        runs[threads] = dict(closures_per_s=round(r['closures'] / r['seconds'], 1), frames=r['frames'], closures=r['closures'],
+                             seconds=round(r['seconds'], 2), ms_per_frame=round(1e3 * r['seconds'] / r['frames'], 1),
+                             final_loss_first_frame=float(r['final_losses'][0]) if r['final_losses'][0] is not None else None,
+                             raw_closure_fwd_bwd_per_s=round(raw, 1))
+    torch.set_num_threads(1)
+    best = max(runs, key=lambda t: runs[t]['closures_per_s'])
+    return dict(value=runs[best]['closures_per_s'], unit='closures/s', cores=best, kind='reference',
+                sample='%d of the %d frames of this batch, full 4-stage fits from the same start (%d closures in %.1f s): the '
+                       'reference itself (code/utils/fitting.py create_fitting_closure + run_fitting, code/optimizers/lbfgs_ls.py '
+                       'LBFGSLs; float32, PyTorch %s CPU), %d thread(s) - the faster of the 1- and %d-thread runs - of %d host '
+                       'cores (%s); %s' % (runs[best]['frames'], gt.shape[0], runs[best]['closures'], runs[best]['seconds'],
+                                           torch.__version__, best, max(runs), ncpu, cpu_model_name(),
+                                           'imported from the staged archive oracle/_ref/reference_stage.tgz' if ri.STAGED
+                                           else 'imported from /root/reference'),
+                host_cores=ncpu, cpu_model=cpu_model_name(),
+                threads={'threads_%d' % t: v for t, v in runs.items()})
 
 
 def cpu_baseline(model, cams, gt, conf, stages, use_vposer, vpw, budget_s=15.0):
@@ -295,7 +428,39 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
         out[name] = dict(kernel=kern if skin_topk else kern.replace('<true>', '<false>'), problems=B,
                          avg_launch_us=round(ms * 1e3, 2), algorithmic_bytes=nbytes,
                          achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                         measured='the per-round launch kernel ALONE (64 back-to-back launches inside one hipEvent pair)',
                          traffic=pmc_value(key, 'vertex_pass_pipe') if key else None)
+    # the pass INSIDE a fit at 128 problems (the per-GPU share of configs[3]): one complete profiled 4-stage fit
+    for name, env in (('split_fp16_B128', {}), ('half_basis_B128', {'MVFIT_HALF_BASIS': '1'})):
+        try:
+            from mvsmplfitting_amd.engine import stage_weights
+            eng = with_env(env, lambda: MvFit(model))
+            cams_b, gt, conf, x0 = build_inputs(eng, syn, 0, 128, 1, views)
+            st = stage_weights(1536.0)
+            x0_d = torch.tensor(x0, device=eng.device)
+            eng.fit(x0_d, st)                                      # warm
+            eng.profile(True)
+            xf, stt = eng.fit(x0_d, st)
+            pr = eng.profile_read()
+            pp = eng.pass_profile()
+            eng.profile(False)
+            nbytes = bytes_fwd(128, skin_topk, half_basis='MVFIT_HALF_BASIS' in env)
+            ms = pr['vertex_pass_ms']
+            e = out[name]
+            e['in_fit'] = dict(
+                kernel=('lbs_vertex_pass_resident_kernel<%d>' % pp['tiles_per_workgroup']) if pp['tiles_per_workgroup'] else e['kernel'],
+                avg_launch_us=round(ms * 1e3, 2), rounds=pr['vertex_pass_launches'],
+                frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                workgroups=pp['workgroups'], workgroup_busy_us=round(pp['workgroup_busy_ms'] * 1e3, 2),
+                alone_per_round_us=round(min(eng.profile_resident_pass_ms(100) for _ in range(3)) * 1e3, 2) if pp['tiles_per_workgroup'] else None,
+                passes=stt['passes'],
+                note='service span of a closure round inside one complete 128-problem fit (resident pass: stamped in the kernel; '
+                     'per-round launches: the dispatches\' own begin / end)')
+            if e['in_fit']['frac'] is not None:
+                e['frac_in_fit'] = e['in_fit']['frac']
+            eng.close()
+        except Exception as ex:                                 # noqa: BLE001 - an extra must not kill the headline line
+            out[name]['in_fit'] = {'error': repr(ex)}
     return out
 
 
@@ -573,27 +738,32 @@ def main():
         eng.profile(True)
         eng.fit(x0_d, stages)
         pr = eng.profile_read()
+        pp = eng.pass_profile()
         eng.profile(False)
         # (b) the kernel alone: 64 back-to-back launches inside one hipEvent pair, in the fit's launch flavour and with
         #     plain loads
+        nbytes = bytes_fwd(B, args.skin_topk, half_basis)
+        standard = views == 8 and args.skin_topk == 4 and not half_basis
+        resident = in_fit and pp['tiles_per_workgroup'] > 0 and pp['rounds_stamped'] > 0
+        if resident:
+            roof = resident_roofline(eng, B, nbytes, pr, pp, passes,
+                                     with_pmc=rank == 0 and world == 1 and not args.no_pmc and standard)
         ms_b2b = min(eng.profile_vertex_pass_ms(64, as_in_async_fit=in_fit) for _ in range(3))
         ms_plain = min(eng.profile_vertex_pass_ms(64) for _ in range(3))
         ms_fit = pr['vertex_pass_ms'] if pr['vertex_pass_launches'] > 0 else ms_b2b
-        nbytes = bytes_fwd(B, args.skin_topk, half_basis)
         ach = nbytes / (ms_fit * 1e-3) / 1e9
         # (c) HBM-side traffic / matrix-pipe cycles per launch: rocprofv3 PMC passes run NOW on this GPU (rank 0, one GPU),
         #     else the committed summary of the same kernel
         pmc_key = 'B%d' % B
         table, src = None, None
-        standard = views == 8 and args.skin_topk == 4 and not half_basis
-        if rank == 0 and world == 1 and not args.no_pmc and standard:
+        if rank == 0 and world == 1 and not args.no_pmc and standard and not resident:
             table = measure_pmc(B)
             src = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes, collected in this run (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 wide-read correction)'
         if table is None and standard and pmc_file():
             src = '%s (rocprofv3 --pmc passes of an earlier run of the same kernel; tools/collect_profiles.sh)' % os.path.relpath(pmc_file(), ROOT)
         traffic = pmc_value(pmc_key, kname.split('<')[0], 'traffic_bytes', table) if standard else None
         busy_cy = pmc_value(pmc_key, kname.split('<')[0], 'mfma_busy_cycles_per_launch', table) if standard else None
-        roof = dict(bound='hbm', kernel=kname, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+        per_round = dict(bound='hbm', kernel=kname, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=src if traffic is not None else None,
                     algorithmic_bytes=nbytes, avg_launch_us=round(ms_fit * 1e3, 2),
                     mfma_util=mfma_util(busy_cy, ms_fit * 1e3),
@@ -605,6 +775,14 @@ def main():
                     alone_back_to_back_us=round(ms_b2b * 1e3, 2), alone_back_to_back_plain_loads_us=round(ms_plain * 1e3, 2),
                     frac_alone_plain_loads=round(nbytes / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     launches_per_fit=(passes or {}).get('run'))
+        if resident:
+            # the per-round launch kernels stay in the library (dense skinning rows, exact-fp32 contraction, launches that
+            # leave no CUs): their stand-alone figures next to the resident pass
+            roof['per_round_launch_kernel_alone'] = dict(kernel=kname, alone_back_to_back_us=round(ms_b2b * 1e3, 2),
+                                                         alone_back_to_back_plain_loads_us=round(ms_plain * 1e3, 2),
+                                                         frac_alone_plain_loads=round(nbytes / (ms_plain * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        else:
+            roof = per_round
         if rank == 0 and not args.no_variants and world == 1 and args.config == 'configs1':
             roof['variants'] = vertex_pass_variants(MvFit, syn, model, views, args.skin_topk)
 
@@ -623,7 +801,12 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.prior != 'gmm':
             cpu_stages = [dict(s) for s in stages]
-            cpu = cpu_baseline(model, cams, gt, conf, cpu_stages, args.prior == 'vposer', vpw)
+            port = cpu_baseline(model, cams, gt, conf, cpu_stages, args.prior == 'vposer', vpw, budget_s=8.0)
+            cpu = cpu_baseline_reference(model, cams, gt, conf, cpu_stages, args.prior == 'vposer', vpw)
+            if cpu is None:                                  # no reference on this box: the port stands in, and says so
+                cpu = port
+            else:
+                cpu['port'] = port
             cpu['reference_in_survey_container'] = dict(
                 value=list(SURVEY_REFERENCE_CLOSURES_PER_S), unit='closures/s',
                 note='the imported reference itself (create_fitting_closure + LBFGSLs + run_fitting, PyTorch CPU, 1 and 8 '

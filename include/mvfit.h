@@ -307,6 +307,21 @@ int mvfit_profile_vertex_pass(mvfit_ctx* ctx, int launches, double* avg_ms);
 /* flavour 0: as above; 1: the pass exactly as the asynchronous fit launches it (operands from its ring, non-temporal
  * basis stream and vertex stores, no side outputs) - needs a preceding asynchronous mvfit_fit on this batch. */
 int mvfit_profile_vertex_pass_ex(mvfit_ctx* ctx, int launches, int flavour, double* avg_ms);
+/* How the vertex passes of the last asynchronous mvfit_fit ran:
+ *   *tiles_per_wg  1 / 2: the RESIDENT pass - one launch per (sub-batch) fit whose workgroups keep the blendshape basis of
+ *                  their vertex tile(s) in registers and serve closure round after closure round from the operand ring
+ *                  (the basis crosses the memory system once per fit); 0: one gate + one pass launch per closure round
+ *                  (dense skinning rows, exact-fp32 contraction, or launches that leave no CUs for resident workgroups);
+ *   *workgroups    workgroups of the resident pass (ceil(tiles / tiles_per_wg));
+ * and, when the fit ran under mvfit_profile(ctx, 1) with the resident pass, what its workgroups stamped per closure round
+ * (wall clock, 10 ns ticks; the first 1024 rounds of the last sub-batch):
+ *   *rounds        rounds stamped;
+ *   *span_ms       mean over the rounds of (last workgroup's vertex stores acknowledged - first workgroup saw the round's
+ *                  operands): the in-fit service time of a round - what mvfit_profile_read reports as the launch duration;
+ *   *busy_ms       mean over rounds and workgroups of a workgroup's own (stores acknowledged - operands seen).
+ * Any pointer may be NULL.  flavour 2 of mvfit_profile_vertex_pass_ex runs the resident pass ALONE over `launches` (<= 128)
+ * rounds whose operands the last fit left in the ring: one kernel launch inside one hipEvent pair, avg_ms = elapsed / rounds. */
+int mvfit_pass_profile(mvfit_ctx* ctx, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms);
 
 /* Known-answer test entry for the device L-BFGS state machine (same template as production,
  * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.

@@ -53,7 +53,7 @@ class LbfgsOpts(C.Structure):
 
 
 EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',
-           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_depth_guess', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex',
+           'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_depth_guess', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex', 'mvfit_pass_profile',
            'mvfit_lbfgs_kat']
 
 
@@ -120,6 +120,9 @@ def load():
     lib.mvfit_profile_vertex_pass.restype = C.c_int
     lib.mvfit_profile_vertex_pass_ex.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.mvfit_profile_vertex_pass_ex.restype = C.c_int
+    lib.mvfit_pass_profile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mvfit_pass_profile.restype = C.c_int
     lib.mvfit_lbfgs_kat.argtypes = [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(LbfgsOpts),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_double)]

@@ -1398,8 +1398,16 @@ __device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRin
         if (have < need) {
             const long long t0 = wall_clock64();
             for (;;) {
-                have = __hip_atomic_load(R.pass_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (have >= need || wall_clock64() - t0 > 2000000) break;
+                // the minimum over the consumers' words: one (the gate kernels of the per-round launches) or one per
+                // workgroup of the resident pass
+                have = 0xffffffffu;
+                for (int i = l; i < R.npass; i += 64)
+                    have = min(have, __hip_atomic_load(R.pass_done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                for (int o = 32; o; o >>= 1) have = min(have, (unsigned)__shfl_xor((int)have, o));
+                if (have >= need) break;
+                // timed out: stop waiting for the passes for the rest of this fit (the overwritten slots are counted as
+                // missed by the pass and fit() reports them) instead of stalling 20 ms in every further round
+                if (wall_clock64() - t0 > 2000000) { have = 0xffffffffu; break; }
                 __builtin_amdgcn_s_sleep(16);
             }
             if (l == 0) L.sh_pass_done = have;

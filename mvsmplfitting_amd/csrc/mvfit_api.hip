@@ -29,6 +29,7 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
                               hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t vertex_pass_configure();
 hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t stream);
+hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
                            void* cull);
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     __syncthreads();
     if (L.opt.lbS.status != 0) {
         if (REMOTE && tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
+        if (tid == 0 && ring.tag)           // finished in an earlier launch: no pass waits for this problem
+            __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
@@ -432,14 +435,15 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         if (L.sh_stage >= pause_stage) { paused = true; break; }
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
+    // passes of later rounds have nothing to wait for from this problem - whatever ended the launch for it (finished, paused
+    // at a stage boundary, or the round cap: the resident pass ends when every problem has said so)
+    if (tid == 0 && ring.tag)
+        __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0 && (done || paused)) {
         if (done) atomicAdd(F.n_done, 1);
         const int left = atomicAdd(F.n_done + 1, 1) + 1;
-        if (ring.tag) {
-            // passes of later rounds have nothing to wait for from this problem; the last problem tells the host
-            __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        // the last problem tells the host (per-round pass launches: it stops queueing them)
+        if (ring.tag && left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!done) {
         for (int i = tid; i < LB_HIST * ldh; i += STEP_NT) {
@@ -611,6 +615,12 @@ struct mvfit_ctx {
     hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr}, ev_init = nullptr;
     int* h_async_done = nullptr;       // pinned host word the last finishing problem writes
     unsigned async_stats[4] = {0, 0, 0, 0};
+    int n_cu = 0;                      // compute units of the device (residency of the resident vertex pass)
+    int resident_tpw = 0;              // tiles per workgroup of the resident pass in the last asynchronous fit (0: per-round launches)
+    unsigned long long* d_vp_log = nullptr;     // mvfit_profile: per-round stamps of the resident pass [kVpLogRounds][grid][2]
+    size_t vp_log_words = 0;
+    double res_span_ms = 0.0, res_busy_ms = 0.0;    // mean per-round service span / mean per-workgroup busy time (last profiled fit)
+    int res_rounds = 0;
     // decoder helpers of the single-launch fit (vposer_service.h): granule memory [requests | answers | 2 counters]
     unsigned long long* vps_mem = nullptr;
     size_t vps_words = 0;
@@ -1072,6 +1082,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     for (void* p : c->allocs) if (!p) return fail(c, MVFIT_E_HIP, "device allocation failed");
     if (c->upload_failed) return fail(c, MVFIT_E_HIP, "copying the model constants to the device failed");
     HIP_OK(c, vertex_pass_configure());
+    HIP_OK(c, hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
     HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(closure_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds()));
@@ -1119,6 +1130,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     free_problem_buffers(c);
     if (c->d_sdf_faces) hipFree(c->d_sdf_faces);
     if (c->d_sdf_op_ws) hipFree(c->d_sdf_op_ws);
+    if (c->d_vp_log) hipFree(c->d_vp_log);
     for (void* p : c->allocs) if (p) hipFree(p);
     if (c->h_done) hipHostFree(c->h_done);
     for (hipEvent_t e : c->ev_done) if (e) hipEventDestroy(e);
@@ -1501,6 +1513,9 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
 static const int kRingSlots = 128;
 static const int kPassBatch = 24;
 static const int kAsyncMaxB = 160;        // one CU per problem for the optimiser: leave >= 96 CUs to the passes
+static const int kResidentMaxB = 128;     // with the resident pass: its workgroups (ntiles / 2 at this size) hold a CU each for the whole fit
+static const int kPassWords = 512;        // back-pressure words of the ring (one per resident-pass workgroup; the gate kernels use word 0)
+static const int kVpLogRounds = 1024;     // mvfit_profile: rounds of the resident pass that are stamped
 
 // The ring is sized by the SUB-BATCH (rb problems, a multiple of 32), not by the batch: only one sub-batch uses it at a
 // time (128 slots x 2.06 KB per problem: 34 MB at 128 problems whatever the batch size).  Everything indexed by ring slot
@@ -1529,7 +1544,7 @@ static int ensure_async(mvfit_ctx* c, int rb) {
     HIP_OK(c, hipMalloc(&R.tag, kRingSlots * Bp * 4));
     HIP_OK(c, hipMalloc(&R.done_round, (size_t)c->Bpad * 4));
     HIP_OK(c, hipMalloc(&R.stats, 4 * 4));
-    HIP_OK(c, hipMalloc(&R.pass_done, 4));
+    HIP_OK(c, hipMalloc(&R.pass_done, 4 * kPassWords));
     HIP_OK(c, hipMemset(R.coefH, 0, kRingSlots * Bp * KROWS * 4));
     HIP_OK(c, hipMemset(R.Amat, 0, kRingSlots * Bp * 288 * 4));
     HIP_OK(c, hipMemset(R.tau, 0, kRingSlots * Bp * 4 * 4));
@@ -1551,18 +1566,25 @@ static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
     return (SW.w[0].flags & MVFIT_F_VPOSER) && c->vps_mem && !off;
 }
 
+// decoder-helper sets a single-launch fit of n problems carries (0: none)
+static int persistent_nsets(const mvfit_ctx* c, const StageWeights& SW, int n) {
+    if (!(vps_enabled(c, SW) && n <= kVpsMaxSparse)) return 0;
+    // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
+    const char* e = getenv("MVFIT_VP_SETS");
+    const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
+    // at least ceil(n / VPS_PMAX) sets: a set has VPS_PMAX request / answer slots (the knob cannot push problems past them)
+    const int need = (n + VPS_PMAX - 1) / VPS_PMAX;
+    return std::max(need, std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n));
+}
+// workgroups of that launch: one per problem + the helpers behind them, one CU each (LDS)
+static int persistent_grid(const mvfit_ctx* c, const StageWeights& SW, int n) { return n + persistent_nsets(c, SW, n) * VPS_SLICES; }
+
 static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, const AsyncRing& R, int b_lo,
                              int b_hi, int done_target, int pause_stage) {
     const int n = b_hi - b_lo;
     DevModel M = c->M;
     int grid = n;
-    if (vps_enabled(c, SW) && n <= kVpsMaxSparse) {
-        // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
-        const char* e = getenv("MVFIT_VP_SETS");
-        const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
-        // at least ceil(n / VPS_PMAX) sets: a set has VPS_PMAX request / answer slots (the knob cannot push problems past them)
-        const int need = (n + VPS_PMAX - 1) / VPS_PMAX;
-        const int nsets = std::max(need, std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n));
+    if (const int nsets = persistent_nsets(c, SW, n)) {
         HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8, c->stream));
         M.vps.req = c->vps_mem;
         M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;
@@ -1583,23 +1605,54 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
     return MVFIT_OK;
 }
 
+// How the passes of an asynchronous (sub-batch) fit run: tiles per workgroup of the RESIDENT pass (one launch per fit, basis
+// stationary in registers; its ceil(ntiles / tpw) workgroups must all be resident next to the optimiser's `opt_grid` ones,
+// every one of them a CU), or 0 = a gate + a pass launch per closure round (dense skinning rows, exact-fp32 contraction,
+// launches that do not leave the CUs - e.g. 160 optimiser + helper workgroups with the VPoser prior).
+// MVFIT_VP_RESIDENT=0 / 1 / 2 forces the choice (developer switch; a forced value that does not fit can stall the fit).
+static int resident_tiles_per_wg(const mvfit_ctx* c, int opt_grid) {
+    if (!c->M.bs_h2 || !c->M.wsp_w) return 0;
+    if (const char* e = getenv("MVFIT_VP_RESIDENT")) return std::max(0, std::min(atoi(e), 2));
+    const int room = c->n_cu - 4 - opt_grid;           // (4 CUs of slack: nothing in HIP promises that every CU takes a workgroup)
+    if (c->M.ntiles <= room) return 1;
+    if ((c->M.ntiles + 1) / 2 <= room) return 2;
+    return 0;
+}
+
 static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1) {
     const int B = c->B;
     // More problems than the optimiser gets CUs (one workgroup per CU, >= 96 CUs left to the passes): time-sliced in
     // sub-batches of whole 32-problem chunks, one after the other - every sub-batch is the same asynchronous fit (problems
     // are independent: the results do not depend on the slicing, tests/test_gpu_large_batch.py).
-    const int maxb = vps_enabled(c, SW) ? kVpsMaxAsync : kAsyncMaxB;
+    const bool want_resident = resident_tiles_per_wg(c, 0) != 0;
+    const int maxb = vps_enabled(c, SW) ? kVpsMaxAsync : (want_resident ? kResidentMaxB : kAsyncMaxB);
     const int nsub = (B + maxb - 1) / maxb;
     const int per = ((B + nsub - 1) / nsub + 31) / 32 * 32;
     int rc = ensure_async(c, per);
     if (rc) return rc;
-    const AsyncRing& R = c->ring;
+    AsyncRing R = c->ring;
     const size_t rb = (size_t)R.Bpad;                       // ring stride in problems (>= per)
     volatile int* h_done = c->h_async_done;
     // polled words: re-initialised every call
     HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
     static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
+    const int tpw = dbg_nopass ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per)));
+    const int res_grid = tpw ? (c->M.ntiles + tpw - 1) / tpw : 0;
+    if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
+    c->resident_tpw = tpw;
+    R.npass = tpw ? res_grid : 1;
+    c->res_rounds = 0; c->res_span_ms = c->res_busy_ms = 0.0;
+    const bool log_on = tpw && c->profile;
+    if (log_on) {
+        const size_t words = (size_t)kVpLogRounds * res_grid * 2;
+        if (c->vp_log_words < words) {
+            if (c->d_vp_log) hipFree(c->d_vp_log);
+            c->d_vp_log = nullptr; c->vp_log_words = 0;
+            HIP_OK(c, hipMalloc(&c->d_vp_log, words * 8));
+            c->vp_log_words = words;
+        }
+    }
     for (int b_lo = 0; b_lo < B; b_lo += per) {
         const int b_hi = std::min(B, b_lo + per);
         *h_done = 0;
@@ -1607,14 +1660,33 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         // that left the launch (finished or paused) - a sub-batch that stops at the round cap does not keep the later ones
         // from seeing theirs complete.  (The ctx stream is behind the previous sub-batch's last passes here.)
         HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * rb * 4, c->stream));
-        HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4, c->stream));
+        HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4 * kPassWords, c->stream));
         HIP_OK(c, hipMemsetAsync(c->F.n_done + 1, 0, 4, c->stream));
+        if (log_on) HIP_OK(c, hipMemsetAsync(c->d_vp_log, 0, c->vp_log_words * 8, c->stream));      // (a profiled fit keeps the last sub-batch's stamps)
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
         rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi - b_lo, pause_stage);
         if (rc) return rc;
-        // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
         int k = 0;
+        if (tpw) {
+            // ---- resident pass: ONE launch serves every closure round of this sub-batch from the ring; it ends when every
+            //      problem has left the optimiser kernel (finished, paused at a stage boundary, or the round cap) ----
+            ResidentArgs RA{};
+            RA.coefH = R.coefH; RA.Amat = R.Amat; RA.tau = R.tau; RA.tag = R.tag;
+            RA.done_round = R.done_round; RA.stats = R.stats; RA.wg_round = R.pass_done;
+            RA.log = log_on ? c->d_vp_log : nullptr; RA.log_rounds = kVpLogRounds;
+            RA.verts = c->d_verts;
+            RA.capture_verts = c->capture_verts; RA.capture_round = c->capture_verts ? c->capture_round : -1;
+            RA.nslots = kRingSlots; RA.rb = (int)rb;
+            RA.b_lo = b_lo; RA.n = b_hi - b_lo;
+            static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
+            RA.flags = dbg_nt;
+            RA.max_rounds = (unsigned)cap;
+            hipError_t e = launch_vertex_pass_resident(c->M, RA, tpw, c->pass_stream);
+            if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "resident vertex pass launch: %s", hipGetErrorString(e));
+            HIP_OK(c, hipEventRecord(c->ev_batch[0], c->pass_stream));
+        } else {
+        // the passes: one per closure round, queued at most two batches ahead of the ones that have completed
         for (;; ++k) {
             for (int i = 0; i < kPassBatch && !dbg_nopass; ++i) {
                 const unsigned r = (unsigned)(k * kPassBatch + i);
@@ -1649,6 +1721,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             if (*h_done >= b_hi - b_lo) break;
             if ((k + 1) * kPassBatch >= cap) break;
         }
+        }
         // behind the optimiser kernel (all problems of the sub-batch, or the round cap) the ctx stream continues behind the
         // last passes (nothing of the fit's result depends on them: ordering only)
         HIP_OK(c, hipStreamWaitEvent(c->stream, c->ev_batch[k & 3], 0));
@@ -1658,6 +1731,29 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     HIP_OK(c, hipMemcpyAsync(c->h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
     *seen_out = c->h_done[0];
+    if (log_on) {
+        // per round: service span = last workgroup's stores drained - first workgroup saw the operands; busy = a workgroup's own
+        // drained - seen (wall clock, 100 MHz)
+        std::vector<unsigned long long> lg((size_t)kVpLogRounds * res_grid * 2);
+        HIP_OK(c, hipMemcpy(lg.data(), c->d_vp_log, lg.size() * 8, hipMemcpyDeviceToHost));
+        double span = 0.0, busy = 0.0;
+        int n = 0;
+        for (int r = 0; r < kVpLogRounds; ++r) {
+            unsigned long long lo = ~0ull, hi = 0ull, bsum = 0ull;
+            bool all = true;
+            for (int w = 0; w < res_grid; ++w) {
+                const unsigned long long a = lg[((size_t)r * res_grid + w) * 2], z = lg[((size_t)r * res_grid + w) * 2 + 1];
+                if (!z) { all = false; break; }
+                lo = std::min(lo, a); hi = std::max(hi, z); bsum += z - a;
+            }
+            if (!all) break;
+            span += (double)(hi - lo) * 1e-5; busy += (double)bsum / res_grid * 1e-5;      // ticks of 10 ns -> ms
+            ++n;
+        }
+        c->res_rounds = n;
+        c->res_span_ms = n ? span / n : 0.0;
+        c->res_busy_ms = n ? busy / n : 0.0;
+    }
     return MVFIT_OK;
 }
 
@@ -1984,6 +2080,37 @@ static int profile_vertex_pass(mvfit_ctx* c, int launches, int flavour, double* 
         P.coefH = c->ring.coefH; P.coefT = nullptr; P.Amat = c->ring.Amat; P.tau = c->ring.tau;
         P.tag = c->ring.tag; P.done_round = c->ring.done_round; P.stats = c->ring.stats; P.round = 0;
     }
+    if (flavour == 2) {
+        // the RESIDENT pass alone: `launches` (<= ring slots) closure rounds whose operands are already in the ring (whatever
+        // trial points the last fit left in slots 0 .. launches - 1) and whose tags say so - ONE kernel launch inside one
+        // hipEvent pair serves them back to back; elapsed / launches = the service time of a round with no optimiser next door
+        if (!c->ring.tag || !c->resident_tpw) return fail(c, MVFIT_E_STATE, "no asynchronous fit with the resident pass has run on this batch yet");
+        const AsyncRing& R = c->ring;
+        const int n = std::min(c->B, R.Bpad), rounds = std::min(launches, R.nslots);
+        std::vector<unsigned> tg((size_t)R.nslots * R.Bpad, 0u), dn((size_t)c->Bpad, 0u);
+        for (int sl = 0; sl < rounds; ++sl) for (int q = 0; q < n; ++q) tg[(size_t)sl * R.Bpad + q] = (unsigned)sl + 1u;
+        for (int q = 0; q < n; ++q) dn[q] = (unsigned)rounds;
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        HIP_OK(c, hipMemcpy(R.tag, tg.data(), tg.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(c, hipMemcpy(R.done_round, dn.data(), dn.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(c, hipMemset(R.pass_done, 0, 4 * kPassWords));
+        ResidentArgs RA{};
+        RA.coefH = R.coefH; RA.Amat = R.Amat; RA.tau = R.tau; RA.tag = R.tag; RA.done_round = R.done_round; RA.stats = R.stats;
+        RA.wg_round = R.pass_done; RA.verts = c->d_verts; RA.capture_round = -1; RA.nslots = R.nslots; RA.rb = R.Bpad;
+        RA.b_lo = 0; RA.n = n; RA.max_rounds = (unsigned)rounds + 1u;
+        hipEvent_t a, b;
+        HIP_OK(c, hipEventCreate(&a)); HIP_OK(c, hipEventCreate(&b));
+        HIP_OK(c, hipEventRecord(a, c->stream));
+        hipError_t e = launch_vertex_pass_resident(c->M, RA, c->resident_tpw, c->stream);
+        HIP_OK(c, hipEventRecord(b, c->stream));
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        hipError_t e2 = hipEventElapsedTime(&ms, a, b);
+        hipEventDestroy(a); hipEventDestroy(b);
+        if (e != hipSuccess || e2 != hipSuccess) return fail(c, MVFIT_E_HIP, "resident vertex pass timing failed");
+        *avg_ms = (double)ms / rounds;
+        return MVFIT_OK;
+    }
     hipEvent_t a, b;
     HIP_OK(c, hipEventCreate(&a)); HIP_OK(c, hipEventCreate(&b));
     hipError_t e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->ksplit, c->stream);      // warm
@@ -2020,11 +2147,23 @@ static double drain(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, int* n)
     return cnt ? tot / cnt : 0.0;
 }
 
+extern "C" int mvfit_pass_profile(mvfit_ctx* c, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms) {
+    if (!c) return MVFIT_E_ARG;
+    if (tiles_per_wg) *tiles_per_wg = c->resident_tpw;
+    if (workgroups) *workgroups = c->resident_tpw ? (c->M.ntiles + c->resident_tpw - 1) / c->resident_tpw : 0;
+    if (rounds) *rounds = c->res_rounds;
+    if (span_ms) *span_ms = c->res_span_ms;
+    if (busy_ms) *busy_ms = c->res_busy_ms;
+    return MVFIT_OK;
+}
+
 extern "C" int mvfit_profile_read(mvfit_ctx* c, double* vp_ms, int* launches, double* step_ms, int* step_launches) {
     if (!c) return MVFIT_E_ARG;
     HIP_OK(c, hipStreamSynchronize(c->stream));
     int n1 = 0, n2 = 0;
     double a = drain(c->ev_vp, &n1), b = drain(c->ev_step, &n2);
+    // resident pass (one launch per fit): the per-round service span stamped inside the kernel stands for the launch duration
+    if (n1 == 0 && c->res_rounds > 0) { a = c->res_span_ms; n1 = c->res_rounds; }
     if (vp_ms) *vp_ms = a;
     if (launches) *launches = n1;
     if (step_ms) *step_ms = b;

@@ -186,7 +186,32 @@ struct AsyncRing {
     // back-pressure: rounds whose vertex pass has completed.  A problem publishes round r into slot r % nslots only once
     // the pass of round r - nslots has run (pass_done > r - nslots): a slot is never overwritten before its pass read it,
     // however slow the passes are (the optimiser is throttled to their rate instead).
+    // npass words, the minimum counts: ONE written by the gate kernels of the per-round launches, or one per workgroup of
+    // the resident pass (rounds whose operands that workgroup has read) - no atomics, every writer owns its word.
     unsigned* pass_done;
+    int npass, rpad_;
+};
+
+// Resident vertex pass of the asynchronous fit (lbs_vertex_pass_resident_kernel, vertex_pass.hip): ONE launch per
+// (sub-batch) fit; every workgroup keeps the basis of its vertex tile(s) in registers and serves closure round after
+// closure round from the ring.
+struct ResidentArgs {
+    const float4* coefH;         // ring bases: slot 0, problem 0 of the sub-batch
+    const float* Amat;
+    const float* tau;
+    const unsigned* tag;
+    const unsigned* done_round;  // [Bpad] by global problem index
+    unsigned* stats;             // [4] chunk passes run / skipped / missed / timed out
+    unsigned* wg_round;          // [grid] back-pressure words (AsyncRing::pass_done)
+    unsigned long long* log;     // mvfit_profile: [log_rounds][grid][2] wall-clock stamps {operands seen, stores drained}, or null
+    float* verts;                // [B][nv][3] by global problem index
+    float* capture_verts;        // test hook: the round capture_round is written here instead
+    int capture_round;
+    int nslots, rb;              // ring geometry: slots, problems per slot
+    int b_lo, n;                 // the sub-batch: global index of its first problem, number of problems
+    int log_rounds;
+    unsigned flags;              // bit 1: plain (not non-temporal) vertex stores
+    unsigned max_rounds;
 };
 
 // SDF interpenetration term (fitting.py:352-393), per problem

@@ -174,7 +174,7 @@ __device__ __forceinline__ void vp_put_partial(float* part, int slice, int kc, c
 
 // all waves: combine the K slices of the contraction in a fixed order (deterministic), undo the basis scale (SCALED:
 // a power of two, exact) and apply T: out = skinned position before "+ transl", vps = v_posed (side outputs only)
-template <int NSLICE, bool SCALED>
+template <int NSLICE, bool SCALED, bool SIDE = true>
 __device__ __forceinline__ void vp_apply(const float* part, const float (&tr)[3][2][4], float* out_l, float* vps_l,
                                          int bb, int vp2, float inv_scale) {
 #pragma unroll
@@ -191,7 +191,7 @@ __device__ __forceinline__ void vp_apply(const float* part, const float (&tr)[3]
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             out_l[bb * 96 + v * 3 + k] = fmaf(tr[k][i][0], vp[0], fmaf(tr[k][i][1], vp[1], fmaf(tr[k][i][2], vp[2], tr[k][i][3])));
-            vps_l[bb * 96 + v * 3 + k] = vp[k];
+            if (SIDE) vps_l[bb * 96 + v * 3 + k] = vp[k];
         }
     }
 }
@@ -993,6 +993,226 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Resident pass of the asynchronous fit: ONE launch per (sub-batch) fit instead of a gate + a pass launch per closure round.
+//
+// The per-round launches above re-stream the 18.2 MB basis every round (379 times per 32-frame fit) and pay launch, ramp
+// and teardown around ~3 us of work.  Here a workgroup owns TPW vertex tiles for the whole fit: the tiles' split-fp16
+// basis is loaded ONCE into the registers of the six contraction waves (56 VGPRs per tile and wave: plane x K half, the
+// mapping of lbs_vertex_pass_split_kernel), and the workgroup then serves closure round after closure round:
+//   * wave 7 polls the round's ring tags (relaxed agent-scope = sc1 loads, s_sleep between polls: one idle wave per
+//     workgroup, the form the guide's polling-cost row asks for) while the other waves sleep at the barrier; the verdict
+//     (go / all problems finished / timed out) and the mask of live 32-problem chunks go through LDS;
+//   * the operands of a chunk (split-fp16 coefficient words straight into the contraction waves' registers, the skinning
+//     transforms of a wave's own 4 problems into its private LDS rows, translations) are read with sc1 loads: the
+//     optimiser wrote them with sc1 (write-through) stores and drained them before the tag, so sc1 on both sides is the
+//     whole hand-off - no acquire fence, nothing invalidated under the optimiser workgroups of the same XCD;
+//   * blend, contraction, combine, apply, store: the code of the single-chunk kernel, unit by unit (chunk x tile) - the
+//     vertices are bit-identical to the per-round kernels' (tests/test_gpu_async.py, test_gpu_large_batch.py);
+//   * back-pressure: the workgroup publishes the number of rounds whose operands it has read in its OWN word
+//     (ResidentArgs::wg_round); the optimiser takes the minimum over the words when its cached copy does not cover
+//     `round - nslots` (a few times per fit) - no atomics, no contention.
+// Per closure round the pass now moves 84,712 bytes per problem + 2.1 KB of operands per problem and workgroup; the basis
+// crosses the memory system once per fit.  Grid = ceil(ntiles / TPW) workgroups that must all be resident next to the
+// optimiser's (one CU each): the host picks TPW from the CU count (mvfit_api.hip: fit_async).
+// mvfit_profile: every workgroup logs {operands seen, stores drained} per round (wall clock, 100 MHz) - the round's
+// service span is max(drained) - min(seen) over the workgroups.
+// ---------------------------------------------------------------------------------------------------------
+template <int TPW>
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_kernel(DevModel M, ResidentArgs RA) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A_l = smem;                              // [32][A_STRIDE]   rows 4 w .. 4 w + 3 are private to wave w
+    float* tau_l = A_l + 32 * A_STRIDE;             // [2 parities][32][4]
+    float* part = tau_l + 2 * 32 * 4;               // [TPW][2 K-halves][3][32][33]
+    float* out_l = part + TPW * 2 * 3 * 32 * 33;    // [TPW][32 b][96]  skinned positions before "+ transl"
+    float4* sw_l = reinterpret_cast<float4*>(out_l + TPW * 32 * 96);   // [TPW][32] 4-pair skinning table of the tiles' vertices
+    int4* sj_l = reinterpret_cast<int4*>(sw_l + TPW * 32);          // [TPW][32]
+    unsigned* ctl = reinterpret_cast<unsigned*>(sj_l + TPW * 32);   // [8] verdict, live-chunk mask, stamp (2 words)
+    float4* coef_l = reinterpret_cast<float4*>(ctl + 8);            // [VP_NBLK][hi, lo][64 lanes] A operands of the chunk
+
+    const int tid_k = threadIdx.x, tid = tid_k, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w blends problems [4 w, 4 w + 4)
+    const int wg = blockIdx.x;
+    const bool mfma_role = wave < 6;
+    const int kc_w = wave % 3, kh_w = wave / 3;
+    const bool store_nt = VP_NT_LOADS && !(RA.flags & 2u);
+    const float inv_scale = 1.0f / M.bs_scale;            // power of two: exact
+    const unsigned nch = (unsigned)(RA.n + 31) >> 5;
+
+    // ---- once per fit: the tiles' basis (B operands of the contraction), v_template, skinning tables ----
+    float vt_init[TPW];
+    float4 bh[TPW][VP_BPW], bl[TPW][VP_BPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = min(wg * TPW + t, M.ntiles - 1);                 // (a tile past the end is never stored)
+        vt_init[t] = 0.f;
+        if (mfma_role) {
+            if (kh_w == 0) vt_init[t] = M.vt_planes[kc_w * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale;
+            const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + kc_w) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < VP_BPW; ++g) {
+                bh[t][g] = nt_load16(&cb[(2 * g) * 64]);
+                if (!M.half_basis) bl[t][g] = nt_load16(&cb[(2 * g + 1) * 64]);
+                else bl[t][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (tid < 32) sw_l[t * 32 + tid] = M.wsp_w[(size_t)tile * TILE_V + tid];
+        else if (tid < 64) sj_l[t * 32 + tid - 32] = M.wsp_j[(size_t)tile * TILE_V + tid - 32];
+    }
+    __syncthreads();
+
+    unsigned unit = 0;                                    // parity of the translation buffer
+    for (unsigned r = 0; r < RA.max_rounds; ++r) {
+        const unsigned slot = r % (unsigned)RA.nslots;
+        // ---- wave 7: wait for the operands of closure round r (every problem: published, or finished before r) ----
+        if (wave == 7) {
+            const unsigned want = r + 1u;
+            const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
+            const unsigned* dn = RA.done_round + RA.b_lo;
+            unsigned verdict = 1u, live_bits = 0u, missed = 0u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                bool ok = true;
+                live_bits = 0u; missed = 0u;
+                for (int p = lane; p < RA.n; p += 64) {
+                    const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool live = d > r;                   // the problem evaluates (or evaluated) closure round r
+                    ok = ok && (t >= want || !live);           // (a larger tag: a later round already overwrote the slot)
+                    if (live) live_bits |= 1u << (p >> 5);
+                    if (live && t > want) ++missed;
+                }
+                if (__all(ok)) break;
+                if (wall_clock64() - t0 > 2000000) { verdict = 3u; break; }            // 20 ms at 100 MHz
+                __builtin_amdgcn_s_sleep(32);
+            }
+            unsigned mask = 0u;
+            for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
+            if (verdict == 1u && mask == 0u) verdict = 2u;     // every problem finished before this round: the fit is over
+            const unsigned long long miss_b = __ballot(missed != 0u);
+            if (lane == 0) {
+                ctl[0] = verdict; ctl[1] = mask;
+                const long long ts = wall_clock64();
+                ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
+                if (wg == 0 && verdict == 1u) {
+                    atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
+                    if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
+                }
+                if (wg == 0 && verdict == 3u) atomicAdd(RA.stats + 3, 1u);
+            }
+            if (wg == 0 && miss_b) {                           // operands overwritten before this pass read them
+                unsigned msum = missed;
+                for (int o = 32; o; o >>= 1) msum += __shfl_xor(msum, o);
+                if (lane == 0) atomicAdd(RA.stats + 2, msum);
+            }
+        }
+        __syncthreads();
+        const unsigned verdict = ctl[0], mask = ctl[1];
+        if (verdict != 1u) break;                              // uniform
+        float* vout = (RA.capture_verts && (int)r == RA.capture_round) ? RA.capture_verts : RA.verts;
+
+        for (unsigned c = 0; c < nch; ++c) {
+            if (!((mask >> c) & 1u)) continue;                 // uniform: the chunk's 32 problems all finished earlier
+            float* tau_c = tau_l + (unit & 1u) * 32 * 4;
+            ++unit;
+            // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address of the unit out of
+            // the round loop (the basis already holds 56 registers per tile; hoisted addresses spill)
+            int tid = tid_k;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, vp2 = tid & 15, bb = tid >> 4;
+            // ---- the chunk's operands: direct global -> LDS loads with sc1 (no registers are held while they fly: the basis
+            //      and the blend need them).  Coefficient words: 28 x 1 KiB shared by the contraction waves, requested by
+            //      all eight; transforms: a wave's own 4 problems (4.5 KiB, contiguous in the ring and in LDS); translations ----
+            {
+                const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
+                for (int i = wave; i < VP_NBLK * 2; i += VP_NT / 64)
+                    __builtin_amdgcn_global_load_lds(csrc + i * 64, coef_l + i * 64, 16, 0, /*aux = sc1*/ 16);
+                static_assert(A_STRIDE == 288, "a wave's 4 problems are one linear copy");
+                const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u + 4u * (unsigned)wave) * 72 + lane;
+                float4* adst = reinterpret_cast<float4*>(A_l + 4 * wave * A_STRIDE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(asrc + i * 64, adst + i * 64, 16, 0, 16);
+                if (lane < 32) __builtin_amdgcn_global_load_lds(asrc + 256, adst + 256, 16, 0, 16);
+                if (wave == 7 && lane < 32)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane,
+                                                     reinterpret_cast<float4*>(tau_c), 16, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // the coefficient words are staged by all waves
+            const int b0 = RA.b_lo + (int)c * 32, b_end = RA.b_lo + RA.n;
+            if (mfma_role) {
+                // ---- blendshape contraction: plane kc_w, K-half kh_w of every tile of this workgroup; small products first.
+                //      The chunk's A operands are read once per block and feed the tiles' independent accumulators ----
+                floatx16 acc[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[t][q] = vt_init[t];
+                const float4* cl = coef_l + (kh_w * VP_BPW * 2) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < VP_BPW; ++g) {
+                    const half8 Ah = __builtin_bit_cast(half8, cl[(2 * g) * 64]), Al = __builtin_bit_cast(half8, cl[(2 * g + 1) * 64]);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const half8 Bh = __builtin_bit_cast(half8, bh[t][g]), Bl = __builtin_bit_cast(half8, bl[t][g]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
+                        if (!M.half_basis) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
+                    }
+                    if (TPW > 1) __builtin_amdgcn_sched_barrier(0);      // one block's operands in flight at a time (registers)
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) vp_put_partial(part + t * (2 * 3 * 32 * 33), kh_w, kc_w, acc[t], lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wg * TPW + t;
+                if (tile >= M.ntiles) break;                   // uniform
+                // ---- skinning blend (lbs.py:209-213), all waves ----
+                float tr[3][2][4];
+                vp_blend_zero(tr);
+                vp_blend_pairs(tr, 0, A_l + bb * A_STRIDE, sw_l[t * 32 + 2 * vp2], sj_l[t * 32 + 2 * vp2]);
+                __builtin_amdgcn_sched_barrier(0);             // 12 transform rows in flight at a time, not 24 (registers)
+                vp_blend_pairs(tr, 1, A_l + bb * A_STRIDE, sw_l[t * 32 + 2 * vp2 + 1], sj_l[t * 32 + 2 * vp2 + 1]);
+                if (t == 0) __syncthreads();                   // the partials of all tiles are published
+                // ---- combine the two K-halves (fixed order), undo the basis scale, apply T ----
+                float* out_t = out_l + t * (32 * 96);
+                vp_apply<2, true, false>(part + t * (2 * 3 * 32 * 33), tr, out_t, nullptr, bb, vp2, inv_scale);
+                __syncthreads();
+                // ---- store x + transl ----
+                vp_store_rows(vout, out_t, tau_c, M.nv, tile * TILE_V, min(TILE_V, M.nv - tile * TILE_V) * 3, b0, b_end, tid, store_nt);
+            }
+        }
+        // every wave has read its operands of this round (they were waited for before the blends, barriers since): the
+        // ring slot may be overwritten as far as this workgroup is concerned
+        if (tid == 0) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RA.log && r < (unsigned)RA.log_rounds) {           // uniform (mvfit_profile only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's vertex stores have been acknowledged
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long* lg = RA.log + ((size_t)r * gridDim.x + wg) * 2;
+                lg[0] = (unsigned long long)ctl[2] | ((unsigned long long)ctl[3] << 32);
+                lg[1] = (unsigned long long)wall_clock64();
+            }
+        }
+    }
+    // whatever ended the loop: nothing waits for this workgroup any more
+    if (tid == 0) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+size_t vertex_pass_resident_lds_bytes(int tpw) {
+    return sizeof(float) * (size_t)(32 * A_STRIDE + 2 * 32 * 4 + tpw * (2 * 3 * 32 * 33 + 32 * 96)) + 32 * (size_t)tpw * 32 + 32 + 16 * (size_t)(VP_NBLK * 2 * 64);
+}
+
+// tpw = tiles per workgroup (1 or 2); grid = ceil(ntiles / tpw) workgroups, all of which must be resident
+hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream) {
+    const dim3 grid((M.ntiles + tpw - 1) / tpw);
+    if (tpw == 1) hipLaunchKernelGGL(lbs_vertex_pass_resident_kernel<1>, grid, dim3(VP_NT), vertex_pass_resident_lds_bytes(1), stream, M, RA);
+    else hipLaunchKernelGGL(lbs_vertex_pass_resident_kernel<2>, grid, dim3(VP_NT), vertex_pass_resident_lds_bytes(2), stream, M, RA);
+    return hipGetLastError();
+}
+
 size_t vertex_pass_pipe_lds_bytes() {
     return sizeof(float) * (size_t)(2 * 32 * A_STRIDE + 3 * 32 * 33 + 2 * 32 * 4) + 16 * (size_t)(2 * VP_NBLK * 2 * 64 + 32 + 32) + 4 * (32 + 4 + 64);
 }
@@ -1065,6 +1285,12 @@ hipError_t vertex_pass_configure() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_resident_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_resident_lds_bytes(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_resident_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_resident_lds_bytes(2));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_pipe_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_pipe_lds_bytes());

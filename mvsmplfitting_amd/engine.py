@@ -224,6 +224,12 @@ class MvFit:
         self._check(self._lib.mvfit_fit_stats(self._ctx, st4))
         stats = dict(final_loss=final, n_closure=ncl, n_iter=nit,
                      passes=dict(run=int(st4[0]), skipped=int(st4[1]), missed=int(st4[2]), timed_out=int(st4[3])))
+        if stats['passes']['missed'] or stats['passes']['timed_out']:
+            # never silent: "every closure round got its full vertex pass" does not hold for this fit (the fitted parameters
+            # do not depend on the passes - they consume what the optimiser publishes - but the per-round vertices do)
+            warnings.warn('vertex passes degraded in this fit: %d lost their operands before reading them, %d gave up waiting '
+                          'for them (is the GPU shared, or were the pass workgroups not all resident?)'
+                          % (stats['passes']['missed'], stats['passes']['timed_out']), RuntimeWarning)
         if any(int(dict(s).get('flags', 0)) & _lib.F_VPOSER for s in stages):
             # decoder helpers (vposer_service.h): an answer that timed out makes that problem decode in its own workgroup
             # from then on - another summation order, i.e. last-bit differences from run to run.  Never silent.
@@ -388,6 +394,21 @@ class MvFit:
         a = C.c_double()
         self._check(self._lib.mvfit_profile_vertex_pass_ex(self._ctx, int(launches), 1 if as_in_async_fit else 0, C.byref(a)))
         return a.value
+
+    def profile_resident_pass_ms(self, rounds=100):
+        """Per-round time (ms) of the RESIDENT vertex pass alone: one launch serving ``rounds`` (<= 128) closure rounds whose
+        operands the last asynchronous fit left in the ring, inside one hipEvent pair (include/mvfit.h, flavour 2)."""
+        a = C.c_double()
+        self._check(self._lib.mvfit_profile_vertex_pass_ex(self._ctx, int(rounds), 2, C.byref(a)))
+        return a.value
+
+    def pass_profile(self):
+        """How the vertex passes of the last asynchronous fit ran (include/mvfit.h:mvfit_pass_profile)."""
+        tpw, wgs, n = C.c_int(), C.c_int(), C.c_int()
+        span, busy = C.c_double(), C.c_double()
+        self._check(self._lib.mvfit_pass_profile(self._ctx, C.byref(tpw), C.byref(wgs), C.byref(n), C.byref(span), C.byref(busy)))
+        return dict(tiles_per_workgroup=tpw.value, workgroups=wgs.value, rounds_stamped=n.value,
+                    round_span_ms=span.value, workgroup_busy_ms=busy.value)
 
     def profile_read(self):
         a, b = C.c_double(), C.c_double()

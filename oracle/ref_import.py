@@ -17,7 +17,39 @@ import types
 
 import numpy as np
 
-REF_ROOT = os.environ.get('MVFIT_REFERENCE', '/root/reference')
+_STAGE = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'reference_stage.tgz')
+
+
+def _resolve_root() -> str:
+    """The reference tree: $MVFIT_REFERENCE, else /root/reference (the build container), else the archive `make -C oracle
+    stage` made of the reference's own Python path (oracle/_ref/reference_stage.tgz: git-ignored, travels to the GPU box
+    with the snapshot like libsdf_ref.so), unpacked once per archive version into a temporary directory."""
+    env = os.environ.get('MVFIT_REFERENCE')
+    if env:
+        return env
+    if os.path.isfile('/root/reference/code/utils/fitting.py') or not os.path.isfile(_STAGE):
+        return '/root/reference'
+    import hashlib
+    import tarfile
+    import tempfile
+    st = os.stat(_STAGE)
+    key = hashlib.sha1(('%s:%d:%d' % (_STAGE, st.st_size, int(st.st_mtime))).encode()).hexdigest()[:12]
+    root = os.path.join(tempfile.gettempdir(), 'mvfit_reference_stage_' + key)
+    if not os.path.isfile(os.path.join(root, '.complete')):
+        tmp = tempfile.mkdtemp(prefix='mvfit_reference_stage_')
+        with tarfile.open(_STAGE) as tf:
+            tf.extractall(tmp)
+        open(os.path.join(tmp, '.complete'), 'w').close()
+        try:
+            os.rename(tmp, root)
+        except OSError:                              # another process was faster: use its copy
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    return root
+
+
+REF_ROOT = _resolve_root()
+STAGED = REF_ROOT != '/root/reference' and not os.environ.get('MVFIT_REFERENCE')
 _mods = None
 
 
@@ -225,3 +257,65 @@ class RefProblem:
             out = self.smpl(return_verts=True, body_pose=bp, return_full_pose=True)
         return (float(loss), grad, out.vertices[0].detach().numpy(),
                 out.joints[0].detach().numpy())
+
+
+def time_reference_fits(model, cams, gt, conf, stages, use_vposer=False, vposer_weights=None, threads=1, budget_s=10.0,
+                        dtype='float32', max_frames=None):
+    """bench.py's cpu_baseline leg: the reference ITSELF - its SMPL / cameras / create_loss / create_optimizer('lbfgsls') /
+    FittingMonitor.create_fitting_closure / run_fitting (code/utils/fitting.py:71-205, code/optimizers/lbfgs_ls.py:256-445)
+    in the stage loop of non_linear_solver.py:156-211 - timed on this box's host cores: whole staged fits of the batch's
+    frames, one after the other as main.py runs them, from the rest pose, until `budget_s` is used up.
+    Returns dict(closures, frames, seconds, final_losses)."""
+    import contextlib as _cl
+    import io
+    import time
+    import torch
+    torch.set_num_threads(int(threads))
+    lay_d = 49 if use_vposer else 86
+    ncl = nfr = 0
+    finals = []
+    t0 = time.time()
+    for b in range(gt.shape[0] if max_frames is None else min(max_frames, gt.shape[0])):
+        rp = RefProblem(model, cams, gt[b], conf[b], dtype, use_vposer=use_vposer, vposer_weights=vposer_weights)
+        x0 = rp.get_flat() * 0.0
+        assert x0.shape[0] == lay_d, x0.shape
+        # scale = 1 (the only non-zero start value; order: betas, global_orient, [body_pose], transl, scale, [embedding])
+        x0[(10 + 3 + (0 if use_vposer else 69) + 3)] = 1.0
+        rp.set_flat(x0)
+        final = None
+        for wts in stages:
+            rp.set_weights({k: v for k, v in wts.items() if k in ('data_weight', 'body_pose_weight', 'shape_weight',
+                                                               'bending_prior_weight', 'coll_loss_weight')})
+            opt = rp.make_optimizer()
+            inner = rp.make_closure(opt)
+
+            def closure(backward=True, inner=inner):
+                nonlocal ncl
+                ncl += 1
+                return inner(backward)
+            with _cl.redirect_stdout(io.StringIO()):
+                final = rp.monitor.run_fitting(opt, closure, rp.final_params(), rp.smpl, use_vposer=rp.use_vposer,
+                                               pose_embedding=rp.pose_embedding, vposer=rp.vposer)
+        finals.append(final)
+        nfr += 1
+        if time.time() - t0 > budget_s:
+            break
+    return dict(closures=ncl, frames=nfr, seconds=time.time() - t0, final_losses=finals)
+
+
+def time_reference_closure(model, cams, gt, conf, weights, use_vposer=False, vposer_weights=None, threads=1, calls=200, warm=5,
+                           dtype='float32'):
+    """Raw fitting_func(backward=True) rate of the reference (fitting.py:162-203) at the rest pose: mean over `calls`."""
+    import time
+    import torch
+    torch.set_num_threads(int(threads))
+    rp = RefProblem(model, cams, gt, conf, dtype, use_vposer=use_vposer, vposer_weights=vposer_weights)
+    rp.set_weights({k: v for k, v in weights.items() if k in ('data_weight', 'body_pose_weight', 'shape_weight',
+                                                             'bending_prior_weight', 'coll_loss_weight')})
+    closure = rp.make_closure(rp.make_optimizer())
+    for _ in range(warm):
+        closure(backward=True)
+    t0 = time.time()
+    for _ in range(calls):
+        closure(backward=True)
+    return calls / (time.time() - t0)

@@ -90,3 +90,58 @@ def test_chained_round_mode_still_available(monkeypatch):
     assert st['passes'] == dict(run=0, skipped=0, missed=0, timed_out=0)
     assert np.all(np.isfinite(st['final_loss'].cpu().numpy()))
     eng.close()
+
+
+def _capture(eng, x0, stages, round_index, monkeypatch, resident):
+    if resident is None:
+        monkeypatch.delenv('MVFIT_VP_RESIDENT', raising=False)
+    else:
+        monkeypatch.setenv('MVFIT_VP_RESIDENT', str(resident))
+    cap = eng.capture_pass(round_index)
+    xf, st = eng.fit(x0, stages)
+    eng.capture_pass(None)
+    assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0, st['passes']
+    return cap.cpu().numpy(), xf.cpu().numpy(), st['n_closure'].cpu().numpy(), eng.pass_profile()
+
+
+@pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 2, 9), (33, None, 1, 140),
+                                                        (70, None, 2, 9), (70, None, 2, 140), (128, None, 2, 31)])
+def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index, monkeypatch):
+    """The resident pass (one launch per fit, the tiles' basis stationary in registers, rounds served from the ring) writes
+    the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup, one chunk / ragged chunks /
+    four chunks, before and after the ring wrapped; and it does not perturb the optimiser either."""
+    eng, x0 = _setup(B=B)
+    stages = eng_stage_weights(1536.0, flags=0)
+    cap_l, x_l, ncl_l, prof_l = _capture(eng, x0, stages, round_index, monkeypatch, 0)
+    cap_r, x_r, ncl_r, prof_r = _capture(eng, x0, stages, round_index, monkeypatch, resident)
+    assert prof_l['tiles_per_workgroup'] == 0 and prof_r['tiles_per_workgroup'] == tpw, (prof_l, prof_r)
+    assert np.array_equal(x_l, x_r) and np.array_equal(ncl_l, ncl_r)
+    have = round_index < ncl_r
+    assert have.any()
+    assert np.isfinite(cap_r[have]).all()
+    assert np.array_equal(cap_l[have], cap_r[have]), np.abs(cap_l[have] - cap_r[have]).max()
+    eng.close()
+
+
+def test_resident_pass_profile_and_alone_timing():
+    """mvfit_profile with the resident pass: every round of the fit is stamped inside the kernel (service span, workgroup
+    busy time), and the pass can be timed alone over the ring the fit left behind."""
+    eng, x0 = _setup(B=32)
+    stages = eng_stage_weights(1536.0, flags=0)
+    eng.profile(True)
+    xf, st = eng.fit(x0, stages)
+    pr = eng.profile_read()
+    pp = eng.pass_profile()
+    eng.profile(False)
+    ncl = int(st['n_closure'].max().item())
+    assert pp['tiles_per_workgroup'] == 1 and pp['workgroups'] == 216
+    assert pp['rounds_stamped'] == min(ncl, 1024) == pr['vertex_pass_launches'], (pp, ncl, pr)
+    assert 0.0 < pp['workgroup_busy_ms'] <= pp['round_span_ms'] < 0.05, pp
+    assert pr['vertex_pass_ms'] == pp['round_span_ms']
+    alone = eng.profile_resident_pass_ms(100)
+    assert 0.0 < alone < 0.05, alone
+    # the ring is usable again afterwards: same fit, same result
+    xf2, st2 = eng.fit(x0, stages)
+    assert np.array_equal(xf.cpu().numpy(), xf2.cpu().numpy())
+    assert st2['passes']['missed'] == 0 and st2['passes']['timed_out'] == 0
+    eng.close()

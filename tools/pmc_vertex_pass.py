@@ -41,6 +41,33 @@ def drive(B, launches=40):
     eng.close()
 
 
+def drive_resident(B, side_file, reps=3, rounds=100):
+    """The RESIDENT pass as the counters' workload: one asynchronous fit of B problems (its resident launch serves every
+    closure round of the fit) + `reps` stand-alone resident launches over `rounds` rounds of the ring the fit left behind.
+    Every dispatch of lbs_vertex_pass_resident_kernel is summed by parse(); the number of closure rounds they served goes
+    to `side_file` so that the traffic can be stated per round."""
+    import numpy as np
+    import torch
+    from mvsmplfitting_amd import synthetic as syn
+    from mvsmplfitting_amd.engine import MvFit, stage_weights
+    import bench
+    eng = MvFit(syn.make_body_model(0, skin_topk=4))
+    cams, gt, conf, x0 = bench.build_inputs(eng, syn, 0, B, 1, 8)
+    xf, st = eng.fit(x0, stage_weights(1536.0))
+    pp = eng.pass_profile()
+    served = int(st['n_closure'].max().item()) if pp['tiles_per_workgroup'] else 0
+    dispatches = 1 if pp['tiles_per_workgroup'] else 0
+    if pp['tiles_per_workgroup']:
+        for _ in range(reps):
+            eng.profile_resident_pass_ms(rounds)
+            served += rounds
+            dispatches += 1
+    torch.cuda.synchronize()
+    with open(side_file, 'w') as f:
+        json.dump(dict(rounds_served=served, dispatches=dispatches, tiles_per_workgroup=pp['tiles_per_workgroup'], problems=B), f)
+    eng.close()
+
+
 def parse(out_json, specs):
     res = {}
     for spec in specs:
@@ -79,5 +106,7 @@ def parse(out_json, specs):
 if __name__ == '__main__':
     if sys.argv[1] == 'drive':
         drive(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 40)
+    elif sys.argv[1] == 'drive_resident':
+        drive_resident(int(sys.argv[2]), sys.argv[3])
     else:
         parse(sys.argv[2], sys.argv[3:])
