@@ -318,10 +318,14 @@ int mvfit_profile_vertex_pass_ex(mvfit_ctx* ctx, int launches, int flavour, doub
  *   *rounds        rounds stamped;
  *   *span_ms       mean over the rounds of (last workgroup's vertex stores acknowledged - first workgroup saw the round's
  *                  operands): the in-fit service time of a round - what mvfit_profile_read reports as the launch duration;
- *   *busy_ms       mean over rounds and workgroups of a workgroup's own (stores acknowledged - operands seen).
+ *   *busy_ms       mean over rounds and workgroups of a workgroup's own (stores acknowledged - operands seen);
+ *   *slowest_ms    mean over the rounds of the SLOWEST workgroup's (stores acknowledged - operands seen): the rate at which the
+ *                  pass can serve rounds (when the passes are slower than the optimiser the workgroups drift apart by up to the
+ *                  ring's depth and the span of a round says nothing about that rate).
  * Any pointer may be NULL.  flavour 2 of mvfit_profile_vertex_pass_ex runs the resident pass ALONE over `launches` (<= 128)
  * rounds whose operands the last fit left in the ring: one kernel launch inside one hipEvent pair, avg_ms = elapsed / rounds. */
-int mvfit_pass_profile(mvfit_ctx* ctx, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms);
+int mvfit_pass_profile(mvfit_ctx* ctx, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms,
+                       double* slowest_ms);
 
 /* Known-answer test entry for the device L-BFGS state machine (same template as production,
  * instantiated in float64) on the analytic objectives of oracle/lbfgs_np.py:kat_objective.

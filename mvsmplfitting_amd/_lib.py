@@ -121,7 +121,7 @@ def load():
     lib.mvfit_profile_vertex_pass_ex.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.mvfit_profile_vertex_pass_ex.restype = C.c_int
     lib.mvfit_pass_profile.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mvfit_pass_profile.restype = C.c_int
     lib.mvfit_lbfgs_kat.argtypes = [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.POINTER(LbfgsOpts),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,

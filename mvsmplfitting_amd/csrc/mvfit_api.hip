@@ -619,7 +619,7 @@ struct mvfit_ctx {
     int resident_tpw = 0;              // tiles per workgroup of the resident pass in the last asynchronous fit (0: per-round launches)
     unsigned long long* d_vp_log = nullptr;     // mvfit_profile: per-round stamps of the resident pass [kVpLogRounds][grid][2]
     size_t vp_log_words = 0;
-    double res_span_ms = 0.0, res_busy_ms = 0.0;    // mean per-round service span / mean per-workgroup busy time (last profiled fit)
+    double res_span_ms = 0.0, res_busy_ms = 0.0, res_slowest_ms = 0.0;   // per round: service span / mean workgroup busy time / slowest workgroup (last profiled fit)
     int res_rounds = 0;
     // decoder helpers of the single-launch fit (vposer_service.h): granule memory [requests | answers | 2 counters]
     unsigned long long* vps_mem = nullptr;
@@ -1642,7 +1642,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
     c->resident_tpw = tpw;
     R.npass = tpw ? res_grid : 1;
-    c->res_rounds = 0; c->res_span_ms = c->res_busy_ms = 0.0;
+    c->res_rounds = 0; c->res_span_ms = c->res_busy_ms = c->res_slowest_ms = 0.0;
     const bool log_on = tpw && c->profile;
     if (log_on) {
         const size_t words = (size_t)kVpLogRounds * res_grid * 2;
@@ -1736,23 +1736,25 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         // drained - seen (wall clock, 100 MHz)
         std::vector<unsigned long long> lg((size_t)kVpLogRounds * res_grid * 2);
         HIP_OK(c, hipMemcpy(lg.data(), c->d_vp_log, lg.size() * 8, hipMemcpyDeviceToHost));
-        double span = 0.0, busy = 0.0;
+        double span = 0.0, busy = 0.0, slowest = 0.0;
         int n = 0;
         for (int r = 0; r < kVpLogRounds; ++r) {
-            unsigned long long lo = ~0ull, hi = 0ull, bsum = 0ull;
+            unsigned long long lo = ~0ull, hi = 0ull, bsum = 0ull, bmax = 0ull;
             bool all = true;
             for (int w = 0; w < res_grid; ++w) {
                 const unsigned long long a = lg[((size_t)r * res_grid + w) * 2], z = lg[((size_t)r * res_grid + w) * 2 + 1];
                 if (!z) { all = false; break; }
-                lo = std::min(lo, a); hi = std::max(hi, z); bsum += z - a;
+                lo = std::min(lo, a); hi = std::max(hi, z); bsum += z - a; bmax = std::max(bmax, z - a);
             }
             if (!all) break;
             span += (double)(hi - lo) * 1e-5; busy += (double)bsum / res_grid * 1e-5;      // ticks of 10 ns -> ms
+            slowest += (double)bmax * 1e-5;
             ++n;
         }
         c->res_rounds = n;
         c->res_span_ms = n ? span / n : 0.0;
         c->res_busy_ms = n ? busy / n : 0.0;
+        c->res_slowest_ms = n ? slowest / n : 0.0;
     }
     return MVFIT_OK;
 }
@@ -2147,13 +2149,15 @@ static double drain(std::vector<std::pair<hipEvent_t, hipEvent_t>>& evs, int* n)
     return cnt ? tot / cnt : 0.0;
 }
 
-extern "C" int mvfit_pass_profile(mvfit_ctx* c, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms) {
+extern "C" int mvfit_pass_profile(mvfit_ctx* c, int* tiles_per_wg, int* workgroups, int* rounds, double* span_ms, double* busy_ms,
+                                  double* slowest_ms) {
     if (!c) return MVFIT_E_ARG;
     if (tiles_per_wg) *tiles_per_wg = c->resident_tpw;
     if (workgroups) *workgroups = c->resident_tpw ? (c->M.ntiles + c->resident_tpw - 1) / c->resident_tpw : 0;
     if (rounds) *rounds = c->res_rounds;
     if (span_ms) *span_ms = c->res_span_ms;
     if (busy_ms) *busy_ms = c->res_busy_ms;
+    if (slowest_ms) *slowest_ms = c->res_slowest_ms;
     return MVFIT_OK;
 }
 

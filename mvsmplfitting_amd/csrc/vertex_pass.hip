@@ -23,6 +23,7 @@
 //     them in registers; k-slice partials then meet in LDS in a fixed order (deterministic), all waves
 //     apply T and store.
 #include <cstdlib>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "mvfit_device.h"
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ bool pass_chunk_live(const DevPose& P, int b0, int B,
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void vp_blend_zero(float (&tr)[3][2][4]) {
 #pragma unroll
@@ -139,6 +141,27 @@ __device__ __forceinline__ void vp_blend_pairs(float (&tr)[3][2][4], int i, cons
             tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
             tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
         }
+}
+
+// the same, the four pairs taken two at a time: 6 transform rows in flight instead of 12 (the resident pass holds its
+// tiles' basis in registers next to this); the products and their order are the same
+__device__ __forceinline__ void vp_blend_pairs_2x2(float (&tr)[3][2][4], int i, const float* arow, const float4& spw, const int4& spj) {
+    const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
+    const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int t = 2 * h; t < 2 * h + 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + jq[t] * 12 + 4 * k);
+                tr[k][i][0] = fmaf(wq[t], a.x, tr[k][i][0]);
+                tr[k][i][1] = fmaf(wq[t], a.y, tr[k][i][1]);
+                tr[k][i][2] = fmaf(wq[t], a.z, tr[k][i][2]);
+                tr[k][i][3] = fmaf(wq[t], a.w, tr[k][i][3]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // T[k][i][:] = sum_j W[v_i][j] A_b[j][k][:]  (lbs.py:209-213), all 24 joints; Wt_w = this wave's copy of the tile's weights
@@ -998,74 +1021,139 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 //
 // The per-round launches above re-stream the 18.2 MB basis every round (379 times per 32-frame fit) and pay launch, ramp
 // and teardown around ~3 us of work.  Here a workgroup owns TPW vertex tiles for the whole fit: the tiles' split-fp16
-// basis is loaded ONCE into the registers of the six contraction waves (56 VGPRs per tile and wave: plane x K half, the
-// mapping of lbs_vertex_pass_split_kernel), and the workgroup then serves closure round after closure round:
+// basis is loaded ONCE into registers (56 VGPRs per contraction chain = tile x coordinate plane x K half, the chains of
+// lbs_vertex_pass_split_kernel), and the workgroup then serves closure round after closure round from the operand ring:
 //   * wave 7 polls the round's ring tags (relaxed agent-scope = sc1 loads, s_sleep between polls: one idle wave per
 //     workgroup, the form the guide's polling-cost row asks for) while the other waves sleep at the barrier; the verdict
 //     (go / all problems finished / timed out) and the mask of live 32-problem chunks go through LDS;
-//   * the operands of a chunk (split-fp16 coefficient words straight into the contraction waves' registers, the skinning
-//     transforms of a wave's own 4 problems into its private LDS rows, translations) are read with sc1 loads: the
-//     optimiser wrote them with sc1 (write-through) stores and drained them before the tag, so sc1 on both sides is the
-//     whole hand-off - no acquire fence, nothing invalidated under the optimiser workgroups of the same XCD;
-//   * blend, contraction, combine, apply, store: the code of the single-chunk kernel, unit by unit (chunk x tile) - the
-//     vertices are bit-identical to the per-round kernels' (tests/test_gpu_async.py, test_gpu_large_batch.py);
+//   * the operands of a chunk (28 KiB of split-fp16 coefficient words, 36 KiB of skinning transforms, translations) come
+//     as direct global -> LDS loads with sc1: the optimiser wrote them with sc1 (write-through) stores and drained them
+//     before the tag, so sc1 on both sides is the whole hand-off - no acquire fence, nothing invalidated under the
+//     optimiser workgroups of the same XCD.  The NEXT live chunk's operands are requested while this chunk is blended and
+//     stored: as soon as every contraction has read this chunk's coefficients, the transforms into the other of two
+//     buffers, the coefficients into their single one.  The buffers are separate __shared__ objects, so the compiler's
+//     wait-count pass knows which LDS accesses an in-flight request can touch (one dynamic array would make it wait for
+//     the request at the next LDS instruction); the barriers inside a chunk are bare s_barrier + lgkmcnt waits for the
+//     same reason (__syncthreads' fence waits for every outstanding request);
+//   * the 6 * TPW contraction chains are spread so that every SIMD carries the same number (TPW = 2: waves 0-3 two chains,
+//     waves 4-7 one; 21 dependent MFMAs each, the association of the per-round kernels: bit-identical vertices); all eight
+//     waves blend (4-pair skinning table), apply and store their (vertex pair, problem) items STRAIGHT from registers
+//     (24 contiguous bytes per item, 384-byte runs per problem) - no staging of the output, two barriers per chunk; the
+//     last tile's stores of a chunk are issued behind the chunk's closing barrier, so that the wait for the next chunk's
+//     operands never waits for fresh store acknowledgements;
 //   * back-pressure: the workgroup publishes the number of rounds whose operands it has read in its OWN word
 //     (ResidentArgs::wg_round); the optimiser takes the minimum over the words when its cached copy does not cover
 //     `round - nslots` (a few times per fit) - no atomics, no contention.
-// Per closure round the pass now moves 84,712 bytes per problem + 2.1 KB of operands per problem and workgroup; the basis
-// crosses the memory system once per fit.  Grid = ceil(ntiles / TPW) workgroups that must all be resident next to the
-// optimiser's (one CU each): the host picks TPW from the CU count (mvfit_api.hip: fit_async).
-// mvfit_profile: every workgroup logs {operands seen, stores drained} per round (wall clock, 100 MHz) - the round's
-// service span is max(drained) - min(seen) over the workgroups.
+// Per closure round the pass now moves 84,712 bytes per problem + the operands; the basis crosses the memory system once
+// per fit.  Grid = ceil(ntiles / TPW) workgroups that must all be resident next to the optimiser's (one CU each): the host
+// picks TPW from the CU count (mvfit_api.hip: fit_async).  Vertices bit-identical to the per-round kernels
+// (tests/test_gpu_async.py).  mvfit_profile: every workgroup logs {operands seen, stores drained} per round (wall clock).
 // ---------------------------------------------------------------------------------------------------------
-template <int TPW>
-__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_kernel(DevModel M, ResidentArgs RA) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* A_l = smem;                              // [32][A_STRIDE]   rows 4 w .. 4 w + 3 are private to wave w
-    float* tau_l = A_l + 32 * A_STRIDE;             // [2 parities][32][4]
-    float* part = tau_l + 2 * 32 * 4;               // [TPW][2 K-halves][3][32][33]
-    float* out_l = part + TPW * 2 * 3 * 32 * 33;    // [TPW][32 b][96]  skinned positions before "+ transl"
-    float4* sw_l = reinterpret_cast<float4*>(out_l + TPW * 32 * 96);   // [TPW][32] 4-pair skinning table of the tiles' vertices
-    int4* sj_l = reinterpret_cast<int4*>(sw_l + TPW * 32);          // [TPW][32]
-    unsigned* ctl = reinterpret_cast<unsigned*>(sj_l + TPW * 32);   // [8] verdict, live-chunk mask, stamp (2 words)
-    float4* coef_l = reinterpret_cast<float4*>(ctl + 8);            // [VP_NBLK][hi, lo][64 lanes] A operands of the chunk
+__device__ __forceinline__ void wg_barrier_lds() {           // workgroup barrier that orders LDS traffic only (see above)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-    const int tid_k = threadIdx.x, tid = tid_k, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave w blends problems [4 w, 4 w + 4)
+template <int TPW, bool HALF>
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_kernel(DevModel M, ResidentArgs RA) {
+    // separate LDS objects (alias information for the wait-count pass, see above)
+    // (element types = access widths, and every access below indexes the array itself: an access through a generic
+    // float* loses the alias information and waits for every request in flight)
+    __shared__ __attribute__((aligned(16))) f32x4 A_0[32 * A_STRIDE / 4];      // skinning transforms of a chunk, two buffers
+    __shared__ __attribute__((aligned(16))) f32x4 A_1[32 * A_STRIDE / 4];
+    __shared__ __attribute__((aligned(16))) f32x4 coef_l[VP_NBLK * 2 * 64];    // [VP_NBLK][hi, lo][64 lanes] A operands of a chunk
+    __shared__ __attribute__((aligned(16))) f32x4 tau_0[32];
+    __shared__ __attribute__((aligned(16))) f32x4 tau_1[32];
+    __shared__ float part[TPW * 2 * 3 * 32 * 33];                             // [TPW][2 K-halves][3][32][33]
+    __shared__ f32x4 sw_l[TPW * 32];                                          // 4-pair skinning table of the tiles' vertices
+    __shared__ i32x4 sj_l[TPW * 32];
+    __shared__ float vt_l[TPW * VP_NT];                                       // v_template rows of the chains (accumulator start)
+    __shared__ unsigned ctl[8];                                               // verdict, live-chunk mask, stamp (2 words)
+
+    const int tid_k = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
     const int wg = blockIdx.x;
-    const bool mfma_role = wave < 6;
-    const int kc_w = wave % 3, kh_w = wave / 3;
     const bool store_nt = VP_NT_LOADS && !(RA.flags & 2u);
     const float inv_scale = 1.0f / M.bs_scale;            // power of two: exact
     const unsigned nch = (unsigned)(RA.n + 31) >> 5;
+    // contraction chains: id = K-half * 3 TPW + tile * 3 + plane; every SIMD (wave & 3) carries 6 TPW / 4 of them
+    const int nchain = TPW == 1 ? (wave < 6 ? 1 : 0) : (wave < 4 ? 2 : 1);
+    const int chain0 = TPW == 1 ? wave : (wave < 4 ? 2 * wave : wave + 4);
+    const int kh_w = chain0 / (3 * TPW);                   // all chains of a wave are of one K half
 
-    // ---- once per fit: the tiles' basis (B operands of the contraction), v_template, skinning tables ----
-    float vt_init[TPW];
-    float4 bh[TPW][VP_BPW], bl[TPW][VP_BPW];
+    // ---- once per fit: the chains' basis (B operands of the contraction), v_template, skinning tables ----
+    float4 bh[TPW][VP_BPW], bl[HALF ? 1 : TPW][HALF ? 1 : VP_BPW];       // HALF (configs[4]): only the hi halves of the basis are read
+    int ch_t[TPW], ch_kc[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = min(wg * TPW + t, M.ntiles - 1);                 // (a tile past the end is never stored)
-        vt_init[t] = 0.f;
-        if (mfma_role) {
-            if (kh_w == 0) vt_init[t] = M.vt_planes[kc_w * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale;
-            const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + kc_w) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+    for (int s = 0; s < TPW; ++s) {
+        const int id = min(chain0 + s, 6 * TPW - 1);
+        const int rem = id - (id / (3 * TPW)) * (3 * TPW);
+        ch_t[s] = rem / 3; ch_kc[s] = rem - 3 * ch_t[s];
+        const int tile = min(wg * TPW + ch_t[s], M.ntiles - 1);           // (a tile past the end is never stored)
+        vt_l[s * VP_NT + tid_k] = 0.f;
+        if (s < nchain) {
+            const int lane = tid_k & 63;
+            if (kh_w == 0) vt_l[s * VP_NT + tid_k] = M.vt_planes[ch_kc[s] * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale;
+            const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + ch_kc[s]) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
 #pragma unroll
             for (int g = 0; g < VP_BPW; ++g) {
-                bh[t][g] = nt_load16(&cb[(2 * g) * 64]);
-                if (!M.half_basis) bl[t][g] = nt_load16(&cb[(2 * g + 1) * 64]);
-                else bl[t][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bh[s][g] = nt_load16(&cb[(2 * g) * 64]);
+                if (!HALF) bl[s][g] = nt_load16(&cb[(2 * g + 1) * 64]);
             }
         }
-        if (tid < 32) sw_l[t * 32 + tid] = M.wsp_w[(size_t)tile * TILE_V + tid];
-        else if (tid < 64) sj_l[t * 32 + tid - 32] = M.wsp_j[(size_t)tile * TILE_V + tid - 32];
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = min(wg * TPW + t, M.ntiles - 1);
+        if (tid_k < 32) sw_l[t * 32 + tid_k] = __builtin_bit_cast(f32x4, M.wsp_w[(size_t)tile * TILE_V + tid_k]);
+        else if (tid_k < 64) sj_l[t * 32 + tid_k - 32] = __builtin_bit_cast(i32x4, M.wsp_j[(size_t)tile * TILE_V + tid_k - 32]);
     }
     __syncthreads();
 
-    unsigned unit = 0;                                    // parity of the translation buffer
+    // requests of a chunk's operands: direct global -> LDS, sc1; spread over the eight waves (A: 36 x 1 KiB, coefficients 28);
+    // Q = the buffer the transforms go to (compile-time: the destination is a named LDS object)
+    auto request_A = [&](auto Q_, unsigned slot, unsigned c, int lane) {
+        constexpr int Q = decltype(Q_)::value;
+        const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u) * 72 + lane;
+        static_assert(A_STRIDE == 288, "a chunk's transforms are one linear 36 KiB copy");
+        for (int i = wave; i < 32 * 288 / 256; i += VP_NT / 64) {
+            if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_0[i * 64], 16, 0, /*aux = sc1*/ 16);
+            else __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_1[i * 64], 16, 0, 16);
+        }
+        if (wave == 7 && lane < 32) {
+            const float4* tsrc = reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane;
+            if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(tsrc, &tau_0[0], 16, 0, 16);
+            else __builtin_amdgcn_global_load_lds(tsrc, &tau_1[0], 16, 0, 16);
+        }
+    };
+    auto request_coef = [&](unsigned slot, unsigned c, int lane) {
+        const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
+        for (int i = 7 - wave; i < VP_NBLK * 2; i += VP_NT / 64)            // (waves 4-7, which carry one chain, take four)
+            __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_l[i * 64], 16, 0, 16);
+    };
+
+    // a (vertex pair, problem) item's finished vertices, kept in registers until their stores are issued
+    struct Pending { float o[6]; float* dst; int nv_ok; };
+    auto issue_stores = [&](const Pending& q) {
+        if (q.nv_ok >= 2) {
+            // 24 contiguous bytes (vertices 2 vp2, 2 vp2 + 1), 8-byte aligned (even vertex count, checked by the host)
+            const f32x2 q0 = {q.o[0], q.o[1]}, q1 = {q.o[2], q.o[3]}, q2 = {q.o[4], q.o[5]};
+            if (store_nt) {
+                __builtin_nontemporal_store(q0, reinterpret_cast<f32x2*>(q.dst));
+                __builtin_nontemporal_store(q1, reinterpret_cast<f32x2*>(q.dst + 2));
+                __builtin_nontemporal_store(q2, reinterpret_cast<f32x2*>(q.dst + 4));
+            } else {
+                *reinterpret_cast<f32x2*>(q.dst) = q0; *reinterpret_cast<f32x2*>(q.dst + 2) = q1; *reinterpret_cast<f32x2*>(q.dst + 4) = q2;
+            }
+        } else if (q.nv_ok == 1) {
+            q.dst[0] = q.o[0]; q.dst[1] = q.o[1]; q.dst[2] = q.o[2];
+        }
+    };
+
     for (unsigned r = 0; r < RA.max_rounds; ++r) {
         const unsigned slot = r % (unsigned)RA.nslots;
         // ---- wave 7: wait for the operands of closure round r (every problem: published, or finished before r) ----
         if (wave == 7) {
+            const int lane = tid_k & 63;
             const unsigned want = r + 1u;
             const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
             const unsigned* dn = RA.done_round + RA.b_lo;
@@ -1107,109 +1195,190 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
         __syncthreads();
-        const unsigned verdict = ctl[0], mask = ctl[1];
+        const unsigned verdict = ctl[0];
+        unsigned mask = ctl[1];
         if (verdict != 1u) break;                              // uniform
         float* vout = (RA.capture_verts && (int)r == RA.capture_round) ? RA.capture_verts : RA.verts;
 
-        for (unsigned c = 0; c < nch; ++c) {
-            if (!((mask >> c) & 1u)) continue;                 // uniform: the chunk's 32 problems all finished earlier
-            float* tau_c = tau_l + (unit & 1u) * 32 * 4;
-            ++unit;
-            // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address of the unit out of
-            // the round loop (the basis already holds 56 registers per tile; hoisted addresses spill)
+        // ---- the round's first live chunk: nothing to overlap its operands with ----
+        unsigned c = (unsigned)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        {
+            const int lane = tid_k & 63;
+            request_A(std::integral_constant<int, 0>{}, slot, c, lane);
+            request_coef(slot, c, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier_lds();
+        }
+        unsigned par = 0u;
+        // one chunk out of the buffers of parity P (compile-time: the buffers are distinct LDS objects)
+        auto chunk = [&](auto P_, unsigned c, int cn) {
+            constexpr int P = decltype(P_)::value;
+            auto A_row = [&](int idx) -> f32x4 { if constexpr (P == 0) return A_0[idx]; else return A_1[idx]; };   // 16-byte words
+            // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address of the chunk out of
+            // the round loop (the basis already holds 56 registers per chain; hoisted addresses spill)
             int tid = tid_k;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, vp2 = tid & 15, bb = tid >> 4;
-            // ---- the chunk's operands: direct global -> LDS loads with sc1 (no registers are held while they fly: the basis
-            //      and the blend need them).  Coefficient words: 28 x 1 KiB shared by the contraction waves, requested by
-            //      all eight; transforms: a wave's own 4 problems (4.5 KiB, contiguous in the ring and in LDS); translations ----
-            {
-                const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
-                for (int i = wave; i < VP_NBLK * 2; i += VP_NT / 64)
-                    __builtin_amdgcn_global_load_lds(csrc + i * 64, coef_l + i * 64, 16, 0, /*aux = sc1*/ 16);
-                static_assert(A_STRIDE == 288, "a wave's 4 problems are one linear copy");
-                const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u + 4u * (unsigned)wave) * 72 + lane;
-                float4* adst = reinterpret_cast<float4*>(A_l + 4 * wave * A_STRIDE);
+            // (c) blendshape contraction: this wave's chains (one K half; plane, tile per chain); small products first.  The
+            //     chunk's A operands are read once per block and feed the chains' independent accumulators
+            // (straight-line code per chain count: a per-MFMA `if (s < nchain)` costs accumulator copies)
+            auto contract = [&](auto NC_) {
+                constexpr int NC = decltype(NC_)::value;
+                floatx16 acc[NC];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(asrc + i * 64, adst + i * 64, 16, 0, 16);
-                if (lane < 32) __builtin_amdgcn_global_load_lds(asrc + 256, adst + 256, 16, 0, 16);
-                if (wave == 7 && lane < 32)
-                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane,
-                                                     reinterpret_cast<float4*>(tau_c), 16, 0, 16);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // the coefficient words are staged by all waves
-            const int b0 = RA.b_lo + (int)c * 32, b_end = RA.b_lo + RA.n;
-            if (mfma_role) {
-                // ---- blendshape contraction: plane kc_w, K-half kh_w of every tile of this workgroup; small products first.
-                //      The chunk's A operands are read once per block and feed the tiles' independent accumulators ----
-                floatx16 acc[TPW];
+                for (int s = 0; s < NC; ++s)
 #pragma unroll
-                for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[t][q] = vt_init[t];
-                const float4* cl = coef_l + (kh_w * VP_BPW * 2) * 64 + lane;
+                    for (int q = 0; q < 16; ++q) acc[s][q] = vt_l[s * VP_NT + tid];
+                const int cl = (kh_w * VP_BPW * 2) * 64 + lane;
 #pragma unroll
                 for (int g = 0; g < VP_BPW; ++g) {
-                    const half8 Ah = __builtin_bit_cast(half8, cl[(2 * g) * 64]), Al = __builtin_bit_cast(half8, cl[(2 * g + 1) * 64]);
+                    const half8 Ah = __builtin_bit_cast(half8, coef_l[cl + (2 * g) * 64]), Al = __builtin_bit_cast(half8, coef_l[cl + (2 * g + 1) * 64]);
 #pragma unroll
-                    for (int t = 0; t < TPW; ++t) {
-                        const half8 Bh = __builtin_bit_cast(half8, bh[t][g]), Bl = __builtin_bit_cast(half8, bl[t][g]);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
-                        if (!M.half_basis) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
+                    for (int s = 0; s < NC; ++s) {
+                        const half8 Bh = __builtin_bit_cast(half8, bh[s][g]);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[s], 0, 0, 0);
+                        if (!HALF) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bl[HALF ? 0 : s][HALF ? 0 : g]), acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[s], 0, 0, 0);
                     }
-                    if (TPW > 1) __builtin_amdgcn_sched_barrier(0);      // one block's operands in flight at a time (registers)
+                    if (NC > 1) __builtin_amdgcn_sched_barrier(0);       // one block's operands in flight at a time (registers)
                 }
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) vp_put_partial(part + t * (2 * 3 * 32 * 33), kh_w, kc_w, acc[t], lane);
+                for (int s = 0; s < NC; ++s) {
+                    // MFMA D layout -> part[tile][K half][plane][problem][33]: col (vertex) = lane & 31,
+                    // row (problem) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                    const int p0 = (((ch_t[s] * 2 + kh_w) * 3 + ch_kc[s]) * 32 + 4 * (lane >> 5)) * 33 + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) part[p0 + ((q & 3) + 8 * (q >> 2)) * 33] = acc[s][q];
+                }
+            };
+            if (nchain == TPW) contract(std::integral_constant<int, TPW>{});
+            else if (TPW > 1 && nchain == 1) contract(std::integral_constant<int, 1>{});
+            wg_barrier_lds();                                  // partials published; every chain has read the coefficients
+            // (d) the next live chunk's operands: transforms into the other buffer, coefficient words into the buffer just
+            //     released.  (Not earlier: no request is in flight while the partials are written - the wait-count pass
+            //     loses the alias information of some of those LDS stores and would wait for the requests there)
+            if (cn >= 0) {
+                request_A(std::integral_constant<int, 1 - P>{}, slot, (unsigned)cn, lane);
+                request_coef(slot, (unsigned)cn, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // (e) all waves: skinning blend (lbs.py:209-213), K halves combined in a fixed order, scale undone, T applied,
+            //     "+ transl"; stores straight from registers (the last tile's: behind the closing barrier)
+            const int b_me = RA.b_lo + (int)c * 32 + bb;
+            const bool b_ok = b_me < RA.b_lo + RA.n;
+            f32x4 tq;
+            if constexpr (P == 0) tq = tau_0[bb]; else tq = tau_1[bb];
+            const float tau3[3] = {tq.x, tq.y, tq.z};
+            Pending last;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tile = wg * TPW + t;
                 if (tile >= M.ntiles) break;                   // uniform
-                // ---- skinning blend (lbs.py:209-213), all waves ----
-                float tr[3][2][4];
-                vp_blend_zero(tr);
-                vp_blend_pairs(tr, 0, A_l + bb * A_STRIDE, sw_l[t * 32 + 2 * vp2], sj_l[t * 32 + 2 * vp2]);
-                __builtin_amdgcn_sched_barrier(0);             // 12 transform rows in flight at a time, not 24 (registers)
-                vp_blend_pairs(tr, 1, A_l + bb * A_STRIDE, sw_l[t * 32 + 2 * vp2 + 1], sj_l[t * 32 + 2 * vp2 + 1]);
-                if (t == 0) __syncthreads();                   // the partials of all tiles are published
-                // ---- combine the two K-halves (fixed order), undo the basis scale, apply T ----
-                float* out_t = out_l + t * (32 * 96);
-                vp_apply<2, true, false>(part + t * (2 * 3 * 32 * 33), tr, out_t, nullptr, bb, vp2, inv_scale);
-                __syncthreads();
-                // ---- store x + transl ----
-                vp_store_rows(vout, out_t, tau_c, M.nv, tile * TILE_V, min(TILE_V, M.nv - tile * TILE_V) * 3, b0, b_end, tid, store_nt);
+                // per vertex of the item: T[k][:] = sum over its 4 (weight, joint) pairs, ascending joint order - the non-zero
+                // products of the dense blend in the same order (vp_blend_pairs) -, then v_posed from the two K halves (fixed
+                // order, scale undone), T applied, "+ transl".  One vertex at a time, two pairs = 6 transform rows in flight:
+                // the tiles' basis sits in registers next to this
+                const int pt = t * (2 * 3 * 32 * 33);
+                Pending cur;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 spw = sw_l[t * 32 + 2 * vp2 + i];
+                    const i32x4 spj = sj_l[t * 32 + 2 * vp2 + i];
+                    const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
+                    const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+                    float tr[3][4];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tr[k][e] = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int u = 2 * h; u < 2 * h + 2; ++u)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const f32x4 a = A_row(bb * (A_STRIDE / 4) + jq[u] * 3 + k);
+                                tr[k][0] = fmaf(wq[u], a.x, tr[k][0]);
+                                tr[k][1] = fmaf(wq[u], a.y, tr[k][1]);
+                                tr[k][2] = fmaf(wq[u], a.z, tr[k][2]);
+                                tr[k][3] = fmaf(wq[u], a.w, tr[k][3]);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const int v = 2 * vp2 + i;
+                    float vp[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float sm = part[pt + ((0 * 3 + k) * 32 + bb) * 33 + v];
+                        sm += part[pt + ((1 * 3 + k) * 32 + bb) * 33 + v];
+                        vp[k] = sm * inv_scale;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        cur.o[3 * i + k] = fmaf(tr[k][0], vp[0], fmaf(tr[k][1], vp[1], fmaf(tr[k][2], vp[2], tr[k][3]))) + tau3[k];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t + 1 < TPW && tile + 1 < M.ntiles) {
+                    const int vbase = tile * TILE_V;
+                    cur.dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vp2) * 3;
+                    cur.nv_ok = b_ok ? min(TILE_V, M.nv - vbase) - 2 * vp2 : 0;
+                    issue_stores(cur);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) last.o[q] = cur.o[q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // (f) the next chunk's operands have landed (this wave's requests; the stores issued above are a tile old); the
+            //     last tile's stores go out BEHIND the closing barrier: the wait never waits for fresh store acknowledgements
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier_lds();
+            {   // (address and validity recomputed here: three registers less across the barrier)
+                int t2 = tid_k;
+                asm volatile("" : "+v"(t2));
+                const int tile = min(wg * TPW + TPW - 1, M.ntiles - 1), vbase = tile * TILE_V, vq = t2 & 15;
+                const int bq = RA.b_lo + (int)c * 32 + (t2 >> 4);
+                last.dst = vout + ((size_t)bq * M.nv + vbase + 2 * vq) * 3;
+                last.nv_ok = bq < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;
+                issue_stores(last);
+            }
+        };
+        for (;;) {
+            const int cn = mask ? __builtin_ctz(mask) : -1;
+            if (par == 0u) chunk(std::integral_constant<int, 0>{}, c, cn);
+            else chunk(std::integral_constant<int, 1>{}, c, cn);
+            if (cn < 0) break;
+            // the first chunk of a round always lands in buffer 0 (see above): parity restarts every round
+            mask &= mask - 1u;
+            c = (unsigned)cn;
+            par ^= 1u;
         }
-        // every wave has read its operands of this round (they were waited for before the blends, barriers since): the
-        // ring slot may be overwritten as far as this workgroup is concerned
-        if (tid == 0) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every wave has read its operands of this round (barriers since): the ring slot may be overwritten as far as this
+        // workgroup is concerned
+        if (tid_k == 0) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (RA.log && r < (unsigned)RA.log_rounds) {           // uniform (mvfit_profile only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's vertex stores have been acknowledged
             __syncthreads();
-            if (tid == 0) {
+            if (tid_k == 0) {
                 unsigned long long* lg = RA.log + ((size_t)r * gridDim.x + wg) * 2;
                 lg[0] = (unsigned long long)ctl[2] | ((unsigned long long)ctl[3] << 32);
                 lg[1] = (unsigned long long)wall_clock64();
             }
         }
+        // (a round's first chunk goes to buffer 0 whatever the last one used: every request of this round has landed and
+        // every wave is behind the closing barrier of its last chunk)
     }
     // whatever ended the loop: nothing waits for this workgroup any more
-    if (tid == 0) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-size_t vertex_pass_resident_lds_bytes(int tpw) {
-    return sizeof(float) * (size_t)(32 * A_STRIDE + 2 * 32 * 4 + tpw * (2 * 3 * 32 * 33 + 32 * 96)) + 32 * (size_t)tpw * 32 + 32 + 16 * (size_t)(VP_NBLK * 2 * 64);
+    if (tid_k == 0) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // tpw = tiles per workgroup (1 or 2); grid = ceil(ntiles / tpw) workgroups, all of which must be resident
 hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream) {
     const dim3 grid((M.ntiles + tpw - 1) / tpw);
-    if (tpw == 1) hipLaunchKernelGGL(lbs_vertex_pass_resident_kernel<1>, grid, dim3(VP_NT), vertex_pass_resident_lds_bytes(1), stream, M, RA);
-    else hipLaunchKernelGGL(lbs_vertex_pass_resident_kernel<2>, grid, dim3(VP_NT), vertex_pass_resident_lds_bytes(2), stream, M, RA);
+    auto kern = tpw == 1 ? (M.half_basis ? lbs_vertex_pass_resident_kernel<1, true> : lbs_vertex_pass_resident_kernel<1, false>)
+                         : (M.half_basis ? lbs_vertex_pass_resident_kernel<2, true> : lbs_vertex_pass_resident_kernel<2, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(VP_NT), 0, stream, M, RA);       // (static LDS)
     return hipGetLastError();
 }
 
@@ -1285,12 +1454,6 @@ hipError_t vertex_pass_configure() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_resident_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_resident_lds_bytes(1));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_resident_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_resident_lds_bytes(2));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_pipe_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_pipe_lds_bytes());

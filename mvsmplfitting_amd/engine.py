@@ -405,10 +405,11 @@ class MvFit:
     def pass_profile(self):
         """How the vertex passes of the last asynchronous fit ran (include/mvfit.h:mvfit_pass_profile)."""
         tpw, wgs, n = C.c_int(), C.c_int(), C.c_int()
-        span, busy = C.c_double(), C.c_double()
-        self._check(self._lib.mvfit_pass_profile(self._ctx, C.byref(tpw), C.byref(wgs), C.byref(n), C.byref(span), C.byref(busy)))
+        span, busy, slowest = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.mvfit_pass_profile(self._ctx, C.byref(tpw), C.byref(wgs), C.byref(n), C.byref(span), C.byref(busy),
+                                                 C.byref(slowest)))
         return dict(tiles_per_workgroup=tpw.value, workgroups=wgs.value, rounds_stamped=n.value,
-                    round_span_ms=span.value, workgroup_busy_ms=busy.value)
+                    round_span_ms=span.value, workgroup_busy_ms=busy.value, slowest_workgroup_ms=slowest.value)
 
     def profile_read(self):
         a, b = C.c_double(), C.c_double()

@@ -119,7 +119,12 @@ def test_unmodified_caller_drives_libmvfit(seams, monkeypatch, use_vposer, n_sta
         ref_loss[dtype] = float(res['loss'])
     worst = max(ref_loss.values())
     # an un-patched reference problem for the closure-level comparison (its loss / monitor objects are the reference's)
+    # ... and its own float32 closure at the same point: the yard-stick for the gradient (the gradient is the small
+    # difference of large data / prior terms; float32 rounding leaves ~0.1 absolute in the reference as on the device).
+    # Both are built BEFORE patch(): their loss / monitor objects must be the reference's, not the mirror's.
     rp64, _, _ = _setting_and_data(*prob, use_vposer, 'float64')
+    rp32, _, _ = _setting_and_data(*prob, use_vposer, 'float32')
+    assert type(rp32.monitor).__module__.endswith('utils.fitting') and type(rp32.loss).__module__.endswith('utils.fitting')
     patch()
     # (1) yaml default optimiser: the reference's own LBFGSLs drives the HIP closure from the host
     log = []
@@ -136,16 +141,23 @@ def test_unmodified_caller_drives_libmvfit(seams, monkeypatch, use_vposer, n_sta
     # closure level: every 7th recorded call + the first call of each stage, against the reference's own closure
     firsts = [next(i for i, r in enumerate(log) if (r['weights']['body_pose_weight'], r['weights']['shape_weight']) == w) for w in seen]
     picks = sorted(set(firsts) | set(range(0, len(log), 7)))
-    worst_l = worst_g = 0.0
+    worst_l, worst_g, worst_info = 0.0, 0.0, None
     for i in picks:
         rec = log[i]
         l_ref, g_ref = _reference_closure_at(rp64, rec)
+        _, g_r32 = _reference_closure_at(rp32, rec)
         worst_l = max(worst_l, abs(rec['loss'] - l_ref) / abs(l_ref))
         gmax = max(np.abs(v).max() for v in g_ref.values())
         for k, v in rec['grads'].items():
-            worst_g = max(worst_g, np.abs(v - g_ref[k]).max() / gmax)
+            err = np.abs(v - g_ref[k]).max()
+            err32 = max(np.abs(g_r32[q] - g_ref[q]).max() for q in g_ref)
+            excess = err / (2e-4 * gmax + 4.0 * err32)
+            if excess > worst_g:
+                worst_g, worst_info = excess, dict(call=i, of=len(log), param=k, err=err, gmax=gmax, reference_float32_err=err32)
     assert worst_l <= 1e-5, worst_l                     # north_star: 1e-5 on the scalar loss
-    assert worst_g <= 2e-4, worst_g
+    # gradient: 2e-4 of its largest entry (the bound of the golden closure tests) + 4 x what the reference's own float32
+    # closure deviates from its float64 one at that point
+    assert worst_g <= 1.0, worst_info
     # (2) opt-in device-resident optimiser: whole stages inside mvfit_fit
     res_hip, _ = _run(nls, prob, use_vposer, 'lbfgs_hip', 'float32', n_stages)
     unpatch()
@@ -156,9 +168,9 @@ def test_unmodified_caller_drives_libmvfit(seams, monkeypatch, use_vposer, n_sta
         assert np.isfinite(res['loss'])
         assert float(res['loss']) <= slack * worst, (name, float(res['loss']), ref_loss)
     print('real caller: use_vposer=%s stages=%d reference fp64 / fp32 %.4f / %.4f, lbfgsls on libmvfit %.4f, lbfgs_hip %.4f; '
-          'closure level over %d points: loss %.1e rel, grad %.1e of max'
+          'closure level over %d points: loss %.1e rel, gradient at %.2f of its bound (worst: %s)'
           % (use_vposer, n_stages, ref_loss['float64'], ref_loss['float32'], float(res_ls['loss']), float(res_hip['loss']),
-             len(picks), worst_l, worst_g))
+             len(picks), worst_l, worst_g, worst_info))
 
 
 def test_sequence_mode_of_the_unmodified_caller_on_libmvfit(seams):
