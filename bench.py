@@ -402,27 +402,14 @@ def end_to_end(MvFit, syn, frames=32, reps=3):
             'reference_counterpart': "code/main.py:27,91-94 (the reference's only timer: whole frame incl. file I/O); not run here"}
 
 
-def with_env(env, fn):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return fn()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
     """Roofline of the vertex pass in its other instantiations, each on its own engine: the exact-fp32 contraction
     at 32 problems and the chunk-loop kernel at 128 problems (64 back-to-back launches inside one hipEvent pair)."""
     out = {}
     cams = syn.make_camera_ring(views)
 
-    def measure(B, env):
-        eng = with_env(env, lambda: MvFit(model))
+    def measure(B, opts):
+        eng = MvFit(model, options=opts)
         rng = np.random.default_rng(B)
         x = np.zeros((B, 118), np.float32)
         x[:, :86] = rng.normal(0, 0.2, (B, 86))
@@ -434,12 +421,12 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
         eng.close()
         return ms
     for name, B, env, kern, key in (
-            ('exact_fp32_B32', 32, {'MVFIT_EXACT_FP32': '1'}, 'lbs_vertex_pass_kernel<true>', None),
+            ('exact_fp32_B32', 32, {'contraction': 'exact_fp32'}, 'lbs_vertex_pass_kernel<true>', None),
             ('split_fp16_B128', 128, {}, 'lbs_vertex_pass_pipe_kernel', 'B128'),
-            ('half_basis_B32', 32, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_split_kernel<true>', None),
-            ('half_basis_B128', 128, {'MVFIT_HALF_BASIS': '1'}, 'lbs_vertex_pass_pipe_kernel', None)):
+            ('half_basis_B32', 32, {'contraction': 'half_basis'}, 'lbs_vertex_pass_split_kernel<true>', None),
+            ('half_basis_B128', 128, {'contraction': 'half_basis'}, 'lbs_vertex_pass_pipe_kernel', None)):
         ms = measure(B, env)
-        nbytes = bytes_fwd(B, skin_topk, half_basis='MVFIT_HALF_BASIS' in env)
+        nbytes = bytes_fwd(B, skin_topk, half_basis=env.get('contraction') == 'half_basis')
         ach = nbytes / (ms * 1e-3) / 1e9
         if B > 32 and not (skin_topk and skin_topk <= 4):
             kern = 'lbs_vertex_pass_split_loop_kernel<false>'     # dense skinning rows: the lock-step chunk loop
@@ -449,10 +436,10 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
                          measured='the per-round launch kernel ALONE (64 back-to-back launches inside one hipEvent pair)',
                          traffic=pmc_value(key, 'vertex_pass_pipe') if key else None)
     # the pass INSIDE a fit at 128 problems (the per-GPU share of configs[3]): one complete profiled 4-stage fit
-    for name, env in (('split_fp16_B128', {}), ('half_basis_B128', {'MVFIT_HALF_BASIS': '1'})):
+    for name, env in (('split_fp16_B128', {}), ('half_basis_B128', {'contraction': 'half_basis'})):
         try:
             from mvsmplfitting_amd.engine import stage_weights
-            eng = with_env(env, lambda: MvFit(model))
+            eng = MvFit(model, options=env)
             cams_b, gt, conf, x0 = build_inputs(eng, syn, 0, 128, 1, views)
             st = stage_weights(1536.0)
             x0_d = torch.tensor(x0, device=eng.device)
@@ -462,7 +449,7 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
             pr = eng.profile_read()
             pp = eng.pass_profile()
             eng.profile(False)
-            nbytes = bytes_fwd(128, skin_topk, half_basis='MVFIT_HALF_BASIS' in env)
+            nbytes = bytes_fwd(128, skin_topk, half_basis=env.get('contraction') == 'half_basis')
             ms = pr['vertex_pass_ms']
             which = 'dispatch'
             if pp['tiles_per_workgroup']:
@@ -514,7 +501,8 @@ def prior_variants(MvFit, syn, _lib, stage_weights, model, frames, views, steps=
         tot = sum(int(n.sum().item()) for n in ncl)
         out[name] = dict(value=round(tot / dt, 1), unit='closures/s', ms_per_step=round(1e3 * dt / steps, 3),
                          closures_per_fit_per_frame=round(tot / steps / frames, 1), closure_rounds_per_fit=int(ncl[-1].max().item()),
-                         final_loss_median=float(np.median(st['final_loss'].cpu().numpy())), vertex_passes_last_fit=st.get('passes'))
+                         final_loss_median=float(np.median(st['final_loss'].cpu().numpy())), vertex_passes_last_fit=st.get('passes'),
+                         vertex_pass_mode=eng.pass_profile())
         if flag & _lib.F_VPOSER:
             out[name]['decoder_helpers_last_fit'] = eng.decoder_stats()
         eng.close()
@@ -598,10 +586,19 @@ def main():
                     help='configs[2]: SDF interpenetration term on (grid 128; yaml coll_loss_weights)')
     ap.add_argument('--sdf-faces', default='wired', choices=['wired', 'all'],
                     help="wired: the first triangle only, as the reference's call site makes the op see it; all: the 13,776 faces")
+    ap.add_argument('--contraction', default='split_fp16', choices=['split_fp16', 'exact_fp32', 'half_basis'],
+                    help='blendshape contraction of the vertex pass (mvfit_options::contraction)')
+    ap.add_argument('--round-mode', default='auto', choices=['auto', 'chained'],
+                    help='chained: vertex pass -> step kernel per closure round also without the SDF term (mvfit_options::round_mode)')
+    ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 resident (mvfit_options)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline / prior variants')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 PMC passes (traffic then comes from profiles/*_pmc.json)')
     ap.add_argument('--dist-backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a dry run)')
+    ap.add_argument('--dump-gathered', default=None,
+                    help='rank 0 writes the gathered parameters of the last fit, [persons, frames_total, 118] float32, to this .npy '
+                         '(tests compare an N-rank run with a 1-rank run bit for bit)')
     ap.add_argument('--single-device', action='store_true',
                     help='dry run of the multi-rank path on ONE GPU: every rank uses cuda:0 (needs --dist-backend gloo)')
     args = ap.parse_args()
@@ -650,7 +647,7 @@ def main():
     views = args.views if args.views is not None else preset['views']
     persons = args.persons if args.persons is not None else preset['persons']
     sdf = args.sdf or preset.get('sdf', False)
-    half_basis = bool(preset.get('half_basis')) or os.environ.get('MVFIT_HALF_BASIS') == '1'
+    half_basis = bool(preset.get('half_basis')) or args.contraction == 'half_basis'
     if demo:
         assert world == 1, 'the demo is one frame'
         g, vpw, model, cams, gt, conf, x0 = demo_inputs(syn)
@@ -667,8 +664,9 @@ def main():
         assert hi > lo, 'more ranks than frames'
         B = persons * (hi - lo)
         total = persons * total_frames
-    eng = with_env({'MVFIT_HALF_BASIS': '1'} if half_basis else {},
-                   lambda: MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank))
+    eng_options = dict(contraction='half_basis' if half_basis else args.contraction, round_mode=1 if args.round_mode == 'chained' else 0,
+                       resident_pass=args.resident_pass)
+    eng = MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank, options=eng_options)
     flags = 0
     if args.prior == 'vposer':
         flags |= _lib.F_VPOSER
@@ -747,6 +745,10 @@ def main():
         dist.all_gather(bz, torch.tensor([busy / args.steps * 1e3], device=dev, dtype=torch.float64))
         busy_all = [round(float(b.item()), 3) for b in bz]
         assert gathered.shape[0] == total_frames
+    if args.dump_gathered and rank == 0:
+        # [frames_total, persons, 118] (the gather's layout: contiguous frame blocks per rank) -> [persons, frames_total, 118]
+        full = gathered if world > 1 else xf.reshape(persons, B // persons, -1).transpose(0, 1)
+        np.save(args.dump_gathered, full.transpose(0, 1).contiguous().cpu().numpy())
         tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
         lost = [int(red[2].item()), int(red[3].item())]
 
@@ -884,7 +886,10 @@ def main():
             'config': {'workload': workload, 'problems_per_gpu': B, 'frames_per_gpu': B // persons, 'persons': persons,
                        'frames_total': total_frames, 'problems_total': total, 'views': views, 'prior': args.prior,
                        'closure_mode': mode, 'parallelism': 'frame-sharded x%d, RCCL all_gather of results' % world},
-            'ms_to_convergence_per_frame': round(1e3 * tmax / args.steps / max(B, 1), 4),
+            # BASELINE's "ms to convergence / frame", both readings: amortised over the concurrently fitted frames (throughput), and
+            # the latency a frame actually sees (its batch's whole staged fit; one frame alone: --config demo)
+            'ms_per_frame_amortised': round(1e3 * tmax / args.steps / max(B, 1), 4),
+            'fit_latency_ms': round(1e3 * tmax / args.steps, 3),
             'lbfgs_iters_per_s': round(tot_iter / tmax, 1),
             'closures_per_fit_per_frame': round(tot_closure / args.steps / total, 1),
             'closure_rounds_per_fit': n_max,      # = closures of the slowest frame of rank 0's batch
@@ -893,6 +898,15 @@ def main():
             'vertex_passes_lost_in_timed_fits': {'missed': lost[0], 'timed_out': lost[1]},
             'decoder_helpers_last_fit': decoder,
             'per_rank_busy_ms_per_step': busy_all,
+            # ranks that exchanged the results over RCCL in this run (0: one rank, or a gloo dry run) - no curve beyond one GPU
+            # has been measured on hardware by the build sessions (one GPU per gpurun box)
+            'rccl_ranks_seen': world if (world > 1 and args.dist_backend == 'nccl') else 0,
+            'dist_backend': args.dist_backend if world > 1 else None,
+            # the same workload with the other pose priors of SURVEY 8(d) config 2, first-class next to `value` (which is the
+            # plain L2 prior, fit_smpl.yaml's body_prior_type with use_vposer off): VPoser-L2 is the reference's shipped yaml
+            # default (use_vposer: true, cfg_files/fit_smpl.yaml:35-37), GMM its max-mixture prior (synthetic, M = 8)
+            'value_vposer': (variants or {}).get('prior_vposer', {}).get('value') if args.prior == 'l2' else None,
+            'value_gmm': (variants or {}).get('prior_gmm', {}).get('value') if args.prior == 'l2' else None,
             'variants': variants,
             'roofline': roof, 'cpu_baseline': cpu,
         }

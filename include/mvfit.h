@@ -128,15 +128,55 @@ typedef struct mvfit_lbfgs_opts {
 
 /* SMPL.__init__ + .to(device) (body_models_scale.py:98-305, code/init.py:143-151): copies and
  * re-tiles the constants into HBM.  hip_stream may be NULL (default stream). */
-/* Environment switches read here (testing / comparison): MVFIT_EXACT_FP32=1 keeps the vertex pass's blendshape
- * contraction as an exact fp32 MFMA chain (default: error-compensated split-fp16 products, fp32 accumulate);
- * MVFIT_DENSE_SKINNING=1 keeps the dense 24-column skinning blend even when every vertex has <= 4 weights;
- * MVFIT_HALF_BASIS=1 (BASELINE configs[4], half-width blendshape operands): the vertex pass streams only the fp16 hi
- * halves of the basis (2 bytes per element; vertices then differ from the fp32 result by up to ~2e-5, tests). */
+/* Precision and path selectors of a ctx.  The released library reads NO environment variable: what used to be MVFIT_*
+ * switches are fields here (mvfit_options_default fills the defaults; mvfit_create(...) = mvfit_create_ex(..., NULL) = the
+ * defaults).  The first group decides what mvfit_create_ex uploads and is fixed for the ctx's life; the second group may be
+ * changed between calls with mvfit_set_options. */
+#define MVFIT_CONTRACTION_SPLIT_FP16 0   /* default: every fp32 product of the blendshape contraction as error-compensated
+                                          * split-fp16 pairs on the fp16 matrix pipe, fp32 accumulate (5e-7 from float64) */
+#define MVFIT_CONTRACTION_EXACT_FP32 1   /* the contraction as an exact fp32 MFMA chain (bitwise an fmaf chain) */
+#define MVFIT_CONTRACTION_HALF_BASIS 2   /* BASELINE configs[4], half-width blendshape operands: only the fp16 hi halves of the
+                                          * basis are streamed (2 bytes per element; vertices within ~2e-5 of the fp32 result) */
+typedef struct mvfit_options {
+    uint32_t struct_size;            /* sizeof(mvfit_options) of the caller */
+    /* ---- fixed at mvfit_create_ex ---- */
+    int32_t contraction;             /* MVFIT_CONTRACTION_* */
+    int32_t dense_skinning;          /* 1: the dense 24-column skinning blend even when every vertex has <= 4 weights (0) */
+    /* ---- mvfit_set_options ---- */
+    int32_t round_mode;              /* 0: automatic (asynchronous single-launch fit wherever the objective allows);
+                                      * 1: chained rounds always (vertex pass -> step kernel per closure round) */
+    int32_t resident_pass;           /* vertex passes of the asynchronous fit: -1 automatic (resident when its workgroups fit
+                                      * next to the optimiser's), 0 a gate + a pass launch per closure round, 1 / 2 resident with
+                                      * that many vertex tiles per workgroup (a forced value that does not fit stalls the fit) */
+    int32_t sdf_two_phase;           /* 1 (default): a fit with the SDF term runs its leading coll_loss_weight == 0 stages
+                                      * asynchronously and hands over to chained rounds; 0: chained rounds in every stage */
+    int32_t sdf_face_lists;          /* 1 (default): long face lists are culled exactly on per-round face lists (bit-identical
+                                      * to the walk); 0: the walk over every face for every vertex / voxel */
+    int32_t vposer_helpers;          /* 1 (default): the single-launch fits decode VPoser on helper workgroups; 0: in the
+                                      * problems' own workgroups (another summation order: last-bit differences) */
+    int32_t vposer_sets;             /* 0: automatic; n: helper sets of a launch (clamped to what the problems need / fit) */
+    int32_t closure_vposer_helpers;  /* 1: mvfit_closure (MVFIT_F_VPOSER, no SDF term, B <= 160) decodes on helper workgroups
+                                      * of its own launch - the decoder arithmetic of the fits, for parity tests (0) */
+    int32_t pass_kernel;             /* per-round launch kernels at more than 32 problems: 0 automatic (two-role pipeline),
+                                      * 1 one workgroup per (tile, chunk), 2 lock-step chunk loop */
+} mvfit_options;
+void mvfit_options_default(mvfit_options* opts);
+
 /* Error contract: MVFIT_E_ARG for a null / incomplete model leaves *out = NULL.  Any later failure (unsupported
  * model, device allocation) still stores a ctx in *out: it carries the message (mvfit_last_error) and owns whatever
  * was allocated so far - release it with mvfit_destroy, it is not usable for anything else. */
 int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* model);
+/* mvfit_create with explicit options (NULL = defaults).  MVFIT_E_ARG for an unknown selector value. */
+int mvfit_create_ex(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* model, const mvfit_options* opts);
+/* Change the second group of options between calls; the first group must equal what the ctx was created with
+ * (MVFIT_E_ARG otherwise).  mvfit_get_options returns what is in force. */
+int mvfit_set_options(mvfit_ctx* ctx, const mvfit_options* opts);
+int mvfit_get_options(const mvfit_ctx* ctx, mvfit_options* opts);
+/* Which path served the last mvfit_sdf call (*op_path) and the SDF term of the last mvfit_fit / mvfit_closure (*term_path):
+ * 0 the walk over every face (short face list, or sdf_face_lists = 0), 1 face lists, 2 the walk because the lists'
+ * workspace (11.6 MB per problem at 13,776 faces) did not fit in half of the free device memory - decided once per shape
+ * and remembered, a ~10x slower path that is never taken silently: the Python adapter warns. */
+int mvfit_sdf_info(const mvfit_ctx* ctx, int* op_path, int* term_path);
 void mvfit_destroy(mvfit_ctx* ctx);
 const char* mvfit_last_error(const mvfit_ctx* ctx);
 int mvfit_sync(mvfit_ctx* ctx);
@@ -159,10 +199,10 @@ int mvfit_set_joints3d(mvfit_ctx* ctx, const float* gt3d, const float* conf3d);
  * (code/utils/fitting.py:162-203) = SMPL.forward + SMPLifyLoss.forward + backward.
  *   params[B,MVFIT_D] dev ; loss[B] dev ; grad[B,MVFIT_D] dev or NULL (forward only) ;
  *   verts[B,Nv,3] dev or NULL ; joints[B,17,3] dev or NULL.
- * Environment, read per call: MVFIT_CLOSURE_VP_HELPERS=1 (with MVFIT_F_VPOSER, no SDF term, B <= 160) decodes the body
- * pose on helper workgroups of the closure's own launch - the decoder arithmetic of the single-launch fits (another
- * summation order than the in-workgroup decoder, ~1e-7 relative) - so that the parity tests can hold the shipping decoder
- * against the closure-level goldens (tests/test_gpu_closure_helpers.py); mvfit_decoder_stats reports that launch. */
+ * mvfit_options::closure_vposer_helpers = 1 (with MVFIT_F_VPOSER, no SDF term, B <= 160) decodes the body pose on helper
+ * workgroups of the closure's own launch - the decoder arithmetic of the single-launch fits (another summation order than
+ * the in-workgroup decoder, ~1e-7 relative) - so that the parity tests can hold the shipping decoder against the
+ * closure-level goldens (tests/test_gpu_closure_helpers.py); mvfit_decoder_stats reports that launch. */
 int mvfit_closure(mvfit_ctx* ctx, const mvfit_weights* w, const float* params,
                   float* loss, float* grad, float* verts, float* joints);
 
@@ -197,7 +237,7 @@ int mvfit_fit_stats(mvfit_ctx* ctx, uint32_t* out4);
 
 /* Counters of the decoder helpers of the last mvfit_fit.  With MVFIT_F_VPOSER the single-launch fits (asynchronous and
  * objective-vertices-only) run the VPoser decoder's layers (VPoser.py:218-232) on helper workgroups of the same launch
- * that keep the weights in registers (csrc/vposer_service.h; MVFIT_VP_HELPERS=0 in the environment keeps them in the
+ * that keep the weights in registers (csrc/vposer_service.h; mvfit_options::vposer_helpers = 0 keeps them in the
  * problems' own workgroups):
  * out3 = { launches that carried helpers, answers that did not arrive within 50 ms (expected 0: that problem decodes
  * locally from then on), helpers that gave up after 0.2 s without a request (expected 0) }.  Waits for the ctx stream. */
@@ -224,7 +264,7 @@ int mvfit_fit_trace(mvfit_ctx* ctx, float* trace, int max_closures);
  *   takes it (sdf_cuda_kernel.cu:314; the reference's own call site passes a [1,F,3] tensor, i.e. ONE triangle).
  * Stand-alone op; the loss term below evaluates the same voxel function without materialising phi.
  * Face lists of 512 faces and more are voxelised on per-call face lists (exact culling: the same bits as the walk
- * over every face for every voxel, which the environment variable MVFIT_SDF_CULL=0 keeps; the workspace, 11.6 MB per batch
+ * over every face for every voxel, which mvfit_options::sdf_face_lists = 0 keeps; the workspace, 11.6 MB per batch
  * element at 13,776 faces, is kept in the ctx between calls of one shape). */
 int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* vertices, int B,
               int num_vertices, int G, float* phi);
@@ -240,7 +280,8 @@ int mvfit_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, const float* 
  * Every problem is one person (the reference asserts batch size 1, :366): boxes, phi and the sum are per problem.
  * The term reads all vertices, so MVFIT_F_SPARSE_VERTS is ignored while it is active.
  * With 512 faces and more the sampled corners take their values from per-round face lists (same bits as the walk over
- * every face; MVFIT_SDF_CULL=0 keeps the walk; a batch whose workspace would not fit in half of the free memory keeps it too). */
+ * every face; mvfit_options::sdf_face_lists = 0 keeps the walk; a batch whose workspace would not fit in half of the free
+ * memory keeps it too - mvfit_sdf_info says which path ran). */
 int mvfit_set_sdf(mvfit_ctx* ctx, const int32_t* faces, int num_faces, int grid_size);
 
 /* Diagnostics of the last evaluated interpenetration term (after mvfit_closure with coll_loss_weight > 0):

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('MVFIT_LIBRARY') or os.path.join(_HERE, 'libmvfit.so')     # MVFIT_LIBRARY: developer A/B builds of the same library
+# MVFIT_LIBRARY (the only environment variable of the product, read by this loader, never by the library): developer builds of
+# the same library - the -DMVFIT_TIMING / -DMVFIT_DEBUG_HOOKS variants the timing tools and the fault-injection test load
+LIB_PATH = os.environ.get('MVFIT_LIBRARY') or os.path.join(_HERE, 'libmvfit.so')
 
 D = 118
 D_MODEL = 86
@@ -52,23 +54,46 @@ class LbfgsOpts(C.Structure):
                 ('num_stages', C.c_int32), ('max_rounds', C.c_int32)]
 
 
+CONTRACTION_SPLIT_FP16, CONTRACTION_EXACT_FP32, CONTRACTION_HALF_BASIS = 0, 1, 2
+
+
+class Options(C.Structure):
+    """mvfit_options (include/mvfit.h): precision and path selectors - the library reads no environment variable."""
+    _fields_ = [('struct_size', C.c_uint32), ('contraction', C.c_int32), ('dense_skinning', C.c_int32),
+                ('round_mode', C.c_int32), ('resident_pass', C.c_int32), ('sdf_two_phase', C.c_int32),
+                ('sdf_face_lists', C.c_int32), ('vposer_helpers', C.c_int32), ('vposer_sets', C.c_int32),
+                ('closure_vposer_helpers', C.c_int32), ('pass_kernel', C.c_int32)]
+
+
 EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',
            'mvfit_closure', 'mvfit_vertices', 'mvfit_full_pose', 'mvfit_fit', 'mvfit_fit_trace', 'mvfit_fit_stats', 'mvfit_decoder_stats', 'mvfit_debug_capture_pass', 'mvfit_sdf', 'mvfit_set_sdf', 'mvfit_sdf_term_read', 'mvfit_triangulate', 'mvfit_depth_guess', 'mvfit_umeyama', 'mvfit_project_points', 'mvfit_gather', 'mvfit_profile', 'mvfit_profile_read', 'mvfit_profile_vertex_pass', 'mvfit_profile_vertex_pass_ex', 'mvfit_pass_profile',
+           'mvfit_options_default', 'mvfit_create_ex', 'mvfit_set_options', 'mvfit_get_options', 'mvfit_sdf_info',
            'mvfit_lbfgs_kat']
 
 
-def load():
+def load(path=None):
     # libmvfit.so is linked against libamdhip64.so.7; PyTorch ships its own copy under the same
     # SONAME.  Exactly one HIP runtime may live in the process (tensors and kernels must share a
     # context), so torch's is loaded first and the dynamic loader binds libmvfit to it.
     import torch  # noqa: F401
-    if not os.path.isfile(LIB_PATH):
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
         raise ImportError('libmvfit.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
-                          'or `make -C mvsmplfitting_amd/csrc` (expected %s)' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          'or `make -C mvsmplfitting_amd/csrc` (expected %s)' % path)
+    lib = C.CDLL(path)
     vp = C.c_void_p
     lib.mvfit_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.POINTER(Model)]
     lib.mvfit_create.restype = C.c_int
+    lib.mvfit_options_default.argtypes = [C.POINTER(Options)]
+    lib.mvfit_options_default.restype = None
+    lib.mvfit_create_ex.argtypes = [C.POINTER(vp), C.c_int, vp, C.POINTER(Model), C.POINTER(Options)]
+    lib.mvfit_create_ex.restype = C.c_int
+    lib.mvfit_set_options.argtypes = [vp, C.POINTER(Options)]
+    lib.mvfit_set_options.restype = C.c_int
+    lib.mvfit_get_options.argtypes = [vp, C.POINTER(Options)]
+    lib.mvfit_get_options.restype = C.c_int
+    lib.mvfit_sdf_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mvfit_sdf_info.restype = C.c_int
     lib.mvfit_destroy.argtypes = [vp]
     lib.mvfit_destroy.restype = None
     lib.mvfit_last_error.argtypes = [vp]

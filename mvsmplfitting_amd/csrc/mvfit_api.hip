@@ -66,7 +66,8 @@ struct FitBuffers {
     float* rinv;         // [B][LB_RPACK] packed R^-1 of the compact direction form: the single-launch fit keeps it in LDS and parks
                          // it here only when a launch ends at its round cap
     double* stage_final; // [B][MVFIT_MAX_STAGES] run_fitting's return value per stage
-    int* n_done;         // [2]: problems finished | problems that left the asynchronous phase (finished or paused at a stage boundary)
+    int* n_done;         // [3]: problems finished | problems of the current sub-batch that left the asynchronous phase (finished or
+                         // paused at a stage boundary) | the same, all sub-batches of the fit
     VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
     const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
     int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     H.ys = L.opt.lb_ys; H.rinv = rinv; H.ld = ldh;
     __syncthreads();
     bool done = false, paused = false;
+    int stage_prev = L.sh_stage;
     for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
         // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
@@ -430,6 +432,14 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring, ring.tag != nullptr, (int)blockIdx.x);       // ring slots: sub-batch-relative problem index
         if (done) break;                                  // block-uniform
+        if (L.sh_stage != stage_prev) {
+            // a new stage starts with a fresh optimiser (non_linear_solver.py:172): its history is empty, and the branch-free
+            // phases of the compact direction read dead rows with zero coefficients - a leftover inf / NaN row of a stage that
+            // ran off would turn 0 * inf into NaN there.  Dead rows are zeros, as at the launch's start.
+            for (int i = tid; i < 2 * LB_HIST * ldh + LB_RPACK; i += STEP_NT) hist[i] = 0.f;
+            stage_prev = L.sh_stage;
+            __syncthreads();
+        }
         // two-phase fit (stages without the SDF term run here, the rest in chained rounds): leave at the stage boundary -
         // the trial point in L.opt.x is the first one of the next stage, the optimiser is fresh (non_linear_solver.py:172)
         if (L.sh_stage >= pause_stage) { paused = true; break; }
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     if (tid == 0 && (done || paused)) {
         if (done) atomicAdd(F.n_done, 1);
         const int left = atomicAdd(F.n_done + 1, 1) + 1;
+        atomicAdd(F.n_done + 2, 1);
         // the last problem tells the host (per-round pass launches: it stops queueing them)
         if (ring.tag && left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -605,7 +616,6 @@ struct mvfit_ctx {
     FitBuffers F{};
     int* h_done = nullptr;             // pinned, 2 slots
     hipEvent_t ev_done[2] = {nullptr, nullptr};
-    int ksplit = 4;
     bool has_vposer = false;
     bool has_joints3d = false;
     float *d_gt3d = nullptr, *d_c3d = nullptr;   // staging of mvfit_set_joints3d ([B][17][3], [B][17])
@@ -615,6 +625,7 @@ struct mvfit_ctx {
     hipEvent_t ev_batch[4] = {nullptr, nullptr, nullptr, nullptr}, ev_init = nullptr;
     int* h_async_done = nullptr;       // pinned host word the last finishing problem writes
     unsigned async_stats[4] = {0, 0, 0, 0};
+    mvfit_options opt{};               // precision / path selectors (include/mvfit.h); the library reads no environment variable
     int n_cu = 0;                      // compute units of the device (residency of the resident vertex pass)
     int resident_tpw = 0;              // tiles per workgroup of the resident pass in the last asynchronous fit (0: per-round launches)
     unsigned long long* d_vp_log = nullptr;     // mvfit_profile: per-round stamps of the resident pass [kVpLogRounds][grid][2]
@@ -644,6 +655,10 @@ struct mvfit_ctx {
     void* d_sdf_cull = nullptr;        // face lists of the all-faces term (sdf_term.hip), sized for (B, sdf_num_faces)
     void* d_sdf_op_ws = nullptr;       // face lists of the stand-alone op (mvfit_sdf), kept between calls of one shape
     int sdf_op_B = 0, sdf_op_F = 0;
+    // which path served the last mvfit_sdf / the SDF term of the last fit (mvfit_sdf_info): 0 walk over every face (short
+    // list or lists switched off), 1 face lists, 2 walk because the lists' workspace did not fit
+    int sdf_op_path = 0, sdf_term_path = 0;
+    bool sdf_cull_refused = false;      // the term's workspace did not fit for the current (batch, face list)
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_vp, ev_step;
@@ -684,7 +699,78 @@ static void drop_graph(mvfit_ctx* c) {
 
 extern "C" const char* mvfit_last_error(const mvfit_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// Developer hooks (fault injection, experiment switches) exist only in the -DMVFIT_DEBUG_HOOKS variant build the tests that
+// need them load (libmvfit_hooks.so); the released library has no trace of them and reads no environment variable.
+#ifdef MVFIT_DEBUG_HOOKS
+static int debug_hook(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static constexpr int debug_hook(const char*) { return 0; }
+#endif
+
+extern "C" void mvfit_options_default(mvfit_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(mvfit_options);
+    o->contraction = MVFIT_CONTRACTION_SPLIT_FP16;
+    o->resident_pass = -1;
+    o->sdf_two_phase = 1;
+    o->sdf_face_lists = 1;
+    o->vposer_helpers = 1;
+}
+
+// a caller's struct (possibly shorter: an older header) over the defaults; range checks
+static int read_options(mvfit_ctx* c, const mvfit_options* in, mvfit_options& o) {
+    mvfit_options_default(&o);
+    if (in) {
+        if (in->struct_size < 8 || in->struct_size > 4096) return fail(c, MVFIT_E_ARG, "mvfit_options: struct_size %u", in->struct_size);
+        memcpy(&o, in, std::min<size_t>(in->struct_size, sizeof(o)));
+        o.struct_size = (uint32_t)sizeof(o);
+    }
+    if (o.contraction < 0 || o.contraction > MVFIT_CONTRACTION_HALF_BASIS) return fail(c, MVFIT_E_ARG, "mvfit_options: contraction %d", o.contraction);
+    if (o.round_mode < 0 || o.round_mode > 1) return fail(c, MVFIT_E_ARG, "mvfit_options: round_mode %d", o.round_mode);
+    if (o.resident_pass < -1 || o.resident_pass > 2) return fail(c, MVFIT_E_ARG, "mvfit_options: resident_pass %d", o.resident_pass);
+    if (o.pass_kernel < 0 || o.pass_kernel > 2) return fail(c, MVFIT_E_ARG, "mvfit_options: pass_kernel %d", o.pass_kernel);
+    if (o.vposer_sets < 0) return fail(c, MVFIT_E_ARG, "mvfit_options: vposer_sets %d", o.vposer_sets);
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_create_ex(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* m, const mvfit_options* opts);
 extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* m) {
+    return mvfit_create_ex(out, device, hip_stream, m, nullptr);
+}
+
+extern "C" int mvfit_get_options(const mvfit_ctx* c, mvfit_options* o) {
+    if (!c || !o) return MVFIT_E_ARG;
+    *o = c->opt;
+    return MVFIT_OK;
+}
+
+static void drop_graph(mvfit_ctx* c);
+extern "C" int mvfit_set_options(mvfit_ctx* c, const mvfit_options* opts) {
+    if (!c || !opts) return MVFIT_E_ARG;
+    mvfit_options o;
+    const int rc = read_options(c, opts, o);
+    if (rc) return rc;
+    if (o.contraction != c->opt.contraction || o.dense_skinning != c->opt.dense_skinning)
+        return fail(c, MVFIT_E_ARG, "mvfit_set_options: contraction / dense_skinning are fixed at mvfit_create_ex");
+    if (o.pass_kernel != c->opt.pass_kernel || o.sdf_face_lists != c->opt.sdf_face_lists) {
+        HIP_OK(c, hipSetDevice(c->device));
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        drop_graph(c);                                   // the captured round graph bakes the kernel choice in
+        if (o.sdf_face_lists != c->opt.sdf_face_lists) c->sdf_cull_refused = false;
+    }
+    c->opt = o;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_sdf_info(const mvfit_ctx* c, int* op_path, int* term_path) {
+    if (!c) return MVFIT_E_ARG;
+    if (op_path) *op_path = c->sdf_op_path;
+    if (term_path) *term_path = c->sdf_term_path;
+    return MVFIT_OK;
+}
+
+extern "C" int mvfit_create_ex(mvfit_ctx** out, int device, void* hip_stream, const mvfit_model* m, const mvfit_options* opts) {
     if (!out || !m || !m->v_template || !m->shapedirs || !m->posedirs || !m->J_regressor || !m->parents ||
         !m->lbs_weights || !m->kp_regressor || !m->face_vertex_ids || !m->joint_map || m->num_verts <= 0) {
         if (out) *out = nullptr;
@@ -697,6 +783,10 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
     c->device = device;
     HIP_OK(c, hipSetDevice(device));
     c->stream = (hipStream_t)hip_stream;
+    {
+        const int rc = read_options(c, opts, c->opt);
+        if (rc) return rc;
+    }
     const int nv = m->num_verts;
     c->nv = nv;
     DevModel& M = c->M;
@@ -731,13 +821,10 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
         // the same basis as split-fp16 MFMA B operands (vertex_pass.hip: lbs_vertex_pass_split_kernel):
         // x * scale = hi + lo, scale = the power of two that brings max |x| into [2^13, 2^14)
         M.bs_h2 = nullptr; M.bs_scale = 1.f; M.half_basis = 0;
-        {   // MVFIT_HALF_BASIS=1 (BASELINE configs[4]: half-width blendshape operands): the contraction streams only the
-            // fp16 hi halves of the basis - 2 bytes per element like bf16, with 11 instead of 8 significant bits
-            const char* hb = getenv("MVFIT_HALF_BASIS");
-            M.half_basis = (hb && hb[0] == '1') ? 1 : 0;
-        }
-        const char* exact = getenv("MVFIT_EXACT_FP32");
-        if (!(exact && exact[0] == '1')) {
+        // MVFIT_CONTRACTION_HALF_BASIS (BASELINE configs[4]: half-width blendshape operands): the contraction streams only the
+        // fp16 hi halves of the basis - 2 bytes per element like bf16, with 11 instead of 8 significant bits
+        M.half_basis = c->opt.contraction == MVFIT_CONTRACTION_HALF_BASIS ? 1 : 0;
+        if (c->opt.contraction != MVFIT_CONTRACTION_EXACT_FP32) {
             float mx = 0.f;
             for (float v : bs) mx = std::max(mx, std::fabs(v));
             int ex = 0;
@@ -777,7 +864,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 wt[((size_t)(v / 32) * NJ + j) * 32 + (v % 32)] = m->lbs_weights[(size_t)v * NJ + j];
         M.wt_tiles = dev_upload(c, wt);
         // sparse skinning table when the model allows it (SMPL-family weights have <= 4 non-zeros per vertex);
-        // MVFIT_DENSE_SKINNING=1 keeps the dense blend (tests compare the two bit for bit)
+        // mvfit_options::dense_skinning keeps the dense blend (tests compare the two bit for bit)
         {
             bool sparse_ok = true;
             for (int v = 0; v < nv && sparse_ok; ++v) {
@@ -785,8 +872,7 @@ extern "C" int mvfit_create(mvfit_ctx** out, int device, void* hip_stream, const
                 for (int j = 0; j < NJ; ++j) nz += m->lbs_weights[(size_t)v * NJ + j] != 0.f;
                 sparse_ok = nz <= 4;
             }
-            const char* env = getenv("MVFIT_DENSE_SKINNING");
-            if (env && env[0] == '1') sparse_ok = false;
+            if (c->opt.dense_skinning) sparse_ok = false;
             M.wsp_w = nullptr; M.wsp_j = nullptr;
             if (sparse_ok) {
                 std::vector<float> sw((size_t)M.nv_pad * 4, 0.f);
@@ -1121,6 +1207,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     c->d_verts = nullptr;
     c->F = FitBuffers{};
     c->d_sdf_box = nullptr; c->d_sdf_samp = nullptr; c->d_sdf_entries = nullptr; c->d_sdf_adj = nullptr; c->d_sdf_cull = nullptr;
+    c->sdf_cull_refused = false;
 }
 
 extern "C" void mvfit_destroy(mvfit_ctx* c) {
@@ -1185,7 +1272,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMemset(c->F.grow, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMemset(c->F.gcol, 0, (size_t)B * LB_GSIZE * 4));
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
-        HIP_OK(c, hipMalloc(&c->F.n_done, 8));
+        HIP_OK(c, hipMalloc(&c->F.n_done, 12));
         HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
         HIP_OK(c, hipMalloc(&c->F.vp, (size_t)B * sizeof(VpBlock)));
         HIP_OK(c, hipMalloc(&c->d_gt3d, (size_t)B * NKP * 3 * 4));
@@ -1226,6 +1313,7 @@ extern "C" int mvfit_set_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, 
     drop_graph(c);
     if (c->d_sdf_faces) { hipFree(c->d_sdf_faces); c->d_sdf_faces = nullptr; }
     if (c->d_sdf_cull) { hipFree(c->d_sdf_cull); c->d_sdf_cull = nullptr; }          // sized by the face count
+    c->sdf_cull_refused = false;
     c->sdf_num_faces = 0; c->sdf_grid = 0;
     if (!faces || num_faces == 0) return MVFIT_OK;                 // term switched off
     if (num_faces < 0 || grid_size < 2 || grid_size > 1024)
@@ -1255,19 +1343,30 @@ extern "C" int mvfit_sdf_term_read(mvfit_ctx* c, float* samples, float* sums) {
 
 // work buffers of the SDF term for the current batch
 static int ensure_sdf_buffers(mvfit_ctx* c) {
-    // all faces (or any list too long for the staged walk): the per-round face lists of sdf_term.hip.  MVFIT_SDF_CULL=0
-    // keeps the brute-force kernel (the check of the culled one).
-    if (!c->d_sdf_cull && c->sdf_num_faces >= sdf_cull_min_faces()) {
-        const char* e = getenv("MVFIT_SDF_CULL");
-        // (11.6 MB of lists, records and bins per problem at 13,776 faces: a batch whose workspace would not fit keeps the walk)
+    // all faces (or any list too long for the staged walk): the per-round face lists of sdf_term.hip.
+    // mvfit_options::sdf_face_lists = 0 keeps the brute-force kernel (the check of the culled one).
+    if (c->d_sdf_cull && !c->opt.sdf_face_lists) {          // switched off since the workspace was made
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_sdf_cull);
+        c->d_sdf_cull = nullptr;
+    }
+    c->sdf_term_path = c->d_sdf_cull ? 1 : 0;
+    if (!c->d_sdf_cull && c->opt.sdf_face_lists && c->sdf_num_faces >= sdf_cull_min_faces() && !c->sdf_cull_refused) {
+        // (11.6 MB of lists, records and bins per problem at 13,776 faces: a batch whose workspace would not fit keeps the
+        // walk - decided ONCE per (batch, face list): the refusal is remembered (and reported by mvfit_sdf_info) instead of
+        // querying the free memory on every fit)
         size_t free_b = 0, total_b = 0;
         HIP_OK(c, hipMemGetInfo(&free_b, &total_b));
-        if (!(e && e[0] == '0') && sdf_cull_bytes(c->B, c->sdf_num_faces) < free_b / 2) {
+        if (sdf_cull_bytes(c->B, c->sdf_num_faces) < free_b / 2) {
             HIP_OK(c, hipMalloc(&c->d_sdf_cull, sdf_cull_bytes(c->B, c->sdf_num_faces)));
             HIP_OK(c, hipMemset(reinterpret_cast<unsigned char*>(c->d_sdf_cull) + sdf_cull_zero_offset(c->B, c->sdf_num_faces), 0,
                                 sdf_cull_zero_bytes(c->B)));
+            c->sdf_term_path = 1;
+        } else {
+            c->sdf_cull_refused = true;
+            c->sdf_term_path = 2;
         }
-    }
+    } else if (!c->d_sdf_cull && c->sdf_cull_refused) c->sdf_term_path = 2;
     if (c->d_sdf_adj) return MVFIT_OK;
     HIP_OK(c, hipMalloc(&c->d_sdf_box, (size_t)c->B * sizeof(SdfBox)));
     HIP_OK(c, hipMalloc(&c->d_sdf_samp, (size_t)c->B * c->nv * sizeof(float4)));
@@ -1313,7 +1412,7 @@ static void prof_end(mvfit_ctx* c, std::vector<std::pair<hipEvent_t, hipEvent_t>
 
 static int run_vertex_pass(mvfit_ctx* c, float* verts) {
     prof_begin(c, c->ev_vp);
-    hipError_t e = launch_vertex_pass(c->M, c->P, c->B, verts, c->ksplit, c->stream);
+    hipError_t e = launch_vertex_pass(c->M, c->P, c->B, verts, c->opt.pass_kernel, c->stream);
     prof_end(c, c->ev_vp);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
     return MVFIT_OK;
@@ -1368,10 +1467,8 @@ extern "C" int mvfit_closure(mvfit_ctx* c, const mvfit_weights* w, const float* 
     if (sdf && !c->sdf_num_faces)
         return fail(c, MVFIT_E_STATE, "coll_loss_weight > 0 needs the SDF term's faces: call mvfit_set_sdf first");
     HIP_OK(c, hipSetDevice(c->device));
-    {
-        const char* e = getenv("MVFIT_CLOSURE_VP_HELPERS");
-        if (e && atoi(e) != 0 && (w->flags & MVFIT_F_VPOSER) && c->vps_mem && !sdf) return closure_via_helpers(c, w, params, loss, grad, verts, joints);
-    }
+    if (c->opt.closure_vposer_helpers && (w->flags & MVFIT_F_VPOSER) && c->vps_mem && !sdf)
+        return closure_via_helpers(c, w, params, loss, grad, verts, joints);
     float* vbuf = verts ? verts : c->d_verts;
     // the interpenetration term reads every vertex: it forces the vertex pass
     const bool sparse = (w->flags & MVFIT_F_SPARSE_VERTS) != 0 && !sdf;
@@ -1460,7 +1557,7 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     memcpy(k, &c->P, sizeof(DevPose)); k += sizeof(DevPose);
     memcpy(k, &c->F, sizeof(FitBuffers)); k += sizeof(FitBuffers);
     memcpy(k, &c->Q, sizeof(DevProblems)); k += sizeof(DevProblems);
-    memcpy(k, &c->ksplit, sizeof(int));
+    memcpy(k, &c->opt.pass_kernel, sizeof(int));
     if (c->round_graph && key == c->graph_key) return MVFIT_OK;
     drop_graph(c);
     hipStream_t cs;
@@ -1469,7 +1566,7 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
         for (int r = 0; r < kGraphRounds && e == hipSuccess; ++r) {
-            e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->ksplit, cs);
+            e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->opt.pass_kernel, cs);
             if (e == hipSuccess && c->F.sdf_adj)
                 e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
                                     c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs, c->d_sdf_cull);
@@ -1558,23 +1655,20 @@ static int ensure_async(mvfit_ctx* c, int rb) {
 // workgroups behind the n problems' ones, every set serving the problems b with b % nsets == s.  All workgroups of the
 // launch must be resident at once (the problems wait for their helpers' answers): such fits run in sub-batches of at most
 // kVpsMaxSparse problems (objective vertices only) / kVpsMaxAsync (asynchronous: the passes keep >= 96 CUs) - every
-// problem's arithmetic is the same whatever the slicing.  MVFIT_VP_HELPERS=0 keeps the decoder in the problems' own
-// workgroups (another summation order: results differ in the last bits).
+// problem's arithmetic is the same whatever the slicing.  mvfit_options::vposer_helpers = 0 keeps the decoder in the
+// problems' own workgroups (another summation order: results differ in the last bits).
 static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
-    const char* e = getenv("MVFIT_VP_HELPERS");          // read per fit: tests switch it inside one process
-    const bool off = e && atoi(e) == 0;
-    return (SW.w[0].flags & MVFIT_F_VPOSER) && c->vps_mem && !off;
+    return (SW.w[0].flags & MVFIT_F_VPOSER) && c->vps_mem && c->opt.vposer_helpers != 0;
 }
 
 // decoder-helper sets a single-launch fit of n problems carries (0: none)
 static int persistent_nsets(const mvfit_ctx* c, const StageWeights& SW, int n) {
     if (!(vps_enabled(c, SW) && n <= kVpsMaxSparse)) return 0;
     // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
-    const char* e = getenv("MVFIT_VP_SETS");
     const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
     // at least ceil(n / VPS_PMAX) sets: a set has VPS_PMAX request / answer slots (the knob cannot push problems past them)
     const int need = (n + VPS_PMAX - 1) / VPS_PMAX;
-    return std::max(need, std::min(e ? std::max(1, std::min(atoi(e), cap)) : cap, n));
+    return std::max(need, std::min(c->opt.vposer_sets > 0 ? std::min(c->opt.vposer_sets, cap) : cap, n));
 }
 // workgroups of that launch: one per problem + the helpers behind them, one CU each (LDS)
 static int persistent_grid(const mvfit_ctx* c, const StageWeights& SW, int n) { return n + persistent_nsets(c, SW, n) * VPS_SLICES; }
@@ -1591,7 +1685,7 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         M.vps.stat = reinterpret_cast<unsigned*>(c->vps_mem + c->vps_words);
         M.vps.nsets = nsets;
         M.vps.nprob = n;
-        { const char* f = getenv("MVFIT_VP_FAULT"); M.vps.fault = f && atoi(f) != 0; }      // test hook: helpers that never answer
+        M.vps.fault = debug_hook("MVFIT_VP_FAULT") != 0;                                     // test hook (hooks build only): helpers that never answer
         grid = n + nsets * VPS_SLICES;
         c->vps_stats[0] += 1;
     }
@@ -1609,10 +1703,11 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
 // stationary in registers; its ceil(ntiles / tpw) workgroups must all be resident next to the optimiser's `opt_grid` ones,
 // every one of them a CU), or 0 = a gate + a pass launch per closure round (dense skinning rows, exact-fp32 contraction,
 // launches that do not leave the CUs - e.g. 160 optimiser + helper workgroups with the VPoser prior).
-// MVFIT_VP_RESIDENT=0 / 1 / 2 forces the choice (developer switch; a forced value that does not fit can stall the fit).
+// mvfit_options::resident_pass = 0 / 1 / 2 forces the choice (a forced value that does not fit can stall the fit: the
+// optimiser then waits 20 ms for the ring once and stops waiting; fit() reports the lost passes).
 static int resident_tiles_per_wg(const mvfit_ctx* c, int opt_grid) {
-    if (!c->M.bs_h2 || !c->M.wsp_w) return 0;
-    if (const char* e = getenv("MVFIT_VP_RESIDENT")) return std::max(0, std::min(atoi(e), 2));
+    if (!c->M.bs_h2 || !c->M.wsp_w || (c->M.nv & 1)) return 0;      // (the resident pass stores vertex pairs: even vertex count)
+    if (c->opt.resident_pass >= 0) return c->opt.resident_pass;
     const int room = c->n_cu - 4 - opt_grid;           // (4 CUs of slack: nothing in HIP promises that every CU takes a workgroup)
     if (c->M.ntiles <= room) return 1;
     if ((c->M.ntiles + 1) / 2 <= room) return 2;
@@ -1636,7 +1731,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     // polled words: re-initialised every call
     HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
-    static const bool dbg_nopass = getenv("MVFIT_DEBUG_NOPASS") != nullptr;
+    const bool dbg_nopass = debug_hook("MVFIT_DEBUG_NOPASS") != 0;          // (hooks build only)
     const int tpw = dbg_nopass ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per)));
     const int res_grid = tpw ? (c->M.ntiles + tpw - 1) / tpw : 0;
     if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
@@ -1679,8 +1774,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             RA.capture_verts = c->capture_verts; RA.capture_round = c->capture_verts ? c->capture_round : -1;
             RA.nslots = kRingSlots; RA.rb = (int)rb;
             RA.b_lo = b_lo; RA.n = b_hi - b_lo;
-            static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
-            RA.flags = dbg_nt;
+            RA.flags = (unsigned)debug_hook("MVFIT_DEBUG_NT_OFF");         // (hooks build only) bit 1 = plain vertex stores
             RA.max_rounds = (unsigned)cap;
             hipError_t e = launch_vertex_pass_resident(c->M, RA, tpw, c->pass_stream);
             if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "resident vertex pass launch: %s", hipGetErrorString(e));
@@ -1703,8 +1797,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                 P.pass_done = R.pass_done;
                 P.round = r;
                 P.chunk0 = b_lo / 32;
-                static const unsigned dbg_nt = getenv("MVFIT_DEBUG_NT_OFF") ? (unsigned)atoi(getenv("MVFIT_DEBUG_NT_OFF")) : 0u;
-                P.pad_ = dbg_nt;                  // experiment switch: bit 0 = plain basis loads, bit 1 = plain vertex stores
+                P.pad_ = (unsigned)debug_hook("MVFIT_DEBUG_NT_OFF");      // (hooks build only) bit 0 = plain basis loads, bit 1 = plain vertex stores
                 float* vout = c->d_verts;
                 if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
                 hipError_t e = launch_pass_gate(P, b_lo, b_hi, c->pass_stream);
@@ -1713,7 +1806,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                     hipEventCreate(&ea); hipEventCreate(&eb);
                     c->ev_vp.emplace_back(ea, eb);
                 }
-                if (e == hipSuccess) e = launch_vertex_pass(c->M, P, b_hi, vout, c->ksplit, c->pass_stream, ea, eb);
+                if (e == hipSuccess) e = launch_vertex_pass(c->M, P, b_hi, vout, c->opt.pass_kernel, c->pass_stream, ea, eb);
                 if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
             }
             HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
@@ -1729,6 +1822,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     // one host wait for all of it
     HIP_OK(c, hipMemcpyAsync(c->async_stats, R.stats, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipMemcpyAsync(c->h_done, c->F.n_done, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->h_done + 1, c->F.n_done + 2, 4, hipMemcpyDeviceToHost, c->stream));   // problems that left, all sub-batches
     HIP_OK(c, hipStreamSynchronize(c->stream));
     *seen_out = c->h_done[0];
     if (log_on) {
@@ -1813,9 +1907,8 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     if (rc) return rc;
     // the interpenetration term reads every vertex: it forces the (vertex pass, step) round structure
     const bool sparse = (sw[0].flags & MVFIT_F_SPARSE_VERTS) != 0 && !any_sdf;
-    // MVFIT_ROUND_MODE=serial keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
-    const char* rmode = getenv("MVFIT_ROUND_MODE");
-    const bool serial = rmode && !strcmp(rmode, "serial");
+    // mvfit_options::round_mode = 1 keeps the chained (vertex pass -> step kernel) round graph also without the SDF term
+    const bool serial = c->opt.round_mode == 1;
     const bool async = !sparse && !any_sdf && c->M.bs_h2 != nullptr && !serial;
     // With the SDF term: the leading stages whose coll_loss_weight is 0 (stages 1-2 of the yaml) do not need the vertices
     // before the loss - they run asynchronously like a fit without the term, every problem leaves at the stage boundary,
@@ -1823,12 +1916,12 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     int lead = 0;
     while (lead < o->num_stages && !(sw[lead].coll_loss_weight > 0.f)) ++lead;
     const bool two_phase = any_sdf && lead >= 1 && lead < o->num_stages && c->M.bs_h2 != nullptr && !serial &&
-                           !getenv("MVFIT_SDF_ONE_PHASE");
+                           c->opt.sdf_two_phase != 0;
     for (unsigned& v : c->async_stats) v = 0;
     for (unsigned& v : c->vps_stats) v = 0;
     if (c->vps_mem) HIP_OK(c, hipMemsetAsync(c->vps_mem + c->vps_words, 0, 8, c->stream));
     const int B = c->B;
-    HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 8, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->F.n_done, 0, 12, c->stream));
     HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
                        (const float*)params,
@@ -1842,6 +1935,15 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
         int seen = 0;
         rc = fit_async(c, SW, O, cap, &seen, lead);
         if (rc) return rc;
+        // every problem must have LEFT the single-launch kernel at the stage boundary (or finished): one that stopped at the
+        // round cap mid-history would be continued by the chained step kernel, whose two-loop direction reads Gram rows the
+        // single-launch kernel (compact direction form) does not maintain
+        if (c->h_done[1] < B) {
+            hipLaunchKernelGGL(fit_finish_kernel, dim3(B), dim3(128), 0, c->stream, c->F, params, final_loss, n_closure, n_iter, B,
+                               o->num_stages);
+            HIP_OK(c, hipGetLastError());
+            return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished the stages without the SDF term", cap);
+        }
     }
     if (async) {
         int seen = 0;
@@ -1992,10 +2094,11 @@ extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, cons
     if (!faces || !vertices || !phi || num_faces < 0 || B <= 0 || num_vertices <= 0 || G < 2 || G > 1024)
         return fail(c, MVFIT_E_ARG, "mvfit_sdf: bad argument (num_faces=%d B=%d num_vertices=%d G=%d)", num_faces, B, num_vertices, G);
     HIP_OK(c, hipSetDevice(c->device));
-    // long face lists: exact culling on face lists (sdf_term.hip), bit-identical to the walk; MVFIT_SDF_CULL=0 keeps the walk
-    const char* ev = getenv("MVFIT_SDF_CULL");
-    if (sdf_op_uses_lists(num_faces) && !(ev && ev[0] == '0')) {
-        if (!c->d_sdf_op_ws || c->sdf_op_B != B || c->sdf_op_F != num_faces) {
+    // long face lists: exact culling on face lists (sdf_term.hip), bit-identical to the walk; mvfit_options::sdf_face_lists = 0
+    // keeps the walk
+    c->sdf_op_path = 0;
+    if (sdf_op_uses_lists(num_faces) && c->opt.sdf_face_lists) {
+        if (c->sdf_op_B != B || c->sdf_op_F != num_faces) {       // a new shape: decide once (the decision, also a refusal, is kept)
             HIP_OK(c, hipStreamSynchronize(c->stream));
             if (c->d_sdf_op_ws) { hipFree(c->d_sdf_op_ws); c->d_sdf_op_ws = nullptr; }
             size_t free_b = 0, total_b = 0;
@@ -2004,14 +2107,16 @@ extern "C" int mvfit_sdf(mvfit_ctx* c, const int32_t* faces, int num_faces, cons
                 HIP_OK(c, hipMalloc(&c->d_sdf_op_ws, sdf_op_ws_bytes(B, num_faces)));
                 HIP_OK(c, hipMemsetAsync(reinterpret_cast<unsigned char*>(c->d_sdf_op_ws) + sdf_cull_zero_offset(B, num_faces), 0,
                                          sdf_cull_zero_bytes(B), c->stream));
-                c->sdf_op_B = B; c->sdf_op_F = num_faces;
             }
+            c->sdf_op_B = B; c->sdf_op_F = num_faces;
         }
         if (c->d_sdf_op_ws) {
             hipError_t e = launch_sdf_voxelize_culled(faces, num_faces, vertices, B, num_vertices, G, phi, c->d_sdf_op_ws, c->stream);
             if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
+            c->sdf_op_path = 1;
             return MVFIT_OK;
         }
+        c->sdf_op_path = 2;                                       // the workspace did not fit: the walk
     }
     hipError_t e = launch_sdf_voxelize(faces, num_faces, vertices, B, num_vertices, G, phi, c->stream);
     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "sdf launch: %s", hipGetErrorString(e));
@@ -2115,9 +2220,9 @@ static int profile_vertex_pass(mvfit_ctx* c, int launches, int flavour, double* 
     }
     hipEvent_t a, b;
     HIP_OK(c, hipEventCreate(&a)); HIP_OK(c, hipEventCreate(&b));
-    hipError_t e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->ksplit, c->stream);      // warm
+    hipError_t e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->opt.pass_kernel, c->stream);      // warm
     HIP_OK(c, hipEventRecord(a, c->stream));
-    for (int i = 0; i < launches && e == hipSuccess; ++i) e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->ksplit, c->stream);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) e = launch_vertex_pass(c->M, P, c->B, c->d_verts, c->opt.pass_kernel, c->stream);
     HIP_OK(c, hipEventRecord(b, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;

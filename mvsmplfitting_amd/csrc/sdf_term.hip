@@ -394,23 +394,26 @@ constexpr int SDF_SCAN_NT = 1024;
 constexpr int SDF_SCAN_PER = SDF_NBINS / SDF_SCAN_NT;
 static_assert(SDF_NBINS % SDF_SCAN_NT == 0 && SDF_SCAN_PER % 4 == 0, "bins per scan thread");
 __global__ __launch_bounds__(SDF_SCAN_NT) void sdf_cull_scan_kernel(int F, const int* __restrict__ gate, SdfCullWs W) {
-    __shared__ int wsum[SDF_SCAN_NT / 64];
+    // (64-bit sums: a face may be counted in up to 256 * 256 + 64^3 bins, so >= 8192 large faces - user meshes handed to
+    // mvfit_sdf - wrap 2^31; a wrapped total could pass the overflow check below and the fill kernel would write out of
+    // bounds.  The offsets themselves stay 32-bit: they are only used when the total fits SDF_CULL_CAP * F entries.)
+    __shared__ long long wsum[SDF_SCAN_NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (gate && !gate[b]) return;
     const int4* cnt = reinterpret_cast<const int4*>(W.cnt + (size_t)b * SDF_NBINS + (size_t)tid * SDF_SCAN_PER);
     int* offs = W.offs + (size_t)b * SDF_OFFS_LD + (size_t)tid * SDF_SCAN_PER;
-    int mine = 0;
+    long long mine = 0;
 #pragma unroll 8
-    for (int k = 0; k < SDF_SCAN_PER / 4; ++k) { const int4 v = cnt[k]; mine += (v.x + v.y) + (v.z + v.w); }
-    int incl = mine;                                     // inclusive scan across the wave
+    for (int k = 0; k < SDF_SCAN_PER / 4; ++k) { const int4 v = cnt[k]; mine += ((long long)v.x + v.y) + ((long long)v.z + v.w); }
+    long long incl = mine;                               // inclusive scan across the wave
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(incl, d); if (lane >= d) incl += o; }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int base = 0, total = 0;
+    long long base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SDF_SCAN_NT / 64; ++w) { const int s = wsum[w]; if (w < wave) base += s; total += s; }
-    int run = base + incl - mine;
+    for (int w = 0; w < SDF_SCAN_NT / 64; ++w) { const long long s = wsum[w]; if (w < wave) base += s; total += s; }
+    int run = (int)(base + incl - mine);
 #pragma unroll 8
     for (int k = 0; k < SDF_SCAN_PER / 4; ++k) {
         const int4 v = cnt[k];
@@ -419,8 +422,9 @@ __global__ __launch_bounds__(SDF_SCAN_NT) void sdf_cull_scan_kernel(int F, const
         *reinterpret_cast<int4*>(offs + 4 * k) = o;
     }
     if (tid == 0) {
-        W.offs[(size_t)b * SDF_OFFS_LD + SDF_NBINS] = total;
-        if ((long long)total > (long long)SDF_CULL_CAP * F) atomicOr(&W.flag[b], 2);
+        const bool over = total > (long long)SDF_CULL_CAP * F;
+        W.offs[(size_t)b * SDF_OFFS_LD + SDF_NBINS] = over ? 0 : (int)total;
+        if (over) atomicOr(&W.flag[b], 2);
     }
 }
 
@@ -728,13 +732,14 @@ static_assert(sizeof(SdfChunk) == 48, "chunk record");
 #endif
 constexpr int SDF_NS = SDF_NS_;      // workgroups (entry slices) per problem in the pull-back
 
-// Kernel 1 of the adjoint, grid (SDF_NC, B): a workgroup scans one eighth of a problem's vertices (the whole list
+// Kernel 1 of the adjoint, grid (SDF_NC, B): a workgroup scans one sixteenth (1 / SDF_NC) of a problem's vertices (the whole list
 // through one CU took 9 us): partial S and box-adjoint sums in float64, and the chunk's entries - the vertices that carry
 // gradient plus the box's arg-min / arg-max vertices - compacted in ascending order at the chunk's offset of the entry
 // buffer, with the gradient of the sampling only (the box adjoint needs the sums of ALL chunks: sdf_pullback_kernel
 // adds it when it loads an entry).
 // FUSED (face lists of at most SDF_CH faces, i.e. the term as the reference wires it): the same workgroups first reduce
-// the problem's box themselves - every chunk the whole vertex list, the same code, hence the same box in all eight - and
+// the problem's box themselves - every chunk the whole vertex list, the same code, hence the same box in all SDF_NC chunks
+// (SDF_NC redundant reductions over nv: 16 x 83 KB of L2-resident reads per problem, cheaper than a launch boundary) - and
 // sample their own vertices against the list staged in LDS: box, sample and entry kernels in one launch (three launches
 // of 6 + 10 + 5 us, mostly latency, became one).  The samples are still written for mvfit_sdf_term_read.
 template <bool FUSED>

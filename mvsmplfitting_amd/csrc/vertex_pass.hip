@@ -1220,6 +1220,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             int tid = tid_k;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63, vp2 = tid & 15, bb = tid >> 4;
+#ifdef MVFIT_TIMING
+            const long long t_ch = clock64();                  // timeline of a chunk in buffer 1 (steady state), tests/vp_resident_timeline.py
+#define VPR_T(k_) do { if (P == 1) VP_T(k_, t_ch); } while (0)
+#else
+#define VPR_T(k_) do { } while (0)
+#endif
             // (c) blendshape contraction: this wave's chains (one K half; plane, tile per chain); small products first.  The
             //     chunk's A operands are read once per block and feed the chains' independent accumulators
             // (straight-line code per chain count: a per-MFMA `if (s < nchain)` costs accumulator copies)
@@ -1254,7 +1260,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             };
             if (nchain == TPW) contract(std::integral_constant<int, TPW>{});
             else if (TPW > 1 && nchain == 1) contract(std::integral_constant<int, 1>{});
+            VPR_T(0);
             wg_barrier_lds();                                  // partials published; every chain has read the coefficients
+            VPR_T(1);
             // (d) the next live chunk's operands: transforms into the other buffer, coefficient words into the buffer just
             //     released.  (Not earlier: no request is in flight while the partials are written - the wait-count pass
             //     loses the alias information of some of those LDS stores and would wait for the requests there)
@@ -1263,6 +1271,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 request_coef(slot, (unsigned)cn, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
+            VPR_T(2);
             // (e) all waves: skinning blend (lbs.py:209-213), K halves combined in a fixed order, scale undone, T applied,
             //     "+ transl"; stores straight from registers (the last tile's: behind the closing barrier)
             const int b_me = RA.b_lo + (int)c * 32 + bb;
@@ -1329,11 +1338,18 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     for (int q = 0; q < 6; ++q) last.o[q] = cur.o[q];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) VPR_T(3);
             }
+            VPR_T(4);
             // (f) the next chunk's operands have landed (this wave's requests; the stores issued above are a tile old); the
             //     last tile's stores go out BEHIND the closing barrier: the wait never waits for fresh store acknowledgements
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VPR_T(5);
             wg_barrier_lds();
+            VPR_T(6);
+#ifdef MVFIT_TIMING
+            if (P == 1 && blockIdx.x == 5 && (tid_k & 255) == 0) g_vp[7 + (tid_k >> 8) * 8] += 1;
+#endif
             {   // (address and validity recomputed here: three registers less across the barrier)
                 int t2 = tid_k;
                 asm volatile("" : "+v"(t2));
@@ -1407,24 +1423,23 @@ static void vp_launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, hipEv
     else hipLaunchKernelGGL(kernel, grid, dim3(VP_NT), lds, stream, M, P, B, verts);
 }
 
-hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int ksplit,
+// pass_kernel (mvfit_options): kernel choice at more than 32 problems: 0 automatic, 1 one workgroup per (tile, chunk),
+// 2 lock-step chunk loop
+hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float* verts, int pass_kernel,
                               hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    (void)ksplit;
     dim3 grid(M.ntiles, (B + 31) / 32 - P.chunk0);       // chunks [P.chunk0, ceil(B / 32))
-    if (M.bs_h2) {        // split-fp16 contraction (default); MVFIT_EXACT_FP32=1 at mvfit_create keeps the fp32 MFMA chain
+    if (M.bs_h2) {        // split-fp16 contraction (default); MVFIT_CONTRACTION_EXACT_FP32 keeps the fp32 MFMA chain
         // more than one 32-problem chunk: one workgroup per vertex tile walks ALL chunks with the tile's basis held in
-        // registers - the basis is read once per launch whatever the number of problems (MVFIT_VP_CHUNK_GRID=1: one
+        // registers - the basis is read once per launch whatever the number of problems (pass_kernel 1: one
         // workgroup per (tile, chunk) as for a single chunk)
-        static const bool chunk_grid = getenv("MVFIT_VP_CHUNK_GRID") != nullptr;
-        if (grid.y == 1 || chunk_grid) {
+        if (grid.y == 1 || pass_kernel == 1) {
             if (M.wsp_w) vp_launch(lbs_vertex_pass_split_kernel<true>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
             else vp_launch(lbs_vertex_pass_split_kernel<false>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
         } else {
             const dim3 g1(M.ntiles, 1);
-            // models with <= 4 weights per vertex and an even vertex count: the two-role pipeline (MVFIT_VP_LOCKSTEP=1 keeps
+            // models with <= 4 weights per vertex and an even vertex count: the two-role pipeline (pass_kernel 2 keeps
             // the lock-step chunk loop, which also serves dense skinning rows)
-            static const bool lockstep = getenv("MVFIT_VP_LOCKSTEP") != nullptr;
-            if (M.wsp_w && (M.nv & 1) == 0 && !lockstep)
+            if (M.wsp_w && (M.nv & 1) == 0 && pass_kernel != 2)
                 vp_launch(lbs_vertex_pass_pipe_kernel, g1, vertex_pass_pipe_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
             else if (M.wsp_w) vp_launch(lbs_vertex_pass_split_loop_kernel<true>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
             else vp_launch(lbs_vertex_pass_split_loop_kernel<false>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);

@@ -50,14 +50,27 @@ def stage_weights(image_height: float, flags: int = 0, rho: float = 100.0,
     return out
 
 
+_SDF_WALK_WARNING = ('%s walked over every face (about ten times slower, same bits): the workspace of the face lists did not '
+                     'fit in half of the free device memory (is the GPU shared?)')
+
+# Options every new engine starts from (field names of include/mvfit.h:mvfit_options; empty = the library's defaults).  The
+# reference-seam mirror (fitting.py) builds its engine internally, so callers that need another default for a whole process
+# (tests, bench.py's named configs) set it here; per-engine values go to MvFit(..., options=...) / set_options().
+DEFAULT_OPTIONS: dict = {}
+CONTRACTIONS = dict(split_fp16=_lib.CONTRACTION_SPLIT_FP16, exact_fp32=_lib.CONTRACTION_EXACT_FP32,
+                    half_basis=_lib.CONTRACTION_HALF_BASIS)
+
+
 class MvFit:
-    def __init__(self, model: dict, vposer: dict | None = None, gmm=None, device: int = 0):
+    def __init__(self, model: dict, vposer: dict | None = None, gmm=None, device: int = 0, options: dict | None = None,
+                 library: str | None = None):
         """model: dict from mvsmplfitting_amd.synthetic.make_body_model (or real SMPL arrays with the
-        same keys); vposer: decoder weight dict; gmm: (means, precisions, nll_weights)."""
+        same keys); vposer: decoder weight dict; gmm: (means, precisions, nll_weights); options: mvfit_options fields
+        (``contraction`` also by name: 'split_fp16' | 'exact_fp32' | 'half_basis'); library: another build of libmvfit."""
         if not torch.cuda.is_available():
             raise MvFitError('MvFit needs a HIP device (torch.cuda.is_available() is False); '
                              'there is no CPU fallback')
-        self._lib = _lib.load()
+        self._lib = _lib.load(library)
         self.device = torch.device('cuda', device)
         self.dtype = torch.float32
         self.nv = int(model['v_template'].shape[0])
@@ -98,11 +111,50 @@ class MvFit:
         ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            rc = self._lib.mvfit_create(C.byref(ctx), device, C.c_void_p(stream), C.byref(m))
+            o = self._options_struct(dict(DEFAULT_OPTIONS, **(options or {})))
+            rc = self._lib.mvfit_create_ex(C.byref(ctx), device, C.c_void_p(stream), C.byref(m), C.byref(o))
         self._ctx = ctx
         self._check(rc)
         self.B = 0
         self.V = 0
+
+    # ------------------------------------------------------------------ options (include/mvfit.h:mvfit_options)
+    def _options_struct(self, values: dict, base=None):
+        o = _lib.Options()
+        if base is None:
+            self._lib.mvfit_options_default(C.byref(o))
+        else:
+            C.memmove(C.byref(o), C.byref(base), C.sizeof(o))
+        names = {f[0] for f in _lib.Options._fields_} - {'struct_size'}
+        for k, v in values.items():
+            if k not in names:
+                raise MvFitError('unknown option %r (mvfit_options has %s)' % (k, sorted(names)))
+            if k == 'contraction' and isinstance(v, str):
+                v = CONTRACTIONS[v]
+            setattr(o, k, int(v))
+        return o
+
+    def options(self) -> dict:
+        o = _lib.Options()
+        self._check(self._lib.mvfit_get_options(self._ctx, C.byref(o)))
+        return {f[0]: int(getattr(o, f[0])) for f in _lib.Options._fields_ if f[0] != 'struct_size'}
+
+    def set_options(self, **values):
+        """Change run-time selectors between calls (round_mode, resident_pass, sdf_two_phase, sdf_face_lists, vposer_helpers,
+        vposer_sets, closure_vposer_helpers, pass_kernel); returns the previous values of the ones changed."""
+        cur = _lib.Options()
+        self._check(self._lib.mvfit_get_options(self._ctx, C.byref(cur)))
+        old = {k: int(getattr(cur, k)) for k in values}
+        self._check(self._lib.mvfit_set_options(self._ctx, C.byref(self._options_struct(values, base=cur))))
+        return old
+
+    def sdf_info(self) -> dict:
+        """Which path served the last sdf() call / the SDF term of the last fit: 'walk', 'face_lists', or
+        'walk_workspace_did_not_fit' (include/mvfit.h:mvfit_sdf_info)."""
+        a, b = C.c_int(), C.c_int()
+        self._check(self._lib.mvfit_sdf_info(self._ctx, C.byref(a), C.byref(b)))
+        names = ('walk', 'face_lists', 'walk_workspace_did_not_fit')
+        return dict(op=names[a.value], term=names[b.value])
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -230,6 +282,9 @@ class MvFit:
             warnings.warn('vertex passes degraded in this fit: %d lost their operands before reading them, %d gave up waiting '
                           'for them (is the GPU shared, or were the pass workgroups not all resident?)'
                           % (stats['passes']['missed'], stats['passes']['timed_out']), RuntimeWarning)
+        if any(float(dict(s).get('coll_loss_weight', 0.0)) > 0.0 for s in stages) and \
+                self.sdf_info()['term'] == 'walk_workspace_did_not_fit':
+            warnings.warn(_SDF_WALK_WARNING % 'the SDF term of this fit', RuntimeWarning)
         if any(int(dict(s).get('flags', 0)) & _lib.F_VPOSER for s in stages):
             # decoder helpers (vposer_service.h): an answer that timed out makes that problem decode in its own workgroup
             # from then on - another summation order, i.e. last-bit differences from run to run.  Never silent.
@@ -282,6 +337,8 @@ class MvFit:
         phi = torch.zeros(v.shape[0], grid_size, grid_size, grid_size, device=self.device)
         self._check(self._lib.mvfit_sdf(self._ctx, f.data_ptr(), int(f.shape[0]), v.data_ptr(), int(v.shape[0]),
                                         int(v.shape[1]), int(grid_size), phi.data_ptr()))
+        if self.sdf_info()['op'] == 'walk_workspace_did_not_fit':
+            warnings.warn(_SDF_WALK_WARNING % 'this mvfit_sdf call', RuntimeWarning)
         return phi
 
     def set_sdf(self, faces, num_faces=1, grid_size=128):

@@ -37,6 +37,7 @@ def flags_for(cfg):
     return f
 
 
-def make_engine(model, vpw=None, gmm=None):
+def make_engine(model, vpw=None, gmm=None, **options):
+    """An engine; options = fields of include/mvfit.h:mvfit_options (the library reads no environment variable)."""
     from mvsmplfitting_amd.engine import MvFit
-    return MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm, np.float32))
+    return MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm, np.float32), options=options)

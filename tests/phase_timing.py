@@ -26,7 +26,7 @@ buf = (C.c_longlong*32)()
 hb = (C.c_longlong*16)()
 ab = (C.c_longlong*16)()
 for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS), ('vposer_sparse_helpers_off', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
-    os.environ['MVFIT_VP_HELPERS'] = '0' if name.endswith('off') else '1'
+    eng.set_options(vposer_helpers=0 if name.endswith('off') else 1)
     lib.mvfit_debug_timing_helpers(hb, 1)
     lib.mvfit_debug_timing_adv(ab, 1)
     lib.mvfit_debug_timing(buf, 1)

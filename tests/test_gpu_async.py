@@ -82,21 +82,18 @@ def test_async_fit_equals_objective_vertices_only_fit():
     eng.close()
 
 
-def test_chained_round_mode_still_available(monkeypatch):
-    """MVFIT_ROUND_MODE=serial: vertex pass -> step kernel per round (the structure the SDF term needs)."""
-    monkeypatch.setenv('MVFIT_ROUND_MODE', 'serial')
+def test_chained_round_mode_still_available():
+    """mvfit_options::round_mode = 1: vertex pass -> step kernel per round (the structure the SDF term needs)."""
     eng, x0 = _setup(B=4)
+    eng.set_options(round_mode=1)
     xf, st = eng.fit(x0, eng_stage_weights(1536.0, flags=0))
     assert st['passes'] == dict(run=0, skipped=0, missed=0, timed_out=0)
     assert np.all(np.isfinite(st['final_loss'].cpu().numpy()))
     eng.close()
 
 
-def _capture(eng, x0, stages, round_index, monkeypatch, resident):
-    if resident is None:
-        monkeypatch.delenv('MVFIT_VP_RESIDENT', raising=False)
-    else:
-        monkeypatch.setenv('MVFIT_VP_RESIDENT', str(resident))
+def _capture(eng, x0, stages, round_index, resident):
+    eng.set_options(resident_pass=-1 if resident is None else resident)      # -1: automatic
     cap = eng.capture_pass(round_index)
     xf, st = eng.fit(x0, stages)
     eng.capture_pass(None)
@@ -106,14 +103,14 @@ def _capture(eng, x0, stages, round_index, monkeypatch, resident):
 
 @pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 2, 9), (33, None, 1, 140),
                                                         (70, None, 2, 9), (70, None, 2, 140), (128, None, 2, 31)])
-def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index, monkeypatch):
+def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index):
     """The resident pass (one launch per fit, the tiles' basis stationary in registers, rounds served from the ring) writes
     the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup, one chunk / ragged chunks /
     four chunks, before and after the ring wrapped; and it does not perturb the optimiser either."""
     eng, x0 = _setup(B=B)
     stages = eng_stage_weights(1536.0, flags=0)
-    cap_l, x_l, ncl_l, prof_l = _capture(eng, x0, stages, round_index, monkeypatch, 0)
-    cap_r, x_r, ncl_r, prof_r = _capture(eng, x0, stages, round_index, monkeypatch, resident)
+    cap_l, x_l, ncl_l, prof_l = _capture(eng, x0, stages, round_index, 0)
+    cap_r, x_r, ncl_r, prof_r = _capture(eng, x0, stages, round_index, resident)
     assert prof_l['tiles_per_workgroup'] == 0 and prof_r['tiles_per_workgroup'] == tpw, (prof_l, prof_r)
     assert np.array_equal(x_l, x_r) and np.array_equal(ncl_l, ncl_r)
     have = round_index < ncl_r

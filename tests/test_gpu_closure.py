@@ -220,9 +220,8 @@ def test_sparse_skinning_path_is_bit_identical_to_dense(monkeypatch):
     gt = rng.uniform(300, 1700, (B, 8, 17, 2)).astype(np.float32)
     conf = np.ones((B, 8, 17), np.float32)
     outs = []
-    for dense in ('0', '1'):
-        monkeypatch.setenv('MVFIT_DENSE_SKINNING', dense)
-        eng = make_engine(model)
+    for dense in (0, 1):
+        eng = make_engine(model, dense_skinning=dense)
         eng.set_problems(cams, gt, conf)
         o = eng.closure(x, dict(stage_weights(1), flags=0), want_verts=True)
         outs.append((o['verts'].cpu().numpy(), o['loss'].cpu().numpy(), o['grad'].cpu().numpy()))
@@ -233,7 +232,7 @@ def test_sparse_skinning_path_is_bit_identical_to_dense(monkeypatch):
 
 def test_split_fp16_contraction_against_exact_fp32(monkeypatch):
     """The default vertex pass takes the blendshape contraction as error-compensated split-fp16 products on the
-    fp16 matrix pipe; MVFIT_EXACT_FP32=1 keeps the exact fp32 MFMA chain.  The two agree to fp32 rounding level
+    fp16 matrix pipe; contraction = 'exact_fp32' keeps the exact fp32 MFMA chain.  The two agree to fp32 rounding level
     on the vertices (both are ~5e-7 from the float64 oracle), far inside the 1e-4 tolerance."""
     model = body_model()
     cams = syn.make_camera_ring(8)
@@ -246,8 +245,7 @@ def test_split_fp16_contraction_against_exact_fp32(monkeypatch):
     conf = np.ones((B, 8, 17), np.float32)
     outs = {}
     for exact in ('0', '1'):
-        monkeypatch.setenv('MVFIT_EXACT_FP32', exact)
-        eng = make_engine(model)
+        eng = make_engine(model, contraction='exact_fp32' if exact == '1' else 'split_fp16')
         eng.set_problems(cams, gt, conf)
         o = eng.closure(x, dict(stage_weights(2), flags=0), want_verts=True)
         outs[exact] = (o['verts'].cpu().numpy().astype(np.float64), o['loss'].cpu().numpy().astype(np.float64))
@@ -263,7 +261,7 @@ def test_split_fp16_contraction_against_exact_fp32(monkeypatch):
 
 
 def test_half_width_basis_operands(monkeypatch):
-    """BASELINE configs[4] ("bf16 LBS with MFMA shapedirs contraction"): MVFIT_HALF_BASIS=1 streams the blendshape basis
+    """BASELINE configs[4] ("bf16 LBS with MFMA shapedirs contraction"): contraction = 'half_basis' streams the blendshape basis
     at 2 bytes per element (the fp16 hi halves of the split operands: 11 significant bits where bf16 has 8).  Relaxed,
     stated tolerance: vertices within 1e-4 of the float64 oracle (SURVEY 8(d) config 5 expected <~ 1e-4); everything
     else of the closure is unchanged (the objective's own 69 vertices do not go through the pass in the fit)."""
@@ -274,9 +272,7 @@ def test_half_width_basis_operands(monkeypatch):
     x = np.zeros((B, 118), np.float32)
     x[:, :86] = rng.normal(0, 0.3, (B, 86))
     x[:, 85] = 1.0
-    monkeypatch.setenv('MVFIT_HALF_BASIS', '1')
-    eng = make_engine(model)
-    monkeypatch.delenv('MVFIT_HALF_BASIS')
+    eng = make_engine(model, contraction='half_basis')
     ref = make_engine(model)
     cams = syn.make_camera_ring(8)
     for e in (eng, ref):

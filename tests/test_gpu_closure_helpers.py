@@ -1,5 +1,5 @@
 """GPU parity of the VPoser decoder the production fits actually use (code/model/VPoser.py:218-232): with
-MVFIT_CLOSURE_VP_HELPERS=1 mvfit_closure decodes the body pose on the helper workgroups of its own launch - the
+mvfit_options::closure_vposer_helpers = 1: mvfit_closure decodes the body pose on the helper workgroups of its own launch - the
 register-stationary decoder of the single-launch fits (csrc/vposer_service.h), whose summation order differs from the
 in-workgroup decoder - and, like those fits, evaluates the objective from the vertices it computes itself while the full
 vertex pass runs on the operands it published.  Same goldens (the reference's own float64 closure), same tolerances as
@@ -22,7 +22,8 @@ GRAD_RTOL = 2e-4
 
 @pytest.fixture
 def helper_route(monkeypatch):
-    monkeypatch.setenv('MVFIT_CLOSURE_VP_HELPERS', '1')        # read by mvfit_closure at call time
+    from mvsmplfitting_amd import engine
+    monkeypatch.setitem(engine.DEFAULT_OPTIONS, 'closure_vposer_helpers', 1)     # every engine of the test: mvfit_closure decodes on helpers
 
 
 @pytest.mark.parametrize('name', ['vp_s0_v8', 'vpwild_s2_v8'])
@@ -50,7 +51,7 @@ def test_closure_through_the_decoder_helpers_matches_reference_golden(name, help
     e_ref32 = np.abs(g['loss32'] - g['loss64']) / np.abs(g['loss64'])
     assert (np.abs(loss - g['loss64']) / np.abs(g['loss64'])).max() <= max(20 * e_ref32.max(), 2e-6)
     # and it IS another decoder than the in-workgroup one (the route is taken): same values to ~1e-6, not bit for bit
-    os.environ['MVFIT_CLOSURE_VP_HELPERS'] = '0'
+    eng.set_options(closure_vposer_helpers=0)
     loc = eng.closure(x, dict(w, flags=w['flags'] | _lib.F_SPARSE_VERTS), want_grad=True)
     l2 = loc['loss'].cpu().numpy().astype(np.float64)
     assert np.all(np.abs(l2 - loss) <= 2e-6 * np.abs(loss))

@@ -51,3 +51,20 @@ def test_gather_over_a_raw_communicator():
     with pytest.raises(MvFitError):
         eng.gather(None, x, 1)              # null communicator: MVFIT_E_ARG with a message, never a crash
     eng.close()
+
+
+@pytest.mark.timeout(600)
+def test_gather_over_a_two_rank_rccl_communicator():
+    """mvfit_gather between two GPUs over RCCL / xGMI: two processes (tests/gather_2rank_worker.py), one GPU each, a raw
+    ncclComm_t made from a shared ncclUniqueId; every rank must end with both ranks' rows.  Skipped on a one-GPU box (the
+    build sessions' and the round-end test box): it runs the day the suite sees two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL refuses two ranks on one device)')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', '29751', os.path.join(root, 'tests', 'gather_2rank_worker.py')],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0 and r.stdout.count('gather ok') == 2, r.stdout[-2000:] + r.stderr[-4000:]

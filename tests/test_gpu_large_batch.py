@@ -7,7 +7,7 @@ half-width basis at 128 problems.
     covers every 32-problem chunk, full and objective-vertices-only mode - north_star's tolerances;
   * the staged fit of the big batch is BIT-IDENTICAL to the same problems fitted 32 at a time (problems are
     independent: batch size, chunk position and the number of resident workgroups must not leak into a result);
-  * 16 views x MVFIT_HALF_BASIS: vertices within the relaxed, stated 1e-4 of the oracle (measured <= 2e-5), loss within
+  * 16 views x half-width basis (contraction = 'half_basis'): vertices within the relaxed, stated 1e-4 of the oracle (measured <= 2e-5), loss within
     1e-3 relative in full mode (the objective then reads the half-width pass's vertices) and within 1e-5 in
     objective-vertices-only mode (which does not go through the pass)."""
 import numpy as np
@@ -72,10 +72,8 @@ def test_closure_against_oracle_at_large_batches(B):
     eng.close()
 
 
-def _fit_chunks_of_32(model, cams, gt, conf, x0, stages, serial, monkeypatch):
-    if serial:
-        monkeypatch.setenv('MVFIT_ROUND_MODE', 'serial')
-    eng = make_engine(model)
+def _fit_chunks_of_32(model, cams, gt, conf, x0, stages, serial):
+    eng = make_engine(model, round_mode=1 if serial else 0)
     xs, fl, nc = [], [], []
     for lo in range(0, x0.shape[0], 32):
         hi = min(lo + 32, x0.shape[0])
@@ -83,13 +81,11 @@ def _fit_chunks_of_32(model, cams, gt, conf, x0, stages, serial, monkeypatch):
         xf, st = eng.fit(x0[lo:hi], stages)
         xs.append(xf.cpu().numpy()); fl.append(st['final_loss'].cpu().numpy()); nc.append(st['n_closure'].cpu().numpy())
     eng.close()
-    if serial:
-        monkeypatch.delenv('MVFIT_ROUND_MODE')
     return np.concatenate(xs), np.concatenate(fl), np.concatenate(nc)
 
 
 @pytest.mark.parametrize('B', [128, 161])
-def test_fit_of_a_large_batch_equals_the_fit_32_at_a_time(B, monkeypatch):
+def test_fit_of_a_large_batch_equals_the_fit_32_at_a_time(B):
     model = body_model(0, 4)
     eng = make_engine(model)
     cams, gt, conf = _inputs(eng, B, 8, seed0=5000)
@@ -102,20 +98,18 @@ def test_fit_of_a_large_batch_equals_the_fit_32_at_a_time(B, monkeypatch):
     if asynchronous:
         # every closure round of every chunk got its pass (a chunk whose 32 problems had all finished is skipped)
         assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0, st['passes']
-    xr, flr, ncr = _fit_chunks_of_32(model, cams, gt, conf, x0, stages, serial=not asynchronous, monkeypatch=monkeypatch)
+    xr, flr, ncr = _fit_chunks_of_32(model, cams, gt, conf, x0, stages, serial=not asynchronous)
     assert np.array_equal(st['n_closure'].cpu().numpy(), ncr)
     assert np.array_equal(xf.cpu().numpy(), xr)
     assert np.array_equal(st['final_loss'].cpu().numpy(), flr)
     assert np.all(np.isfinite(flr))
 
 
-def test_16_views_half_width_basis_at_128_problems(monkeypatch):
+def test_16_views_half_width_basis_at_128_problems():
     """configs[4]'s per-GPU shape: 16-view rig, 128 frames, half-width blendshape operands."""
     model = body_model(0, 4)
     orc = oracle_for(model, None, None)
-    monkeypatch.setenv('MVFIT_HALF_BASIS', '1')
-    eng = make_engine(model)
-    monkeypatch.delenv('MVFIT_HALF_BASIS')
+    eng = make_engine(model, contraction='half_basis')
     B, V = 128, 16
     cams, gt, conf = _inputs(eng, B, V, seed0=6000)
     rng = np.random.default_rng(61)

@@ -97,7 +97,7 @@ def test_sdf_matches_reference_kernel_goldens(name):
 @pytest.mark.parametrize('case', ['body', 'folded', 'edge'])
 def test_op_on_face_lists_gives_the_bits_of_the_walk(case):
     """mvfit_sdf with a long face list works on per-call face lists (sdf_term.hip: projective bins for the crossing parity,
-    rings of cells for the minimum distance); MVFIT_SDF_CULL=0 keeps the walk over every face for every voxel.  Same bits,
+    rings of cells for the minimum distance); sdf_face_lists = 0 keeps the walk over every face for every voxel.  Same bits,
     every voxel, G = 128 and all 13,776 faces: a normalised body, a body with folded limbs (self-intersections), and a mesh
     pushed against the -1 faces of the box (the lists do not cover it: its voxels walk all faces)."""
     import os
@@ -119,18 +119,16 @@ def test_op_on_face_lists_gives_the_bits_of_the_walk(case):
     faces = torch.tensor(model['faces'], device='cuda', dtype=torch.int32)
     vt = torch.tensor(vn[None], device='cuda')
     res, ms = [], []
-    for cull in ('1', '0'):
-        os.environ['MVFIT_SDF_CULL'] = cull
-        try:
-            SDF(eng)(faces, vt, grid_size=128)
-            torch.cuda.synchronize()
-            t0 = time.time()
-            phi = SDF(eng)(faces, vt, grid_size=128)
-            torch.cuda.synchronize()
-            ms.append(1e3 * (time.time() - t0))
-            res.append(phi.cpu().numpy())
-        finally:
-            os.environ.pop('MVFIT_SDF_CULL', None)
+    for cull in (1, 0):
+        eng.set_options(sdf_face_lists=cull)
+        SDF(eng)(faces, vt, grid_size=128)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        phi = SDF(eng)(faces, vt, grid_size=128)
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.time() - t0))
+        res.append(phi.cpu().numpy())
+        assert eng.sdf_info()['op'] == ('face_lists' if cull else 'walk'), eng.sdf_info()
     print('mvfit_sdf, 13,776 faces, G = 128, %s: %.2f ms on lists, %.2f ms by the walk' % (case, ms[0], ms[1]))
     assert (res[1] > 0).mean() > 0.005
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))

@@ -1,6 +1,6 @@
 """GPU: the all-faces interpenetration term on face lists (sdf_term.hip: projective bins for the crossing parity, cells for
 the minimum distance) must give the brute-force kernel's bits - the walk over every face for every corner that the
-reference performs (sdf/sdf/csrc/sdf_cuda_kernel.cu:258-287).  MVFIT_SDF_CULL=0 keeps the brute-force kernel; both
+reference performs (sdf/sdf/csrc/sdf_cuda_kernel.cu:258-287).  mvfit_options::sdf_face_lists = 0 keeps the brute-force kernel; both
 engines see the same posed bodies.  The brute-force kernel itself is pinned against the reference's kernel source in
 tests/test_gpu_sdf.py (same per-voxel code, sdf_device.h) and against the oracle in tests/test_gpu_sdf_term.py."""
 import os
@@ -16,22 +16,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _term(model, x, cams, gt, conf, num_faces, G, cull):
-    old = os.environ.get('MVFIT_SDF_CULL')
-    os.environ['MVFIT_SDF_CULL'] = '1' if cull else '0'
-    try:
-        eng = MvFit(model)
-        eng.set_problems(cams, gt, conf)
-        eng.set_sdf(model['faces'], num_faces=num_faces, grid_size=G)
-        w = dict(stage_weights(1536.0, coll_w=[0.0, 0.0, 1000.0, 4500.0])[3])
-        out = eng.closure(x, w, want_grad=True)
-        smp, S = eng.sdf_term_read()
-        res = (smp.cpu().numpy(), S.cpu().numpy(), out['loss'].cpu().numpy(), out['grad'].cpu().numpy())
-        eng.close()
-    finally:
-        if old is None:
-            os.environ.pop('MVFIT_SDF_CULL', None)
-        else:
-            os.environ['MVFIT_SDF_CULL'] = old
+    eng = MvFit(model, options=dict(sdf_face_lists=1 if cull else 0))
+    eng.set_problems(cams, gt, conf)
+    eng.set_sdf(model['faces'], num_faces=num_faces, grid_size=G)
+    w = dict(stage_weights(1536.0, coll_w=[0.0, 0.0, 1000.0, 4500.0])[3])
+    out = eng.closure(x, w, want_grad=True)
+    smp, S = eng.sdf_term_read()
+    res = (smp.cpu().numpy(), S.cpu().numpy(), out['loss'].cpu().numpy(), out['grad'].cpu().numpy())
+    eng.close()
     return res
 
 
@@ -77,26 +69,19 @@ def test_a_staged_fit_with_all_faces_is_the_same_fit_on_lists_and_by_the_walk():
     xgt = _poses(B, 4242, 0.2)
     res = []
     for cull in (True, False):
-        old = os.environ.get('MVFIT_SDF_CULL')
-        os.environ['MVFIT_SDF_CULL'] = '1' if cull else '0'
-        try:
-            eng = MvFit(model)
-            eng.set_problems(cams, np.zeros((B, V, 17, 2), np.float32), np.ones((B, V, 17), np.float32))
-            _, joints = eng.vertices(xgt)
-            gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=77)
-            eng.set_problems(cams, gt, conf)
-            eng.set_sdf(model['faces'], num_faces=None, grid_size=G)
-            x0 = np.zeros((B, 118), np.float32)
-            x0[:, 85] = 1
-            stages = stage_weights(1536.0, coll_w=[0.0, 0.0, 0.01, 0.05])       # small weights: the fit stays a fit
-            xf, st = eng.fit(x0, stages)
-            res.append((xf.cpu().numpy(), st['final_loss'].cpu().numpy(), st['n_closure'].cpu().numpy()))
-            eng.close()
-        finally:
-            if old is None:
-                os.environ.pop('MVFIT_SDF_CULL', None)
-            else:
-                os.environ['MVFIT_SDF_CULL'] = old
+        eng = MvFit(model, options=dict(sdf_face_lists=1 if cull else 0))
+        eng.set_problems(cams, np.zeros((B, V, 17, 2), np.float32), np.ones((B, V, 17), np.float32))
+        _, joints = eng.vertices(xgt)
+        gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=77)
+        eng.set_problems(cams, gt, conf)
+        eng.set_sdf(model['faces'], num_faces=None, grid_size=G)
+        x0 = np.zeros((B, 118), np.float32)
+        x0[:, 85] = 1
+        stages = stage_weights(1536.0, coll_w=[0.0, 0.0, 0.01, 0.05])       # small weights: the fit stays a fit
+        xf, st = eng.fit(x0, stages)
+        assert eng.sdf_info()['term'] == ('face_lists' if cull else 'walk'), eng.sdf_info()
+        res.append((xf.cpu().numpy(), st['final_loss'].cpu().numpy(), st['n_closure'].cpu().numpy()))
+        eng.close()
     assert np.isfinite(res[0][1]).all()
     assert np.array_equal(res[0][2], res[1][2])
     assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))

@@ -192,7 +192,7 @@ def test_fit_with_sdf_term_last_stage():
 def test_two_phase_fit_hands_over_to_the_chained_rounds(use_vp):
     """mvfit_fit with the term in the last two stages runs the leading stages as an asynchronous single-launch fit that
     pauses at the stage boundary (with VPoser: decoder helpers in that phase, the in-workgroup decoder and its
-    pre-activations handed to the chained rounds) - MVFIT_SDF_ONE_PHASE=1 runs all stages chained.  Both must end on a
+    pre-activations handed to the chained rounds) - mvfit_options::sdf_two_phase = 0 runs all stages chained.  Both must end on a
     finite loss that IS the objective at the returned parameters; the two structures differ in the arithmetic of the
     leading stages (objective vertices evaluated in the optimiser kernel vs read from the vertex pass: 2e-6), so the end
     points agree only as far as the piecewise-smooth objective lets two roundings agree (cf. the test above)."""
@@ -209,13 +209,9 @@ def test_two_phase_fit_hands_over_to_the_chained_rounds(use_vp):
         stages[s_]['coll_loss_weight'] = cw
     out = {}
     for mode in ('two_phase', 'one_phase'):
-        if mode == 'one_phase':
-            os.environ['MVFIT_SDF_ONE_PHASE'] = '1'
-        try:
-            xf, st = eng.fit(x0, stages)
-            ds = eng.decoder_stats()
-        finally:
-            os.environ.pop('MVFIT_SDF_ONE_PHASE', None)
+        eng.set_options(sdf_two_phase=0 if mode == 'one_phase' else 1)
+        xf, st = eng.fit(x0, stages)
+        ds = eng.decoder_stats()
         fk = st['final_loss'].cpu().numpy().astype(np.float64)
         chk = eng.closure(xf, dict(stages[-1]), want_grad=False)['loss'].cpu().numpy()
         assert np.all(np.isfinite(fk)) and np.all(chk <= fk * (1 + 1e-3) + 1e-3), (mode, fk, chk)

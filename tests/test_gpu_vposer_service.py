@@ -33,22 +33,15 @@ def _problems(eng, B, views=8, seed=5):
 
 
 def _fit(eng, x0, flags, helpers, trace=0):
-    old = os.environ.get('MVFIT_VP_HELPERS')
-    os.environ['MVFIT_VP_HELPERS'] = '1' if helpers else '0'
-    try:
-        tr = eng.fit_trace(trace) if trace else None
-        xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
-        ds = eng.decoder_stats()
-        out = dict(x=xf.cpu().numpy(), final=st['final_loss'].cpu().numpy(), ncl=st['n_closure'].cpu().numpy(), stats=ds,
-                   passes=st['passes'], trace=None if tr is None else tr.cpu().numpy().astype(np.float64))
-        if trace:
-            eng.fit_trace(0)
-        return out
-    finally:
-        if old is None:
-            del os.environ['MVFIT_VP_HELPERS']
-        else:
-            os.environ['MVFIT_VP_HELPERS'] = old
+    eng.set_options(vposer_helpers=1 if helpers else 0)
+    tr = eng.fit_trace(trace) if trace else None
+    xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
+    ds = eng.decoder_stats()
+    out = dict(x=xf.cpu().numpy(), final=st['final_loss'].cpu().numpy(), ncl=st['n_closure'].cpu().numpy(), stats=ds,
+               passes=st['passes'], trace=None if tr is None else tr.cpu().numpy().astype(np.float64))
+    if trace:
+        eng.fit_trace(0)
+    return out
 
 
 @pytest.mark.parametrize('sparse', [True, False])
@@ -110,10 +103,14 @@ def test_helpers_serving_many_problems_each(B, sparse, launches):
 
 
 def test_a_fit_whose_helpers_never_answer_falls_back_to_the_local_decoder():
-    """Fault injection (MVFIT_VP_FAULT=1: the helper workgroups leave at once): every problem's first request times out
-    (50 ms), the problem decodes in its own workgroup from then on - the fit completes, the counters say what happened,
-    and the result is the helpers-off fit bit for bit."""
-    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    """Fault injection (the -DMVFIT_DEBUG_HOOKS build, MVFIT_VP_FAULT=1: the helper workgroups leave at once): every
+    problem's first request times out (50 ms), the problem decodes in its own workgroup from then on - the fit completes,
+    the counters say what happened, and the result is the helpers-off fit bit for bit.  The released library has no such
+    hook (and reads no environment variable): the test loads the hooks build."""
+    hooks = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mvsmplfitting_amd', 'libmvfit_hooks.so')
+    if not os.path.isfile(hooks):
+        pytest.skip('libmvfit_hooks.so not built (make -C mvsmplfitting_amd/csrc hooks)')
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder(), library=hooks)
     B = 5
     x0 = _problems(eng, B)[0]
     flags = _lib.F_VPOSER | _lib.F_SPARSE_VERTS

@@ -15,7 +15,7 @@ timeout 300 python bench.py --prior vposer $NOX > $OUT/bench_vposer.json.log 2>>
 timeout 300 python bench.py --prior vposer --sparse $NOX > $OUT/bench_vposer_sparse.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --prior gmm $NOX > $OUT/bench_gmm.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --config configs3 --prior vposer $NOX > $OUT/bench_configs3_vposer.json.log 2>> $OUT/bench.err
-MVFIT_ROUND_MODE=serial timeout 300 python bench.py $NOX > $OUT/bench_chained.json.log 2>> $OUT/bench.err
+timeout 300 python bench.py $NOX --round-mode chained > $OUT/bench_chained.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --gpus 2 --dist-backend gloo --single-device $NOX > $OUT/bench_2rank_gloo_single_device.json.log 2>> $OUT/bench.err
 timeout 600 python bench.py --config configs2 --sdf-faces all --steps 3 $NOX > $OUT/bench_sdf_all_faces.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --config demo $NOX > $OUT/bench_demo.json.log 2>> $OUT/bench.err
