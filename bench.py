@@ -592,6 +592,7 @@ def main():
                     help='chained: vertex pass -> step kernel per closure round also without the SDF term (mvfit_options::round_mode)')
     ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2],
                     help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 resident (mvfit_options)')
+    ap.add_argument('--vposer-sets', type=int, default=0, help='decoder-helper sets of a VPoser fit (0 automatic; mvfit_options::vposer_sets)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline / prior variants')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 PMC passes (traffic then comes from profiles/*_pmc.json)')
@@ -665,7 +666,7 @@ def main():
         B = persons * (hi - lo)
         total = persons * total_frames
     eng_options = dict(contraction='half_basis' if half_basis else args.contraction, round_mode=1 if args.round_mode == 'chained' else 0,
-                       resident_pass=args.resident_pass)
+                       resident_pass=args.resident_pass, vposer_sets=args.vposer_sets)
     eng = MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank, options=eng_options)
     flags = 0
     if args.prior == 'vposer':

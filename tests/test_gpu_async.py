@@ -142,3 +142,24 @@ def test_resident_pass_profile_and_alone_timing():
     assert np.array_equal(xf.cpu().numpy(), xf2.cpu().numpy())
     assert st2['passes']['missed'] == 0 and st2['passes']['timed_out'] == 0
     eng.close()
+
+
+def test_compact_and_two_loop_direction_forms_end_on_the_same_fits():
+    """The single-launch fit takes the L-BFGS direction in compact (Byrd-Nocedal-Schnabel) form with an explicitly maintained
+    float32 R^-1, the chained step kernel in two-loop form over its Gram matrices: two associations of the same direction
+    (lbfgs_ls.py:336-358).  Whole staged fits of the same problems must end on the same optima to the precision two float32
+    roundings of a 300-closure trajectory allow (a poorly conditioned R^-1 would show as a worse fit or an early stop)."""
+    eng, x0 = _setup(B=16)
+    stages = eng_stage_weights(1536.0, flags=0)
+    xa, sa = eng.fit(x0, stages)
+    eng.set_options(round_mode=1)
+    xc, sc = eng.fit(x0, stages)
+    eng.set_options(round_mode=0)
+    fa, fc = sa['final_loss'].cpu().numpy().astype(np.float64), sc['final_loss'].cpu().numpy().astype(np.float64)
+    na, nc = sa['n_closure'].cpu().numpy(), sc['n_closure'].cpu().numpy()
+    rel = np.abs(fa - fc) / np.abs(fc)
+    print('compact vs two-loop: final loss rel diff median %.1e max %.1e; closures %d vs %d' % (np.median(rel), rel.max(), na.sum(), nc.sum()))
+    assert np.isfinite(fa).all() and np.isfinite(fc).all()
+    assert np.median(rel) <= 2e-3 and rel.max() <= 5e-2, rel
+    assert 0.7 * nc.sum() <= na.sum() <= 1.3 * nc.sum(), (na, nc)
+    eng.close()
