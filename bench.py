@@ -746,12 +746,12 @@ def main():
         dist.all_gather(bz, torch.tensor([busy / args.steps * 1e3], device=dev, dtype=torch.float64))
         busy_all = [round(float(b.item()), 3) for b in bz]
         assert gathered.shape[0] == total_frames
+        tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
+        lost = [int(red[2].item()), int(red[3].item())]
     if args.dump_gathered and rank == 0:
         # [frames_total, persons, 118] (the gather's layout: contiguous frame blocks per rank) -> [persons, frames_total, 118]
         full = gathered if world > 1 else xf.reshape(persons, B // persons, -1).transpose(0, 1)
         np.save(args.dump_gathered, full.transpose(0, 1).contiguous().cpu().numpy())
-        tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
-        lost = [int(red[2].item()), int(red[3].item())]
 
     # roofline of the dominant HBM kernel (LBS vertex pass), measured live with HIP events on the stream the kernel is
     # launched on

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE - how far the REFERENCE's own float32 fit of the demo frame (BASELINE configs[0]) moves when the start is
 perturbed in the last bits: its staged fit (create_fitting_closure + LBFGSLs + run_fitting in the stage loop of
 non_linear_solver.py:156-211, cfg_files/fit_smpl.yaml:40-68) from 48 starts = the reference's initial guess and 47 copies
-perturbed by 1e-6 (relative), the generator of tests/test_gpu_demo.py::test_demo_fit_spread_against_the_reference's (seed 0,
+perturbed by 1e-6 (relative), the generator of tests/test_gpu_demo.py::test_demo_fit_spread_against_the_reference_spread (seed 0,
 drawn in the C ABI's 118-parameter layout so that the device fits the SAME 48 starts).
 
     python -m oracle.make_golden_demo_spread [n]       (build container; ~6 s per fit)

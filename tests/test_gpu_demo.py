@@ -66,9 +66,11 @@ def test_demo_four_stage_fit(sparse):
     g, vpw, model, cams, stages = _load()
     eng = make_engine(model, vpw)
     # five fits in one batch: the reference's start and four starts perturbed by 1e-6 (relative), as the reference's own
-    # spread was recorded.  48 such starts (tests/report_demo_spread.py) land in the reference's band except for ~4 % that end
-    # at ~44.4 k - with this library and with round 3's alike -, so the yard-stick is applied to the MEDIAN of the five and
-    # every single fit must still be a fit (<= 1.25 x).
+    # spread was recorded.  The reference's OWN float32 fits from 48 such starts (tests/golden/demo_spread48.npz, written by
+    # oracle/make_golden_demo_spread.py) land in 34.2 k ... 39.9 k except for 2 of 48 that end at 44.4 k - the same second
+    # optimum, at the same rate (~4 %), that the device fits show (test_demo_fit_spread_against_the_reference_spread below holds
+    # the two distributions against each other).  Here: the MEDIAN of the five inside the six-start band, and no single fit
+    # worse than the worst the reference itself reaches over its 48 starts.
     NB = 5
     eng.set_problems(cams, np.repeat(g['gt_xy'][None], NB, 0), np.repeat(g['conf'][None], NB, 0))
     x0 = np.repeat(to118(g['x0'], True)[None], NB, 0)
@@ -82,8 +84,38 @@ def test_demo_four_stage_fit(sparse):
     final, ncl = float(np.median(finals)), int(np.median(ncls))
     ref_hi = max(float(g['fit_final32']), float(g['fit_final64']), float(g['fit_spread32'].max()))
     ref_n = [int(g['fit_ncl32'].sum()), int(g['fit_ncl64'].sum())] + [int(n) for n in g['fit_spread_ncl32'].sum(1)]
-    assert np.isfinite(finals).all() and final <= 1.02 * ref_hi and finals.max() <= 1.25 * ref_hi, (finals, ref_hi)
+    ref_worst48 = float(np.load(os.path.join(GOLD, 'demo_spread48.npz'))['final32'].max())
+    assert np.isfinite(finals).all() and final <= 1.02 * ref_hi and finals.max() <= 1.02 * ref_worst48, (finals, ref_hi, ref_worst48)
     assert 0.5 * min(ref_n) <= ncl <= 2.0 * max(ref_n), (ncls, ref_n)
     chk = eng.closure(xf, dict(st_w[-1]), want_grad=False)['loss'].cpu().numpy().astype(np.float64)
     assert (chk <= finals * (1 + 1e-3)).all()
+    eng.close()
+
+
+@pytest.mark.parametrize('sparse', [False, True])
+def test_demo_fit_spread_against_the_reference_spread(sparse):
+    """The SAME 48 starts (the reference's initial guess + 47 copies perturbed by 1e-6, relative) fitted by the reference itself
+    in float32 (tests/golden/demo_spread48.npz: 46 fits in 34.2 k ... 39.9 k, 2 at 44.4 k) and by the device in one batch.
+    Which optimum a start reaches is chaotic in the last bits, so the two are compared as distributions: the device's share of
+    fits outside the main band must not exceed the reference's by more than 3 of 48, its median and its worst fit must not be
+    worse than the reference's (2 %), and the effort must be comparable."""
+    g, vpw, model, cams, stages = _load()
+    sp = np.load(os.path.join(GOLD, 'demo_spread48.npz'))
+    x0, ref = sp['x0'].astype(np.float32), sp['final32']
+    n = x0.shape[0]
+    eng = make_engine(model, vpw)
+    eng.set_problems(cams, np.repeat(g['gt_xy'][None], n, 0), np.repeat(g['conf'][None], n, 0))
+    st_w = [dict(s, flags=s['flags'] | (_lib.F_SPARSE_VERTS if sparse else 0)) for s in stages]
+    xf, st = eng.fit(x0, st_w)
+    dev = st['final_loss'].cpu().numpy().astype(np.float64)
+    ncl = st['n_closure'].cpu().numpy()
+    band = 1.1 * float(np.median(ref))                       # 40.9 k: between the main band and the second optimum
+    out_ref, out_dev = int((ref > band).sum()), int((dev > band).sum())
+    print('demo, %d starts: reference float32 median %.0f max %.0f, %d outside the band; device median %.0f max %.0f, %d outside; '
+          'closures reference %d (median), device %d' % (n, np.median(ref), ref.max(), out_ref, np.median(dev), dev.max(), out_dev,
+                                                       int(np.median(sp['ncl32'].sum(1))), int(np.median(ncl))))
+    assert np.isfinite(dev).all()
+    assert out_dev <= out_ref + 3, (np.sort(dev), np.sort(ref))
+    assert np.median(dev) <= 1.02 * np.median(ref) and dev.max() <= 1.02 * ref.max(), (np.sort(dev), np.sort(ref))
+    assert 0.5 * np.median(sp['ncl32'].sum(1)) <= np.median(ncl) <= 2.0 * np.median(sp['ncl32'].sum(1))
     eng.close()
