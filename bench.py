@@ -667,6 +667,12 @@ def main():
         total = persons * total_frames
     eng_options = dict(contraction='half_basis' if half_basis else args.contraction, round_mode=1 if args.round_mode == 'chained' else 0,
                        resident_pass=args.resident_pass, vposer_sets=args.vposer_sets)
+    if args.single_device and world > 1 and args.resident_pass == -1:
+        # the dry run of the N-rank path puts N processes on ONE GPU: the resident pass assumes that a fit's workgroups (the
+        # optimiser's + the pass's, ~250 CUs) are resident together, which several processes sharing the device cannot all have
+        # (they would wait for one another's CUs until the ring's 20 ms patience ends; include/mvfit.h: resident_pass) - the dry
+        # run uses the per-round pass launches; one process per GPU, the deployment, keeps the automatic choice
+        eng_options['resident_pass'] = 0
     eng = MvFit(model, vposer=vpw, gmm=None if gmm is None else syn.gmm_constants(gmm), device=local_rank, options=eng_options)
     flags = 0
     if args.prior == 'vposer':

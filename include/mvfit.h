@@ -147,7 +147,12 @@ typedef struct mvfit_options {
                                       * 1: chained rounds always (vertex pass -> step kernel per closure round) */
     int32_t resident_pass;           /* vertex passes of the asynchronous fit: -1 automatic (resident when its workgroups fit
                                       * next to the optimiser's), 0 a gate + a pass launch per closure round, 1 / 2 resident with
-                                      * that many vertex tiles per workgroup (a forced value that does not fit stalls the fit) */
+                                      * that many vertex tiles per workgroup (a forced value that does not fit stalls the fit).
+                                      * The resident pass assumes what the path's deployment gives it - one process per GPU
+                                      * (SURVEY 8(e)): a fit's ~250 workgroups are resident together.  Processes (or concurrent
+                                      * ctxs) that SHARE a device should set 0: waiting for one another's CUs they would exhaust
+                                      * the ring's patience (20 ms) and lose passes - counted by mvfit_fit_stats, never silent,
+                                      * and without effect on the fitted parameters */
     int32_t sdf_two_phase;           /* 1 (default): a fit with the SDF term runs its leading coll_loss_weight == 0 stages
                                       * asynchronously and hands over to chained rounds; 0: chained rounds in every stage */
     int32_t sdf_face_lists;          /* 1 (default): long face lists are culled exactly on per-round face lists (bit-identical
