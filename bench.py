@@ -227,7 +227,7 @@ def mfma_util(busy_cycles, launch_us):
     return None if busy_cycles is None else round(busy_cycles / (launch_us * 1e-6 * 2.4e9 * 1024), 4)
 
 
-def build_inputs(eng, syn, frame_lo, frame_hi, persons, views, seed_base=1000):
+def build_inputs(eng, syn, frame_lo, frame_hi, persons, views, seed_base=1000, per_frame_noise=False):
     """Synthetic inputs of this rank: for every person (own fixed shape) the frames [frame_lo, frame_hi) - GT parameter
     draws (seeded by person and GLOBAL frame index) -> keypoints (by the GPU forward) -> noisy 2-D observations +
     confidences; initial parameters = zeros, scale 1.  Problem order: person-major."""
@@ -242,7 +242,17 @@ def build_inputs(eng, syn, frame_lo, frame_hi, persons, views, seed_base=1000):
             xgt[p * nf:(p + 1) * nf, a:b] = fr[k]
     eng.set_problems(cams, np.zeros((B, views, 17, 2), np.float32), np.ones((B, views, 17), np.float32))
     _, joints = eng.vertices(xgt)
-    gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=seed_base + frame_lo + 7)
+    if per_frame_noise:
+        # strong scaling splits ONE fixed problem set over the ranks: the observation noise is drawn per (person, GLOBAL frame),
+        # so that a frame's problem does not depend on which rank's shard it falls into (tests/test_gpu_bench_8rank.py compares
+        # the 8-rank result with the 1-rank result bit for bit).  The weak-scaling workloads keep the per-shard draw of the
+        # earlier rounds (rank 0's frames 0..31 are the same problems at every N).
+        jn = joints.cpu().numpy()
+        parts = [syn.make_observations(jn[p * nf + f:p * nf + f + 1], cams, seed=seed_base + 7 + 100000 * p + frame_lo + f)
+                 for p in range(persons) for f in range(nf)]
+        gt, conf = np.concatenate([a for a, _ in parts]), np.concatenate([b for _, b in parts])
+    else:
+        gt, conf = syn.make_observations(joints.cpu().numpy(), cams, seed=seed_base + frame_lo + 7)
     eng.set_problems(cams, gt, conf)
     x0 = np.zeros((B, 118), np.float32)
     x0[:, 85] = 1.0
@@ -687,7 +697,7 @@ def main():
     if demo:
         eng.set_problems(cams, gt, conf)
     else:
-        cams, gt, conf, x0 = build_inputs(eng, syn, lo, hi, persons, views)
+        cams, gt, conf, x0 = build_inputs(eng, syn, lo, hi, persons, views, per_frame_noise=args.strong)
     x0_d = torch.tensor(x0, device=dev)
 
     def barrier():
