@@ -117,9 +117,10 @@ def measure_pmc(B, launches=40, timeout_s=90):
 
 
 def measure_pmc_resident(B, timeout_s=120):
-    """The same three PMC passes on the RESIDENT pass (tools/pmc_vertex_pass.py drive_resident): one fit's resident launch +
-    three stand-alone resident launches; every dispatch of the kernel summed and divided by the closure rounds they served.
-    Returns dict(traffic_bytes_per_round, mfma_busy_cycles_per_round, rounds_served, dispatches) or None."""
+    """The same three PMC passes on the RESIDENT pass (tools/pmc_vertex_pass.py drive_resident): after one fit has filled the
+    ring, three stand-alone resident launches serve 100 rounds each; their counters (the fit's own resident dispatch is left
+    out: rocprofv3 serialises kernels while collecting, so it cannot run beside its optimiser kernel) are summed and divided
+    by the rounds served.  Returns dict(traffic_bytes_per_round, mfma_busy_cycles_per_round, rounds_served, dispatches) or None."""
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
     if exe is None:
         return None
@@ -129,7 +130,7 @@ def measure_pmc_resident(B, timeout_s=120):
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     tot = {}
-    side = None
+    used = rounds = 0
     try:
         for cn in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_VALU_MFMA_BUSY_CYCLES'):
             d = os.path.join(out, cn)
@@ -141,17 +142,14 @@ def measure_pmc_resident(B, timeout_s=120):
                 return None
             with open(sf) as f:
                 side = json.load(f)
-            if not side['rounds_served']:
+            if not side.get('standalone_dispatches'):
                 return None
-            t = pv.parse(None, ['x=%s' % d]).get('x', {})
-            e = next((v for k, v in t.items() if 'resident' in k), None)
-            if e is None:
+            rounds = side['rounds_per_standalone_dispatch']
+            tot[cn], used = pv.resident_per_round(d, cn, rounds)
+            if tot[cn] is None:
                 return None
-            key = cn + ('_KiB_avg' if cn != 'SQ_VALU_MFMA_BUSY_CYCLES' else '_avg')
-            tot[cn] = e[key] * e['launches_' + cn] / side['rounds_served']
         return dict(traffic_bytes_per_round=round((2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0),
-                    mfma_busy_cycles_per_round=tot['SQ_VALU_MFMA_BUSY_CYCLES'], rounds_served=side['rounds_served'],
-                    dispatches=side['dispatches'])
+                    mfma_busy_cycles_per_round=tot['SQ_VALU_MFMA_BUSY_CYCLES'], rounds_served=used * rounds, dispatches=used)
     except Exception:
         return None
     finally:
@@ -209,8 +207,10 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
                 traffic=None if table is None else table['traffic_bytes_per_round'],
                 traffic_source=None if table is None else
                 ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes collected in this run on %d '
-                 'dispatches of the resident kernel serving %d closure rounds (2 x FETCH_SIZE + WRITE_SIZE, per round; includes '
-                 'the basis once per dispatch)' % (table['dispatches'], table['rounds_served'])),
+                 'stand-alone dispatches of the resident kernel serving %d closure rounds from the ring (2 x FETCH_SIZE + WRITE_SIZE, '
+                 'per round; the basis once per dispatch = 1 %% of it; FETCH_SIZE counts what the L2s request from the fabric - '
+                 'every workgroup reads the round\'s 66 KB of operands itself, mostly from the Infinity Cache)'
+                 % (table['dispatches'], table['rounds_served'])),
                 mfma_util=None if table is None else mfma_util(table['mfma_busy_cycles_per_round'], span_ms * 1e3),
                 mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per round / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',
                 timed_region='every closure round of one complete fit, stamped inside the resident kernel (s_memrealtime) on the pass '

@@ -46,9 +46,11 @@ def _setting_and_data(model, cams, vpw, gt, cf, use_vposer, dtype):
     return rp, setting, data
 
 
-def _run(nls, prob, use_vposer, optim_type, dtype, n_stages=4, warm_start=None):
+def _run(nls, prob, use_vposer, optim_type, dtype, n_stages=4, warm_start=None, start=None):
     rp, setting, data = _setting_and_data(*prob, use_vposer, dtype)
     kw = dict(YAML_KW, use_vposer=use_vposer, optim_type=optim_type, float_dtype=dtype)
+    if start is not None:                 # another start point of the same (first-frame) fit
+        rp.set_flat(start)
     if warm_start is not None:            # a later frame of a sequence (main.py:76-79: load_init, seq_start False)
         rp.set_flat(warm_start)
         setting['seq_start'] = False

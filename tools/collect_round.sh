@@ -2,7 +2,7 @@
 # Run on the MI355X box (gpurun): the bench lines of a round.  Usage: bash tools/collect_round.sh <tag> [quick]
 #   -> gpurun_out/<tag>/bench_*.json.log (copy what is to be judged into profiles/<tag>_*)
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -21,6 +21,7 @@ timeout 600 python bench.py --config configs2 --sdf-faces all --steps 3 $NOX > $
 timeout 300 python bench.py --config demo $NOX > $OUT/bench_demo.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --config configs3 --no-cpu-baseline --no-variants > $OUT/bench_configs3.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --config configs4 --no-cpu-baseline --no-variants > $OUT/bench_configs4.json.log 2>> $OUT/bench.err
+timeout 300 python bench.py --resident-pass 0 $NOX > $OUT/bench_per_round_launches.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --frames 128 $NOX > $OUT/bench_b128.json.log 2>> $OUT/bench.err
 timeout 300 python bench.py --frames 256 $NOX > $OUT/bench_b256.json.log 2>> $OUT/bench.err
 timeout 600 python bench.py --config configs2 --no-pmc --no-cpu-baseline > $OUT/bench_sdf.json.log 2>> $OUT/bench.err

@@ -64,8 +64,27 @@ def drive_resident(B, side_file, reps=3, rounds=100):
             dispatches += 1
     torch.cuda.synchronize()
     with open(side_file, 'w') as f:
-        json.dump(dict(rounds_served=served, dispatches=dispatches, tiles_per_workgroup=pp['tiles_per_workgroup'], problems=B), f)
+        json.dump(dict(rounds_served=served, dispatches=dispatches, tiles_per_workgroup=pp['tiles_per_workgroup'], problems=B,
+                       standalone_dispatches=reps if pp['tiles_per_workgroup'] else 0, rounds_per_standalone_dispatch=rounds), f)
     eng.close()
+
+
+def resident_per_round(d, counter, rounds_per_dispatch):
+    """Per-round value of `counter` over the STAND-ALONE dispatches of the resident pass in a drive_resident run: the rows of
+    lbs_vertex_pass_resident_kernel in dispatch order, the first one dropped (the fit's own dispatch: rocprofv3 serialises
+    kernels while it collects counters, so that dispatch cannot run beside its optimiser kernel and serves nothing useful),
+    summed over the agents / dimensions rocprofv3 splits a counter into, divided by the rounds the stand-alone dispatches
+    served.  -> (value per round, dispatches used) or (None, 0)."""
+    per = {}
+    for fn in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                if 'vertex_pass_resident' in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                    per[int(row['Dispatch_Id'])] = per.get(int(row['Dispatch_Id']), 0.0) + float(row['Counter_Value'])
+    ids = sorted(per)[1:]
+    if not ids:
+        return None, 0
+    return sum(per[i] for i in ids) / (len(ids) * rounds_per_dispatch), len(ids)
 
 
 def parse(out_json, specs):
