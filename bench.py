@@ -208,8 +208,10 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
                 traffic_source=None if table is None else
                 ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes collected in this run on %d '
                  'stand-alone dispatches of the resident kernel serving %d closure rounds from the ring (2 x FETCH_SIZE + WRITE_SIZE, '
-                 'per round; the basis once per dispatch = 1 %% of it; FETCH_SIZE counts what the L2s request from the fabric - '
-                 'every workgroup reads the round\'s 66 KB of operands itself, mostly from the Infinity Cache)'
+                 'per round; the basis once per dispatch.  It is what reached the fabric, far below the bytes the kernel moves: the '
+                 'round\'s 66 KB of operands are requested from the fabric once per XCD and served to the other 26 workgroups of that '
+                 'XCD by its L2, and the vertices of consecutive rounds overwrite the same 2.6 MB buffer, whose lines the write-back '
+                 'L2s merge before they leave - the pass has no streaming traffic left, it is latency-bound)'
                  % (table['dispatches'], table['rounds_served'])),
                 mfma_util=None if table is None else mfma_util(table['mfma_busy_cycles_per_round'], span_ms * 1e3),
                 mfma_util_note='SQ_VALU_MFMA_BUSY_CYCLES per round / (avg_launch_us x 2.4 GHz x 1024 SIMDs)',

@@ -1237,14 +1237,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[s][q] = vt_l[s * VP_NT + tid];
                 const int cl = (kh_w * VP_BPW * 2) * 64 + lane;
-                // (two chains: the A operands of block g + 1 are read while block g's MFMAs issue - two blocks' operands in
-                // flight, not all seven: registers)
-                f32x4 ah = coef_l[cl], al = coef_l[cl + 64];
 #pragma unroll
                 for (int g = 0; g < VP_BPW; ++g) {
-                    const half8 Ah = __builtin_bit_cast(half8, ah), Al = __builtin_bit_cast(half8, al);
-                    if (g + 1 < VP_BPW) { ah = coef_l[cl + (2 * g + 2) * 64]; al = coef_l[cl + (2 * g + 3) * 64]; }
-                    if (NC > 1) __builtin_amdgcn_sched_barrier(0);
+                    const half8 Ah = __builtin_bit_cast(half8, coef_l[cl + (2 * g) * 64]), Al = __builtin_bit_cast(half8, coef_l[cl + (2 * g + 1) * 64]);
 #pragma unroll
                     for (int s = 0; s < NC; ++s) {
                         const half8 Bh = __builtin_bit_cast(half8, bh[s][g]);
@@ -1252,6 +1247,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                         if (!HALF) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bl[HALF ? 0 : s][HALF ? 0 : g]), acc[s], 0, 0, 0);
                         acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[s], 0, 0, 0);
                     }
+                    // one block's operands in flight at a time (registers; reading block g + 1 under block g's MFMAs was
+                    // measured: no gain - the one-chain waves of the same SIMDs set the phase's length)
                     if (NC > 1) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
