@@ -163,12 +163,19 @@ def test_unmodified_caller_drives_libmvfit(seams, monkeypatch, use_vposer, n_sta
     # (2) opt-in device-resident optimiser: whole stages inside mvfit_fit
     res_hip, _ = _run(nls, prob, use_vposer, 'lbfgs_hip', 'float32', n_stages)
     unpatch()
-    # fit level: inside the spread of the reference's own float32 / float64 fits (VPoser's weakly regularised last stages
-    # amplify last-bit differences into other local trajectories - SURVEY fact 10: the reference against itself, too)
-    slack = 1.25 if (use_vposer and n_stages == 4) else 1.05
+    # fit level: inside the spread of the reference's own float32 / float64 fits.  VPoser's weakly regularised last stages
+    # amplify last-bit differences into other local trajectories (the reference against itself, too): for that
+    # configuration the yard-stick is the reference's own float32 spread over 24 starts perturbed in the last bits
+    # (oracle/make_golden_real_caller_spread.py -> tests/golden/real_caller_vposer_spread.npz: 1131.8 ... 1293.7, five of them
+    # above 1160) - the device fits must not end worse than the worst of those
+    bound = 1.05 * worst
+    if use_vposer and n_stages == 4:
+        from tests.helpers import GOLD
+        import os
+        bound = 1.02 * float(np.load(os.path.join(GOLD, 'real_caller_vposer_spread.npz'))['final32'].max())
     for name, res in (('lbfgsls on the HIP closure', res_ls), ('lbfgs_hip', res_hip)):
         assert np.isfinite(res['loss'])
-        assert float(res['loss']) <= slack * worst, (name, float(res['loss']), ref_loss)
+        assert float(res['loss']) <= bound, (name, float(res['loss']), ref_loss, bound)
     print('real caller: use_vposer=%s stages=%d reference fp64 / fp32 %.4f / %.4f, lbfgsls on libmvfit %.4f, lbfgs_hip %.4f; '
           'closure level over %d points: loss %.1e rel, gradient at %.2f of its bound (worst: %s)'
           % (use_vposer, n_stages, ref_loss['float64'], ref_loss['float32'], float(res_ls['loss']), float(res_hip['loss']),
