@@ -791,11 +791,13 @@ def main():
         eng.profile(False)
         # (b) the kernel alone: 64 back-to-back launches inside one hipEvent pair, in the fit's launch flavour and with
         #     plain loads
-        nbytes = bytes_fwd(B, args.skin_topk, half_basis)
-        standard = views == 8 and args.skin_topk == 4 and not half_basis
         resident = in_fit and pp['tiles_per_workgroup'] > 0 and pp['rounds_stamped'] > 0
+        # (more than 128 problems are fitted in sub-batches: the resident pass serves one sub-batch's problems per round)
+        B_pass = B if not resident or B <= 128 else -(-(-(-B // -(-B // 128))) // 32) * 32
+        nbytes = bytes_fwd(B_pass, args.skin_topk, half_basis)
+        standard = views == 8 and args.skin_topk == 4 and not half_basis
         if resident:
-            roof = resident_roofline(eng, B, nbytes, pr, pp, passes,
+            roof = resident_roofline(eng, B_pass, nbytes, pr, pp, passes,
                                      with_pmc=rank == 0 and world == 1 and not args.no_pmc and standard,
                                      round_period_us=1e6 * tmax / args.steps / max(n_max, 1))
         ms_b2b = min(eng.profile_vertex_pass_ms(64, as_in_async_fit=in_fit) for _ in range(3))
