@@ -184,7 +184,7 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
     table = measure_pmc_resident(B) if with_pmc else None
     roof = dict(bound='hbm', kernel='lbs_vertex_pass_resident_kernel<%d>' % pp['tiles_per_workgroup'],
                 achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
-                algorithmic_bytes=nbytes, avg_launch_us=round(span_ms * 1e3, 2),
+                algorithmic_bytes=nbytes, avg_launch_us=round(span_ms * 1e3, 2), avg_launch_is=which,
                 avg_launch_note=('resident pass: no per-round launch exists; this is the in-fit service span of a closure round '
                                  '(max over workgroups of stores acknowledged - min over workgroups of operands seen), mean over '
                                  'the %d rounds of one complete profiled fit' % pp['rounds_stamped']) if which == 'span' else
@@ -602,7 +602,7 @@ def main():
                     help='blendshape contraction of the vertex pass (mvfit_options::contraction)')
     ap.add_argument('--round-mode', default='auto', choices=['auto', 'chained'],
                     help='chained: vertex pass -> step kernel per closure round also without the SDF term (mvfit_options::round_mode)')
-    ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 resident (mvfit_options)')
     ap.add_argument('--vposer-sets', type=int, default=0, help='decoder-helper sets of a VPoser fit (0 automatic; mvfit_options::vposer_sets)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -147,7 +147,9 @@ typedef struct mvfit_options {
                                       * 1: chained rounds always (vertex pass -> step kernel per closure round) */
     int32_t resident_pass;           /* vertex passes of the asynchronous fit: -1 automatic (resident when its workgroups fit
                                       * next to the optimiser's), 0 a gate + a pass launch per closure round, 1 / 2 resident with
-                                      * that many vertex tiles per workgroup (a forced value that does not fit stalls the fit).
+                                      * that many vertex tiles per workgroup, 3 resident with two tiles per workgroup and the
+                                      * workgroup split into contraction and worker waves (a forced value that does not fit
+                                      * stalls the fit).
                                       * The resident pass assumes what the path's deployment gives it - one process per GPU
                                       * (SURVEY 8(e)): a fit's ~250 workgroups are resident together.  Processes (or concurrent
                                       * ctxs) that SHARE a device should set 0: waiting for one another's CUs they would exhaust

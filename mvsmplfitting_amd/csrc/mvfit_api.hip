@@ -728,7 +728,7 @@ static int read_options(mvfit_ctx* c, const mvfit_options* in, mvfit_options& o)
     }
     if (o.contraction < 0 || o.contraction > MVFIT_CONTRACTION_HALF_BASIS) return fail(c, MVFIT_E_ARG, "mvfit_options: contraction %d", o.contraction);
     if (o.round_mode < 0 || o.round_mode > 1) return fail(c, MVFIT_E_ARG, "mvfit_options: round_mode %d", o.round_mode);
-    if (o.resident_pass < -1 || o.resident_pass > 2) return fail(c, MVFIT_E_ARG, "mvfit_options: resident_pass %d", o.resident_pass);
+    if (o.resident_pass < -1 || o.resident_pass > 3) return fail(c, MVFIT_E_ARG, "mvfit_options: resident_pass %d", o.resident_pass);
     if (o.pass_kernel < 0 || o.pass_kernel > 2) return fail(c, MVFIT_E_ARG, "mvfit_options: pass_kernel %d", o.pass_kernel);
     if (o.vposer_sets < 0) return fail(c, MVFIT_E_ARG, "mvfit_options: vposer_sets %d", o.vposer_sets);
     return MVFIT_OK;
@@ -1705,6 +1705,14 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
 // launches that do not leave the CUs - e.g. 160 optimiser + helper workgroups with the VPoser prior).
 // mvfit_options::resident_pass = 0 / 1 / 2 forces the choice (a forced value that does not fit can stall the fit: the
 // optimiser then waits 20 ms for the ring once and stops waiting; fit() reports the lost passes).
+// workgroups of the resident pass: form 1 / 2 = tiles per workgroup; 3 = two tiles per workgroup split into contraction and
+// worker waves (lbs_vertex_pass_resident_roles_kernel)
+static int resident_grid(const mvfit_ctx* c, int form) {
+    if (!form) return 0;
+    const int tiles = form == 3 ? 2 : form;
+    return (c->M.ntiles + tiles - 1) / tiles;
+}
+
 static int resident_tiles_per_wg(const mvfit_ctx* c, int opt_grid) {
     if (!c->M.bs_h2 || !c->M.wsp_w || (c->M.nv & 1)) return 0;      // (the resident pass stores vertex pairs: even vertex count)
     if (c->opt.resident_pass >= 0) return c->opt.resident_pass;
@@ -1733,7 +1741,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
     const bool dbg_nopass = debug_hook("MVFIT_DEBUG_NOPASS") != 0;          // (hooks build only)
     const int tpw = dbg_nopass ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per)));
-    const int res_grid = tpw ? (c->M.ntiles + tpw - 1) / tpw : 0;
+    const int res_grid = resident_grid(c, tpw);
     if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
     c->resident_tpw = tpw;
     R.npass = tpw ? res_grid : 1;
@@ -2258,7 +2266,7 @@ extern "C" int mvfit_pass_profile(mvfit_ctx* c, int* tiles_per_wg, int* workgrou
                                   double* slowest_ms) {
     if (!c) return MVFIT_E_ARG;
     if (tiles_per_wg) *tiles_per_wg = c->resident_tpw;
-    if (workgroups) *workgroups = c->resident_tpw ? (c->M.ntiles + c->resident_tpw - 1) / c->resident_tpw : 0;
+    if (workgroups) *workgroups = resident_grid(c, c->resident_tpw);
     if (rounds) *rounds = c->res_rounds;
     if (span_ms) *span_ms = c->res_span_ms;
     if (busy_ms) *busy_ms = c->res_busy_ms;

@@ -1391,8 +1391,359 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     if (tid_k == 0) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Resident pass, two tiles per workgroup, with the workgroup split by ROLE (more than 32 problems per optimiser launch: the
+// per-GPU shares of BASELINE configs[3] / [4], where the pass has 108 workgroups for 216 tiles).
+//
+// The kernel above runs a chunk's phases one after the other on all eight waves: contraction (2.4-3.0 k cycles: the matrix
+// pipe), barrier, two tiles' blend / apply / stores (3.6 k: LDS gathers), waits (profiles/r5_resident_timeline.log: 8.9 k
+// cycles per chunk).  The matrix pipe and the LDS are different units: here they work at the same time.
+//   * waves 0-3 (one per SIMD) = CONTRACTION waves: wave w owns tile w & 1, K half w >> 1, all three coordinate planes - three
+//     independent 21-MFMA chains interleaved (no dependent-issue bubbles), 168 VGPRs of basis.  While the workers blend chunk
+//     k they contract chunk k + 1 into registers, and they are the loaders: coefficient words of chunk k + 2 (two buffers),
+//     transforms of chunk k + 1 (ONE buffer, requested when the workers have finished blending chunk k).
+//   * waves 4-7 = WORKERS: the 1024 (vertex pair, problem, tile) items of a chunk, four per thread: blend all four (the
+//     transforms are then free for the next chunk's request), then K halves combined, T applied, "+ transl", stores straight
+//     from registers.
+//   * three bare barriers per chunk: P (blend done: transforms free), X (apply done: partials free), Y (the next chunk's
+//     partials and transforms are in LDS).
+// The chains, the blend and the apply are those of the kernel above: the same bits (tests/test_gpu_async.py).
+// LDS: transforms 36 KiB, coefficient words 2 x 28 KiB, partials 49.5 KiB, tables: 147.5 KB.
+// ---------------------------------------------------------------------------------------------------------
+template <bool HALF>
+__global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_roles_kernel(DevModel M, ResidentArgs RA) {
+    constexpr int TPW = 2;
+    __shared__ __attribute__((aligned(16))) f32x4 A_s[32 * A_STRIDE / 4];      // skinning transforms of the chunk being blended
+    __shared__ __attribute__((aligned(16))) f32x4 coef_0[VP_NBLK * 2 * 64];    // [VP_NBLK][hi, lo][64 lanes] A operands, two chunks
+    __shared__ __attribute__((aligned(16))) f32x4 coef_1[VP_NBLK * 2 * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 tau_s[32];
+    __shared__ float part[TPW * 2 * 3 * 32 * 33];                             // [tile][K half][plane][32][33]
+    __shared__ f32x4 sw_l[TPW * 32];
+    __shared__ i32x4 sj_l[TPW * 32];
+    __shared__ float vt_l[4 * 3 * 64];                                        // v_template rows of the contraction waves' chains
+    __shared__ unsigned ctl[8];
+
+    const int tid_k = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_k >> 6);
+    const int wg = blockIdx.x;
+    const unsigned nch = (unsigned)(RA.n + 31) >> 5;
+
+    // The two roles are two separate loops (the basis registers exist only in the contraction waves' one: in a common loop
+    // they would be live at every program point of the workers' code as well).  Both execute the same barriers per round:
+    //   S (verdict), Q (first chunk's operands), Y (first chunk's partials), then per chunk P, X, Y.
+    if (wave < 4) {
+        // ======================================== contraction waves ========================================
+        const int t_w = wave & 1, kh_w = (wave >> 1) & 1;                      // this wave's tile and K half
+        float4 bh[3][VP_BPW], bl[HALF ? 1 : 3][HALF ? 1 : VP_BPW];
+        {
+            const int lane = tid_k & 63;
+            const int tile = min(wg * TPW + t_w, M.ntiles - 1);               // (a tile past the end is never stored)
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                vt_l[(wave * 3 + kc) * 64 + lane] = kh_w == 0 ? M.vt_planes[kc * M.nv_pad + tile * TILE_V + (lane & 31)] * M.bs_scale : 0.f;
+                const float4* cb = M.bs_h2 + ((size_t)((tile * 3 + kc) * VP_NBLK + kh_w * VP_BPW) * 2) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < VP_BPW; ++g) {
+                    bh[kc][g] = nt_load16(&cb[(2 * g) * 64]);
+                    if (!HALF) bl[kc][g] = nt_load16(&cb[(2 * g + 1) * 64]);
+                }
+            }
+        }
+        __syncthreads();
+        // requests (these four waves): transforms 36 x 1 KiB + translations, coefficient words 28 x 1 KiB
+        auto request_A = [&](unsigned slot, unsigned c, int lane) {
+            const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u) * 72 + lane;
+            static_assert(A_STRIDE == 288, "a chunk's transforms are one linear 36 KiB copy");
+            for (int i = wave; i < 32 * 288 / 256; i += 4) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_s[i * 64], 16, 0, /*aux = sc1*/ 16);
+            if (wave == 3 && lane < 32)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane, &tau_s[0], 16, 0, 16);
+        };
+        auto request_coef = [&](auto Q_, unsigned slot, unsigned c, int lane) {
+            constexpr int Q = decltype(Q_)::value;
+            const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
+            for (int i = wave; i < VP_NBLK * 2; i += 4) {
+                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_0[i * 64], 16, 0, 16);
+                else __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_1[i * 64], 16, 0, 16);
+            }
+        };
+        // the wave's three chains out of coefficient buffer Q: small products first, one accumulator per plane
+        auto contract = [&](auto Q_, floatx16 (&acc)[3], int lane) {
+            constexpr int Q = decltype(Q_)::value;
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                const float v0 = vt_l[(wave * 3 + kc) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[kc][q] = v0;
+            }
+            const int cl = (kh_w * VP_BPW * 2) * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < VP_BPW; ++g) {
+                f32x4 a_h, a_l;
+                if constexpr (Q == 0) { a_h = coef_0[cl + (2 * g) * 64]; a_l = coef_0[cl + (2 * g + 1) * 64]; }
+                else { a_h = coef_1[cl + (2 * g) * 64]; a_l = coef_1[cl + (2 * g + 1) * 64]; }
+                const half8 Ah = __builtin_bit_cast(half8, a_h), Al = __builtin_bit_cast(half8, a_l);
+#pragma unroll
+                for (int kc = 0; kc < 3; ++kc) acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
+                if (!HALF) {
+#pragma unroll
+                    for (int kc = 0; kc < 3; ++kc)
+                        acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bl[HALF ? 0 : kc][HALF ? 0 : g]), acc[kc], 0, 0, 0);
+                }
+#pragma unroll
+                for (int kc = 0; kc < 3; ++kc) acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);             // one block's operands in flight at a time (registers)
+            }
+        };
+        auto put_partials = [&](const floatx16 (&acc)[3], int lane) {
+#pragma unroll
+            for (int kc = 0; kc < 3; ++kc) {
+                const int p0 = (((t_w * 2 + kh_w) * 3 + kc) * 32 + 4 * (lane >> 5)) * 33 + (lane & 31);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) part[p0 + ((q & 3) + 8 * (q >> 2)) * 33] = acc[kc][q];
+            }
+        };
+        for (unsigned r = 0; r < RA.max_rounds; ++r) {
+            const unsigned slot = r % (unsigned)RA.nslots;
+            __syncthreads();                                                  // (S) wave 7's verdict
+            const unsigned verdict = ctl[0];
+            unsigned mask = ctl[1];
+            if (verdict != 1u) break;                                         // uniform
+            int lane = tid_k & 63;
+            asm volatile("" : "+v"(lane));                                    // (opaque copy: no address hoisting out of the round loop)
+            unsigned c = (unsigned)__builtin_ctz(mask);
+            mask &= mask - 1u;
+            int cn = mask ? __builtin_ctz(mask) : -1;
+            // ---- the round's first live chunk: its operands, its contraction; the second chunk's coefficient words ----
+            request_A(slot, c, lane);
+            request_coef(std::integral_constant<int, 0>{}, slot, c, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_barrier_lds();                                                 // (Q)
+            {
+                if (cn >= 0) request_coef(std::integral_constant<int, 1>{}, slot, (unsigned)cn, lane);
+                floatx16 acc[3];
+                contract(std::integral_constant<int, 0>{}, acc, lane);
+                put_partials(acc, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wg_barrier_lds();                                                 // (Y)
+            unsigned par = 0u;                                                // coefficient buffer of chunk c
+            // one chunk (buffer P holds THIS chunk's coefficient words, 1 - P the next chunk's): contraction of the NEXT chunk
+            // into registers while the workers blend this one; before it, the request of the chunk after next's words into the
+            // buffer this chunk's no longer need
+            auto chunk = [&](auto P_, int cn, int cnn) {
+                constexpr int P = decltype(P_)::value;
+                floatx16 acc[3];
+                if (cnn >= 0) request_coef(std::integral_constant<int, P>{}, slot, (unsigned)cnn, lane);
+                if (cn >= 0) contract(std::integral_constant<int, 1 - P>{}, acc, lane);
+                wg_barrier_lds();                                             // (P) the workers have blended: the transforms are free
+                if (cn >= 0) request_A(slot, (unsigned)cn, lane);
+                wg_barrier_lds();                                             // (X) the workers have applied: the partials are free
+                if (cn >= 0) put_partials(acc, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's requests have landed
+                wg_barrier_lds();                                             // (Y)
+            };
+            for (;;) {
+                const unsigned m2 = cn >= 0 ? (mask & (mask - 1u)) : 0u;      // live chunks behind the next one
+                const int cnn = m2 ? __builtin_ctz(m2) : -1;
+                if (par == 0u) chunk(std::integral_constant<int, 0>{}, cn, cnn);
+                else chunk(std::integral_constant<int, 1>{}, cn, cnn);
+                if (cn < 0) break;
+                mask &= mask - 1u;
+                cn = cnn;
+                par ^= 1u;
+            }
+            if (RA.log && r < (unsigned)RA.log_rounds) __syncthreads();       // (the workers' log barrier)
+        }
+        return;
+    }
+
+    // ================================================ workers ================================================
+    const bool store_nt = VP_NT_LOADS && !(RA.flags & 2u);
+    const float inv_scale = 1.0f / M.bs_scale;
+    {
+        const int wt = tid_k - 256;
+        if (wt < 64) sw_l[wt] = __builtin_bit_cast(f32x4, M.wsp_w[(size_t)min(wg * TPW + (wt >> 5), M.ntiles - 1) * TILE_V + (wt & 31)]);
+        else if (wt < 128) sj_l[wt - 64] = __builtin_bit_cast(i32x4, M.wsp_j[(size_t)min(wg * TPW + ((wt - 64) >> 5), M.ntiles - 1) * TILE_V + (wt & 31)]);
+    }
+    __syncthreads();
+    for (unsigned r = 0; r < RA.max_rounds; ++r) {
+        const unsigned slot = r % (unsigned)RA.nslots;
+        // ---- wave 7: wait for the operands of closure round r (every problem: published, or finished before r) ----
+        if (wave == 7) {
+            const int lane = tid_k & 63;
+            const unsigned want = r + 1u;
+            const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
+            const unsigned* dn = RA.done_round + RA.b_lo;
+            unsigned verdict = 1u, live_bits = 0u, missed = 0u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                bool ok = true;
+                live_bits = 0u; missed = 0u;
+                for (int p = lane; p < RA.n; p += 64) {
+                    const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool live = d > r;
+                    ok = ok && (t >= want || !live);
+                    if (live) live_bits |= 1u << (p >> 5);
+                    if (live && t > want) ++missed;
+                }
+                if (__all(ok)) break;
+                if (wall_clock64() - t0 > 2000000) { verdict = 3u; break; }            // 20 ms at 100 MHz
+                __builtin_amdgcn_s_sleep(32);
+            }
+            unsigned mask = 0u;
+            for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
+            if (verdict == 1u && mask == 0u) verdict = 2u;
+            const unsigned long long miss_b = __ballot(missed != 0u);
+            if (lane == 0) {
+                ctl[0] = verdict; ctl[1] = mask;
+                const long long ts = wall_clock64();
+                ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
+                if (wg == 0 && verdict == 1u) {
+                    atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
+                    if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
+                }
+                if (wg == 0 && verdict == 3u) atomicAdd(RA.stats + 3, 1u);
+            }
+            if (wg == 0 && miss_b) {
+                unsigned msum = missed;
+                for (int o = 32; o; o >>= 1) msum += __shfl_xor(msum, o);
+                if (lane == 0) atomicAdd(RA.stats + 2, msum);
+            }
+        }
+        __syncthreads();                                                      // (S)
+        const unsigned verdict = ctl[0];
+        unsigned mask = ctl[1];
+        if (verdict != 1u) break;                                             // uniform
+        float* vout = (RA.capture_verts && (int)r == RA.capture_round) ? RA.capture_verts : RA.verts;
+        unsigned c = (unsigned)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        wg_barrier_lds();                                                     // (Q)
+        wg_barrier_lds();                                                     // (Y)
+        for (;;) {
+            const int cn = mask ? __builtin_ctz(mask) : -1;
+            int tid = tid_k;
+            asm volatile("" : "+v"(tid));                                     // (opaque copy: no address hoisting out of the round loop)
+            // ---- four items per thread = (vertex pair vp2) x (problems q, q + 16) x (tiles 0, 1): blend all four (the
+            //      transforms are then free for the next chunk's request) ----
+            const int wt = tid - 256, vp2 = wt & 15, q = wt >> 4;
+            float tr[4][2][3][4];                                             // [item = 2 t + e][vertex][row][4]
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 spw = sw_l[t * 32 + 2 * vp2 + i];
+                    const i32x4 spj = sj_l[t * 32 + 2 * vp2 + i];
+                    const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
+                    const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int bb = q + 16 * e;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) tr[2 * t + e][i][k][z] = 0.f;
+                        // (ascending joint order: the non-zero products of the dense blend in the same order, vp_blend_pairs;
+                        // two pairs = 6 transform rows in flight at a time)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                            for (int u = 2 * h; u < 2 * h + 2; ++u)
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) {
+                                    const f32x4 a = A_s[bb * (A_STRIDE / 4) + jq[u] * 3 + k];
+                                    tr[2 * t + e][i][k][0] = fmaf(wq[u], a.x, tr[2 * t + e][i][k][0]);
+                                    tr[2 * t + e][i][k][1] = fmaf(wq[u], a.y, tr[2 * t + e][i][k][1]);
+                                    tr[2 * t + e][i][k][2] = fmaf(wq[u], a.z, tr[2 * t + e][i][k][2]);
+                                    tr[2 * t + e][i][k][3] = fmaf(wq[u], a.w, tr[2 * t + e][i][k][3]);
+                                }
+                            // (the products are pinned HERE: instruction selection otherwise emits all 96 row loads of the four
+                            // items first and the FMAs behind them - 384 registers of rows in flight)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                asm volatile("" : "+v"(tr[2 * t + e][i][k][0]), "+v"(tr[2 * t + e][i][k][1]), "+v"(tr[2 * t + e][i][k][2]),
+                                                  "+v"(tr[2 * t + e][i][k][3]));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            const f32x4 tq0 = tau_s[q], tq1 = tau_s[q + 16];
+            wg_barrier_lds();                                                 // (P)
+            // ---- K halves combined (fixed order), scale undone, T applied, "+ transl", stores straight from registers ----
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wg * TPW + t;
+                if (tile >= M.ntiles) break;                                  // uniform
+                const int vbase = tile * TILE_V, pt = t * (2 * 3 * 32 * 33);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int bb = q + 16 * e;
+                    const float tau3[3] = {e ? tq1.x : tq0.x, e ? tq1.y : tq0.y, e ? tq1.z : tq0.z};
+                    float o[6];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int v = 2 * vp2 + i;
+                        float vp[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            float sm = part[pt + ((0 * 3 + k) * 32 + bb) * 33 + v];
+                            sm += part[pt + ((1 * 3 + k) * 32 + bb) * 33 + v];
+                            vp[k] = sm * inv_scale;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            o[3 * i + k] = fmaf(tr[2 * t + e][i][k][0], vp[0], fmaf(tr[2 * t + e][i][k][1], vp[1],
+                                                fmaf(tr[2 * t + e][i][k][2], vp[2], tr[2 * t + e][i][k][3]))) + tau3[k];
+                    }
+                    const int b_me = RA.b_lo + (int)c * 32 + bb;
+                    const int nv_ok = b_me < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vp2 : 0;
+                    float* dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vp2) * 3;
+                    if (nv_ok >= 2) {
+                        // 24 contiguous bytes (vertices 2 vp2, 2 vp2 + 1), 8-byte aligned (even vertex count, checked by the host)
+                        const f32x2 q0 = {o[0], o[1]}, q1 = {o[2], o[3]}, q2 = {o[4], o[5]};
+                        if (store_nt) {
+                            __builtin_nontemporal_store(q0, reinterpret_cast<f32x2*>(dst));
+                            __builtin_nontemporal_store(q1, reinterpret_cast<f32x2*>(dst + 2));
+                            __builtin_nontemporal_store(q2, reinterpret_cast<f32x2*>(dst + 4));
+                        } else {
+                            *reinterpret_cast<f32x2*>(dst) = q0; *reinterpret_cast<f32x2*>(dst + 2) = q1; *reinterpret_cast<f32x2*>(dst + 4) = q2;
+                        }
+                    } else if (nv_ok == 1) {
+                        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wg_barrier_lds();                                                 // (X)
+            wg_barrier_lds();                                                 // (Y)
+            if (cn < 0) break;
+            mask &= mask - 1u;
+            c = (unsigned)cn;
+        }
+        // every operand of this round has been read (the contraction waves waited for their requests before the last (Y))
+        if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (RA.log && r < (unsigned)RA.log_rounds) {                          // uniform (mvfit_profile only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's vertex stores have been acknowledged
+            __syncthreads();
+            if (tid_k == 256) {
+                unsigned long long* lg = RA.log + ((size_t)r * gridDim.x + wg) * 2;
+                lg[0] = (unsigned long long)ctl[2] | ((unsigned long long)ctl[3] << 32);
+                lg[1] = (unsigned long long)wall_clock64();
+            }
+        }
+    }
+    // whatever ended the loop: nothing waits for this workgroup any more
+    if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // tpw = tiles per workgroup (1 or 2); grid = ceil(ntiles / tpw) workgroups, all of which must be resident
 hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream) {
+    if (tpw == 3) {                  // two tiles per workgroup, contraction / worker roles
+        const dim3 grid((M.ntiles + 1) / 2);
+        hipLaunchKernelGGL(M.half_basis ? lbs_vertex_pass_resident_roles_kernel<true> : lbs_vertex_pass_resident_roles_kernel<false>,
+                           grid, dim3(VP_NT), 0, stream, M, RA);
+        return hipGetLastError();
+    }
     const dim3 grid((M.ntiles + tpw - 1) / tpw);
     auto kern = tpw == 1 ? (M.half_basis ? lbs_vertex_pass_resident_kernel<1, true> : lbs_vertex_pass_resident_kernel<1, false>)
                          : (M.half_basis ? lbs_vertex_pass_resident_kernel<2, true> : lbs_vertex_pass_resident_kernel<2, false>);

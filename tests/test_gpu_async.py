@@ -102,7 +102,8 @@ def _capture(eng, x0, stages, round_index, resident):
 
 
 @pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 2, 9), (33, None, 1, 140),
-                                                        (70, None, 2, 9), (70, None, 2, 140), (128, None, 2, 31)])
+                                                        (70, None, 2, 9), (70, None, 2, 140), (128, None, 2, 31),
+                                                        (5, 3, 3, 9), (33, 3, 3, 140), (70, 3, 3, 9), (70, 3, 3, 140), (128, 3, 3, 31)])
 def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index):
     """The resident pass (one launch per fit, the tiles' basis stationary in registers, rounds served from the ring) writes
     the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup, one chunk / ragged chunks /
