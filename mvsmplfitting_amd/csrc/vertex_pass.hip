@@ -1636,36 +1636,40 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     const i32x4 spj = sj_l[t * 32 + 2 * vp2 + i];
                     const float wq[4] = {spw.x, spw.y, spw.z, spw.w};
                     const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
+                    // one vertex of the tile for BOTH of the thread's problems: 24 transform rows requested before the first
+                    // product (one worker wave per SIMD: the latency of the LDS gathers is hidden by loads in flight, not by
+                    // other waves); ascending joint order per item: the non-zero products of the dense blend in the same order
+                    f32x4 rows[2][4][3];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) rows[e][u][k] = A_s[(q + 16 * e) * (A_STRIDE / 4) + jq[u] * 3 + k];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int bb = q + 16 * e;
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
 #pragma unroll
                             for (int z = 0; z < 4; ++z) tr[2 * t + e][i][k][z] = 0.f;
-                        // (ascending joint order: the non-zero products of the dense blend in the same order, vp_blend_pairs;
-                        // two pairs = 6 transform rows in flight at a time)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                            for (int u = 2 * h; u < 2 * h + 2; ++u)
+                            for (int k = 0; k < 3; ++k) {
+                                const f32x4 a = rows[e][u][k];
+                                tr[2 * t + e][i][k][0] = fmaf(wq[u], a.x, tr[2 * t + e][i][k][0]);
+                                tr[2 * t + e][i][k][1] = fmaf(wq[u], a.y, tr[2 * t + e][i][k][1]);
+                                tr[2 * t + e][i][k][2] = fmaf(wq[u], a.z, tr[2 * t + e][i][k][2]);
+                                tr[2 * t + e][i][k][3] = fmaf(wq[u], a.w, tr[2 * t + e][i][k][3]);
+                            }
+                        // (the products are pinned HERE: instruction selection otherwise emits the row loads of all four items
+                        // first and the FMAs behind them - 384 registers of rows in flight)
 #pragma unroll
-                                for (int k = 0; k < 3; ++k) {
-                                    const f32x4 a = A_s[bb * (A_STRIDE / 4) + jq[u] * 3 + k];
-                                    tr[2 * t + e][i][k][0] = fmaf(wq[u], a.x, tr[2 * t + e][i][k][0]);
-                                    tr[2 * t + e][i][k][1] = fmaf(wq[u], a.y, tr[2 * t + e][i][k][1]);
-                                    tr[2 * t + e][i][k][2] = fmaf(wq[u], a.z, tr[2 * t + e][i][k][2]);
-                                    tr[2 * t + e][i][k][3] = fmaf(wq[u], a.w, tr[2 * t + e][i][k][3]);
-                                }
-                            // (the products are pinned HERE: instruction selection otherwise emits all 96 row loads of the four
-                            // items first and the FMAs behind them - 384 registers of rows in flight)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k)
-                                asm volatile("" : "+v"(tr[2 * t + e][i][k][0]), "+v"(tr[2 * t + e][i][k][1]), "+v"(tr[2 * t + e][i][k][2]),
-                                                  "+v"(tr[2 * t + e][i][k][3]));
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        for (int k = 0; k < 3; ++k)
+                            asm volatile("" : "+v"(tr[2 * t + e][i][k][0]), "+v"(tr[2 * t + e][i][k][1]), "+v"(tr[2 * t + e][i][k][2]),
+                                              "+v"(tr[2 * t + e][i][k][3]));
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             const f32x4 tq0 = tau_s[q], tq1 = tau_s[q + 16];
             wg_barrier_lds();                                                 // (P)
@@ -1711,7 +1715,6 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     } else if (nv_ok == 1) {
                         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             wg_barrier_lds();                                                 // (X)
