@@ -182,7 +182,7 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
     # once from HBM) - SURVEY 8(d)'s per-problem figure; the 18.2 MB of constants cross the memory system once per FIT
     moved = PER_PROBLEM_BYTES * B
     table = measure_pmc_resident(B) if with_pmc else None
-    roof = dict(bound='hbm', kernel='lbs_vertex_pass_resident_kernel<%d>' % pp['tiles_per_workgroup'],
+    roof = dict(bound='hbm', kernel=pp['kernel'],
                 achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                 algorithmic_bytes=nbytes, avg_launch_us=round(span_ms * 1e3, 2), avg_launch_is=which,
                 avg_launch_note=('resident pass: no per-round launch exists; this is the in-fit service span of a closure round '
@@ -474,7 +474,7 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
                 ms = us * 1e-3
             e = out[name]
             e['in_fit'] = dict(
-                kernel=('lbs_vertex_pass_resident_kernel<%d>' % pp['tiles_per_workgroup']) if pp['tiles_per_workgroup'] else e['kernel'],
+                kernel=pp['kernel'] if pp['tiles_per_workgroup'] else e['kernel'],
                 avg_launch_us=round(ms * 1e3, 2), avg_launch_is=which, rounds=pr['vertex_pass_launches'],
                 round_span_us=round(pp['round_span_ms'] * 1e3, 2), slowest_workgroup_us=round(pp['slowest_workgroup_ms'] * 1e3, 2),
                 frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,

@@ -356,11 +356,13 @@ int mvfit_profile_vertex_pass(mvfit_ctx* ctx, int launches, double* avg_ms);
  * basis stream and vertex stores, no side outputs) - needs a preceding asynchronous mvfit_fit on this batch. */
 int mvfit_profile_vertex_pass_ex(mvfit_ctx* ctx, int launches, int flavour, double* avg_ms);
 /* How the vertex passes of the last asynchronous mvfit_fit ran:
- *   *tiles_per_wg  1 / 2: the RESIDENT pass - one launch per (sub-batch) fit whose workgroups keep the blendshape basis of
- *                  their vertex tile(s) in registers and serve closure round after closure round from the operand ring
- *                  (the basis crosses the memory system once per fit); 0: one gate + one pass launch per closure round
- *                  (dense skinning rows, exact-fp32 contraction, or launches that leave no CUs for resident workgroups);
- *   *workgroups    workgroups of the resident pass (ceil(tiles / tiles_per_wg));
+ *   *tiles_per_wg  the form of mvfit_options::resident_pass that ran.  1 / 2 / 3: the RESIDENT pass - one launch per (sub-batch)
+ *                  fit whose workgroups keep the blendshape basis of their one / two / two vertex tile(s) in registers and serve
+ *                  closure round after closure round from the operand ring (the basis crosses the memory system once per fit;
+ *                  3 = two tiles with the workgroup split into contraction and worker waves, the automatic choice beside more
+ *                  than 36 optimiser workgroups); 0: one gate + one pass launch per closure round (dense skinning rows,
+ *                  exact-fp32 contraction, or launches that leave no CUs for resident workgroups);
+ *   *workgroups    workgroups of the resident pass (ceil(tiles / tiles per workgroup));
  * and, when the fit ran under mvfit_profile(ctx, 1) with the resident pass, what its workgroups stamped per closure round
  * (wall clock, 10 ns ticks; the first 1024 rounds of the last sub-batch):
  *   *rounds        rounds stamped;

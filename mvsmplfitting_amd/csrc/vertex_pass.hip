@@ -1532,15 +1532,31 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             // buffer this chunk's no longer need
             auto chunk = [&](auto P_, int cn, int cnn) {
                 constexpr int P = decltype(P_)::value;
+#ifdef MVFIT_TIMING
+                const long long t_ch = clock64();              // timeline of a middle chunk (steady state), tests/vp_resident_timeline.py
+#define VPQ_T(k_) do { if (P == 1 && cn >= 0) VP_T(k_, t_ch); } while (0)
+#else
+#define VPQ_T(k_) do { } while (0)
+#endif
                 floatx16 acc[3];
                 if (cnn >= 0) request_coef(std::integral_constant<int, P>{}, slot, (unsigned)cnn, lane);
+                VPQ_T(0);
                 if (cn >= 0) contract(std::integral_constant<int, 1 - P>{}, acc, lane);
+                VPQ_T(1);
                 wg_barrier_lds();                                             // (P) the workers have blended: the transforms are free
+                VPQ_T(2);
                 if (cn >= 0) request_A(slot, (unsigned)cn, lane);
+                VPQ_T(3);
                 wg_barrier_lds();                                             // (X) the workers have applied: the partials are free
+                VPQ_T(4);
                 if (cn >= 0) put_partials(acc, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's requests have landed
+                VPQ_T(5);
                 wg_barrier_lds();                                             // (Y)
+                VPQ_T(6);
+#ifdef MVFIT_TIMING
+                if (P == 1 && cn >= 0 && blockIdx.x == 5 && (tid_k & 255) == 0) g_vp[7 + (tid_k >> 8) * 8] += 1;
+#endif
             };
             for (;;) {
                 const unsigned m2 = cn >= 0 ? (mask & (mask - 1u)) : 0u;      // live chunks behind the next one
@@ -1624,6 +1640,13 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             const int cn = mask ? __builtin_ctz(mask) : -1;
             int tid = tid_k;
             asm volatile("" : "+v"(tid));                                     // (opaque copy: no address hoisting out of the round loop)
+#ifdef MVFIT_TIMING
+            const long long t_wk = clock64();
+            const bool t_mid = cn >= 0 && c != (unsigned)__builtin_ctz(ctl[1]);      // a middle chunk of the round
+#define VPW_T(k_) do { if (t_mid) VP_T(k_, t_wk); } while (0)
+#else
+#define VPW_T(k_) do { } while (0)
+#endif
             // ---- four items per thread = (vertex pair vp2) x (problems q, q + 16) x (tiles 0, 1): blend all four (the
             //      transforms are then free for the next chunk's request) ----
             const int wt = tid - 256, vp2 = wt & 15, q = wt >> 4;
@@ -1672,7 +1695,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     __builtin_amdgcn_sched_barrier(0);
                 }
             const f32x4 tq0 = tau_s[q], tq1 = tau_s[q + 16];
+            VPW_T(1);
             wg_barrier_lds();                                                 // (P)
+            VPW_T(2);
             // ---- K halves combined (fixed order), scale undone, T applied, "+ transl", stores straight from registers ----
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -1717,8 +1742,14 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     }
                 }
             }
+            VPW_T(3);
             wg_barrier_lds();                                                 // (X)
+            VPW_T(4);
             wg_barrier_lds();                                                 // (Y)
+            VPW_T(6);
+#ifdef MVFIT_TIMING
+            if (t_mid && blockIdx.x == 5 && (tid_k & 255) == 0) g_vp[7 + (tid_k >> 8) * 8] += 1;
+#endif
             if (cn < 0) break;
             mask &= mask - 1u;
             c = (unsigned)cn;

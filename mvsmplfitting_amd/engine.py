@@ -465,7 +465,10 @@ class MvFit:
         span, busy, slowest = C.c_double(), C.c_double(), C.c_double()
         self._check(self._lib.mvfit_pass_profile(self._ctx, C.byref(tpw), C.byref(wgs), C.byref(n), C.byref(span), C.byref(busy),
                                                  C.byref(slowest)))
-        return dict(tiles_per_workgroup=tpw.value, workgroups=wgs.value, rounds_stamped=n.value,
+        form = tpw.value               # 0 per-round launches; 1 / 2 tiles per workgroup, every wave does everything; 3 two tiles, role-split
+        kernel = {0: None, 1: 'lbs_vertex_pass_resident_kernel<1>', 2: 'lbs_vertex_pass_resident_kernel<2>',
+                  3: 'lbs_vertex_pass_resident_roles_kernel'}[form]
+        return dict(form=form, tiles_per_workgroup=2 if form == 3 else form, kernel=kernel, workgroups=wgs.value, rounds_stamped=n.value,
                     round_span_ms=span.value, workgroup_busy_ms=busy.value, slowest_workgroup_ms=slowest.value)
 
     def profile_read(self):

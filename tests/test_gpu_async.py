@@ -102,17 +102,18 @@ def _capture(eng, x0, stages, round_index, resident):
 
 
 @pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 2, 9), (33, None, 1, 140),
-                                                        (70, None, 2, 9), (70, None, 2, 140), (128, None, 2, 31),
-                                                        (5, 3, 3, 9), (33, 3, 3, 140), (70, 3, 3, 9), (70, 3, 3, 140), (128, 3, 3, 31)])
-def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index):
+                                                        (70, None, 3, 9), (70, None, 3, 140), (128, None, 3, 31),
+                                                        (5, 3, 3, 9), (33, 3, 3, 140), (70, 2, 2, 9), (70, 2, 2, 140), (128, 2, 2, 31)])
+def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index):      # tpw: the expected form
     """The resident pass (one launch per fit, the tiles' basis stationary in registers, rounds served from the ring) writes
-    the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup, one chunk / ragged chunks /
-    four chunks, before and after the ring wrapped; and it does not perturb the optimiser either."""
+    the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup (form 2: every wave does everything;
+    form 3, the automatic choice beside more than 36 optimiser workgroups: contraction waves + worker waves), one chunk / ragged
+    chunks / four chunks, before and after the ring wrapped; and it does not perturb the optimiser either."""
     eng, x0 = _setup(B=B)
     stages = eng_stage_weights(1536.0, flags=0)
     cap_l, x_l, ncl_l, prof_l = _capture(eng, x0, stages, round_index, 0)
     cap_r, x_r, ncl_r, prof_r = _capture(eng, x0, stages, round_index, resident)
-    assert prof_l['tiles_per_workgroup'] == 0 and prof_r['tiles_per_workgroup'] == tpw, (prof_l, prof_r)
+    assert prof_l['form'] == 0 and prof_r['form'] == tpw, (prof_l, prof_r)
     assert np.array_equal(x_l, x_r) and np.array_equal(ncl_l, ncl_r)
     have = round_index < ncl_r
     assert have.any()
