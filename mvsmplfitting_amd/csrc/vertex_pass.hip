@@ -1400,23 +1400,32 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 // cycles per chunk).  The matrix pipe and the LDS are different units: here they work at the same time.
 //   * waves 0-3 (one per SIMD) = CONTRACTION waves: wave w owns tile w & 1, K half w >> 1, all three coordinate planes - three
 //     independent 21-MFMA chains interleaved (no dependent-issue bubbles), 168 VGPRs of basis.  While the workers blend chunk
-//     k they contract chunk k + 1 into registers, and they are the loaders: coefficient words of chunk k + 2 (two buffers),
-//     transforms of chunk k + 1 (ONE buffer, requested when the workers have finished blending chunk k).
-//   * waves 4-7 = WORKERS: the 1024 (vertex pair, problem, tile) items of a chunk, four per thread: blend all four (the
-//     transforms are then free for the next chunk's request), then K halves combined, T applied, "+ transl", stores straight
-//     from registers.
-//   * three bare barriers per chunk: P (blend done: transforms free), X (apply done: partials free), Y (the next chunk's
-//     partials and transforms are in LDS).
+//     k they request chunk k + 1's transforms into the other of two buffers, contract chunk k and write its partials; while
+//     the workers apply, they request the coefficient words of chunk k + 1 into the single buffer.
+//   * waves 4-7 = WORKERS: the 1024 (vertex pair, problem, tile) items of a chunk, four per thread: blend all four with 24
+//     transform rows in flight (one worker wave per SIMD: loads in flight hide the LDS latency, not other waves), then K
+//     halves combined, T applied, "+ transl", stores straight from registers.
+//   * two bare barriers per chunk: P (blend done | partials published, next contraction done), Y (apply done | the next
+//     chunk's operands landed).
 // The chains, the blend and the apply are those of the kernel above: the same bits (tests/test_gpu_async.py).
-// LDS: transforms 36 KiB, coefficient words 2 x 28 KiB, partials 49.5 KiB, tables: 147.5 KB.
+// LDS: transforms 2 x 36 KiB, coefficient words 28 KiB, partials 49.5 KiB, tables: 155.5 KB.
 // ---------------------------------------------------------------------------------------------------------
+// vmcnt(0) as an instruction the compiler's wait-count pass SEES (an asm statement is opaque to it: it would then take every earlier
+// LDS-DMA request for still in flight and put its own vmcnt(0) before the next read of that LDS object - in the middle of the
+// requests issued since).  gfx9 encoding: vmcnt = 0, expcnt = 7, lgkmcnt = 15 (untouched)
+__device__ __forceinline__ void wait_vm0() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
+
 template <bool HALF>
 __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_roles_kernel(DevModel M, ResidentArgs RA) {
     constexpr int TPW = 2;
-    __shared__ __attribute__((aligned(16))) f32x4 A_s[32 * A_STRIDE / 4];      // skinning transforms of the chunk being blended
-    __shared__ __attribute__((aligned(16))) f32x4 coef_0[VP_NBLK * 2 * 64];    // [VP_NBLK][hi, lo][64 lanes] A operands, two chunks
-    __shared__ __attribute__((aligned(16))) f32x4 coef_1[VP_NBLK * 2 * 64];
-    __shared__ __attribute__((aligned(16))) f32x4 tau_s[32];
+    __shared__ __attribute__((aligned(16))) f32x4 A_0[32 * A_STRIDE / 4];      // skinning transforms, two chunks
+    __shared__ __attribute__((aligned(16))) f32x4 A_1[32 * A_STRIDE / 4];
+    __shared__ __attribute__((aligned(16))) f32x4 coef_s[VP_NBLK * 2 * 64];    // [VP_NBLK][hi, lo][64 lanes] A operands of the chunk being contracted
+    __shared__ __attribute__((aligned(16))) f32x4 tau_0[32];
+    __shared__ __attribute__((aligned(16))) f32x4 tau_1[32];
     __shared__ float part[TPW * 2 * 3 * 32 * 33];                             // [tile][K half][plane][32][33]
     __shared__ f32x4 sw_l[TPW * 32];
     __shared__ i32x4 sj_l[TPW * 32];
@@ -1430,7 +1439,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
     // The two roles are two separate loops (the basis registers exist only in the contraction waves' one: in a common loop
     // they would be live at every program point of the workers' code as well).  Both execute the same barriers per round:
-    //   S (verdict), Q (first chunk's operands), Y (first chunk's partials), then per chunk P, X, Y.
+    //   S (verdict), Q (first chunk's operands), then per chunk P (blend done / contraction done, partials published) and
+    //   Y (apply done / next operands landed).
     if (wave < 4) {
         // ======================================== contraction waves ========================================
         const int t_w = wave & 1, kh_w = (wave >> 1) & 1;                      // this wave's tile and K half
@@ -1451,24 +1461,28 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
         __syncthreads();
         // requests (these four waves): transforms 36 x 1 KiB + translations, coefficient words 28 x 1 KiB
-        auto request_A = [&](unsigned slot, unsigned c, int lane) {
+        auto request_A = [&](auto Q_, unsigned slot, unsigned c, int lane) {
+            constexpr int Q = decltype(Q_)::value;
             const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u) * 72 + lane;
             static_assert(A_STRIDE == 288, "a chunk's transforms are one linear 36 KiB copy");
-            for (int i = wave; i < 32 * 288 / 256; i += 4) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_s[i * 64], 16, 0, /*aux = sc1*/ 16);
-            if (wave == 3 && lane < 32)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane, &tau_s[0], 16, 0, 16);
-        };
-        auto request_coef = [&](auto Q_, unsigned slot, unsigned c, int lane) {
-            constexpr int Q = decltype(Q_)::value;
-            const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
-            for (int i = wave; i < VP_NBLK * 2; i += 4) {
-                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_0[i * 64], 16, 0, 16);
-                else __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_1[i * 64], 16, 0, 16);
+            for (int i = wave; i < 32 * 288 / 256; i += 4) {
+                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_0[i * 64], 16, 0, /*aux = sc1*/ 16);
+                else __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_1[i * 64], 16, 0, 16);
+            }
+            if (wave == 3 && lane < 32) {
+                const float4* tsrc = reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane;
+                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(tsrc, &tau_0[0], 16, 0, 16);
+                else __builtin_amdgcn_global_load_lds(tsrc, &tau_1[0], 16, 0, 16);
             }
         };
-        // the wave's three chains out of coefficient buffer Q: small products first, one accumulator per plane
-        auto contract = [&](auto Q_, floatx16 (&acc)[3], int lane) {
-            constexpr int Q = decltype(Q_)::value;
+        auto request_coef = [&](unsigned slot, unsigned c, int lane) {
+            const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
+            for (int i = wave; i < VP_NBLK * 2; i += 4) __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_s[i * 64], 16, 0, 16);
+        };
+        // the wave's three chains: small products first, one accumulator per plane.  The A operands of block g + 1 are read
+        // into the SAME registers as soon as block g's MFMAs that take them have issued (an MFMA reads its operands at issue):
+        // the lo words under six MFMAs, the hi words under the next block's first three - no second operand set (registers)
+        auto contract = [&](floatx16 (&acc)[3], int lane) {
 #pragma unroll
             for (int kc = 0; kc < 3; ++kc) {
                 const float v0 = vt_l[(wave * 3 + kc) * 64 + lane];
@@ -1476,22 +1490,26 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 for (int q = 0; q < 16; ++q) acc[kc][q] = v0;
             }
             const int cl = (kh_w * VP_BPW * 2) * 64 + lane;
+            f32x4 a_h = coef_s[cl], a_l = coef_s[cl + 64];
 #pragma unroll
             for (int g = 0; g < VP_BPW; ++g) {
-                f32x4 a_h, a_l;
-                if constexpr (Q == 0) { a_h = coef_0[cl + (2 * g) * 64]; a_l = coef_0[cl + (2 * g + 1) * 64]; }
-                else { a_h = coef_1[cl + (2 * g) * 64]; a_l = coef_1[cl + (2 * g + 1) * 64]; }
-                const half8 Ah = __builtin_bit_cast(half8, a_h), Al = __builtin_bit_cast(half8, a_l);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kc = 0; kc < 3; ++kc) acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
+                for (int kc = 0; kc < 3; ++kc)
+                    acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a_l), __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < VP_BPW) a_l = coef_s[cl + (2 * g + 3) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 if (!HALF) {
 #pragma unroll
                     for (int kc = 0; kc < 3; ++kc)
-                        acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bl[HALF ? 0 : kc][HALF ? 0 : g]), acc[kc], 0, 0, 0);
+                        acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a_h), __builtin_bit_cast(half8, bl[HALF ? 0 : kc][HALF ? 0 : g]), acc[kc], 0, 0, 0);
                 }
 #pragma unroll
-                for (int kc = 0; kc < 3; ++kc) acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);             // one block's operands in flight at a time (registers)
+                for (int kc = 0; kc < 3; ++kc)
+                    acc[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a_h), __builtin_bit_cast(half8, bh[kc][g]), acc[kc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < VP_BPW) a_h = coef_s[cl + (2 * g + 2) * 64];
             }
         };
         auto put_partials = [&](const floatx16 (&acc)[3], int lane) {
@@ -1513,24 +1531,17 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             unsigned c = (unsigned)__builtin_ctz(mask);
             mask &= mask - 1u;
             int cn = mask ? __builtin_ctz(mask) : -1;
-            // ---- the round's first live chunk: its operands, its contraction; the second chunk's coefficient words ----
-            request_A(slot, c, lane);
-            request_coef(std::integral_constant<int, 0>{}, slot, c, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- the round's first live chunk: its operands ----
+            request_A(std::integral_constant<int, 0>{}, slot, c, lane);
+            request_coef(slot, c, lane);
+            wait_vm0();
             wg_barrier_lds();                                                 // (Q)
-            {
-                if (cn >= 0) request_coef(std::integral_constant<int, 1>{}, slot, (unsigned)cn, lane);
-                floatx16 acc[3];
-                contract(std::integral_constant<int, 0>{}, acc, lane);
-                put_partials(acc, lane);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            wg_barrier_lds();                                                 // (Y)
-            unsigned par = 0u;                                                // coefficient buffer of chunk c
-            // one chunk (buffer P holds THIS chunk's coefficient words, 1 - P the next chunk's): contraction of the NEXT chunk
-            // into registers while the workers blend this one; before it, the request of the chunk after next's words into the
-            // buffer this chunk's no longer need
-            auto chunk = [&](auto P_, int cn, int cnn) {
+            unsigned par = 0u;                                                // transform buffer of the chunk the workers blend
+            // one chunk (transform buffer P holds its transforms, the coefficient buffer its words): the next chunk's transforms
+            // requested into the other buffer, then the contraction and the partials, while the workers blend; then, while they
+            // apply and store, the next chunk's coefficient words into the single buffer (every contraction wave is past P:
+            // the words have been read).  No work is done ahead of the workers: a round has no pipeline to fill.
+            auto chunk = [&](auto P_, int cn) {
                 constexpr int P = decltype(P_)::value;
 #ifdef MVFIT_TIMING
                 const long long t_ch = clock64();              // timeline of a middle chunk (steady state), tests/vp_resident_timeline.py
@@ -1538,34 +1549,31 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #else
 #define VPQ_T(k_) do { } while (0)
 #endif
-                floatx16 acc[3];
-                if (cnn >= 0) request_coef(std::integral_constant<int, P>{}, slot, (unsigned)cnn, lane);
+                if (cn >= 0) request_A(std::integral_constant<int, 1 - P>{}, slot, (unsigned)cn, lane);
                 VPQ_T(0);
-                if (cn >= 0) contract(std::integral_constant<int, 1 - P>{}, acc, lane);
+                floatx16 acc[3];
+                contract(acc, lane);
                 VPQ_T(1);
-                wg_barrier_lds();                                             // (P) the workers have blended: the transforms are free
+                put_partials(acc, lane);
                 VPQ_T(2);
-                if (cn >= 0) request_A(slot, (unsigned)cn, lane);
+                wg_barrier_lds();                                             // (P) partials published; the workers have blended
                 VPQ_T(3);
-                wg_barrier_lds();                                             // (X) the workers have applied: the partials are free
+                if (cn >= 0) request_coef(slot, (unsigned)cn, lane);
                 VPQ_T(4);
-                if (cn >= 0) put_partials(acc, lane);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's requests have landed
+                wait_vm0();                                                   // this wave's requests have landed
                 VPQ_T(5);
-                wg_barrier_lds();                                             // (Y)
+                wg_barrier_lds();                                             // (Y) the workers have applied
                 VPQ_T(6);
 #ifdef MVFIT_TIMING
                 if (P == 1 && cn >= 0 && blockIdx.x == 5 && (tid_k & 255) == 0) g_vp[7 + (tid_k >> 8) * 8] += 1;
 #endif
             };
             for (;;) {
-                const unsigned m2 = cn >= 0 ? (mask & (mask - 1u)) : 0u;      // live chunks behind the next one
-                const int cnn = m2 ? __builtin_ctz(m2) : -1;
-                if (par == 0u) chunk(std::integral_constant<int, 0>{}, cn, cnn);
-                else chunk(std::integral_constant<int, 1>{}, cn, cnn);
+                if (par == 0u) chunk(std::integral_constant<int, 0>{}, cn);
+                else chunk(std::integral_constant<int, 1>{}, cn);
                 if (cn < 0) break;
                 mask &= mask - 1u;
-                cn = cnn;
+                cn = mask ? __builtin_ctz(mask) : -1;
                 par ^= 1u;
             }
             if (RA.log && r < (unsigned)RA.log_rounds) __syncthreads();       // (the workers' log barrier)
@@ -1635,7 +1643,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         unsigned c = (unsigned)__builtin_ctz(mask);
         mask &= mask - 1u;
         wg_barrier_lds();                                                     // (Q)
-        wg_barrier_lds();                                                     // (Y)
+        unsigned par = 0u;                                                    // transform buffer of the chunk being blended
         for (;;) {
             const int cn = mask ? __builtin_ctz(mask) : -1;
             int tid = tid_k;
@@ -1668,7 +1676,10 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) rows[e][u][k] = A_s[(q + 16 * e) * (A_STRIDE / 4) + jq[u] * 3 + k];
+                            for (int k = 0; k < 3; ++k) {
+                                const int at = (q + 16 * e) * (A_STRIDE / 4) + jq[u] * 3 + k;
+                                rows[e][u][k] = par ? A_1[at] : A_0[at];      // (uniform)
+                            }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -1694,7 +1705,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            const f32x4 tq0 = tau_s[q], tq1 = tau_s[q + 16];
+            const f32x4 tq0 = par ? tau_1[q] : tau_0[q], tq1 = par ? tau_1[q + 16] : tau_0[q + 16];
             VPW_T(1);
             wg_barrier_lds();                                                 // (P)
             VPW_T(2);
@@ -1743,8 +1754,6 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
             VPW_T(3);
-            wg_barrier_lds();                                                 // (X)
-            VPW_T(4);
             wg_barrier_lds();                                                 // (Y)
             VPW_T(6);
 #ifdef MVFIT_TIMING
@@ -1753,6 +1762,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             if (cn < 0) break;
             mask &= mask - 1u;
             c = (unsigned)cn;
+            par ^= 1u;
         }
         // every operand of this round has been read (the contraction waves waited for their requests before the last (Y))
         if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

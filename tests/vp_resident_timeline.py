@@ -28,9 +28,9 @@ torch.cuda.synchronize()
 eng._lib.mvfit_debug_vp(vb)
 form = eng.pass_profile()['form']
 if form == 3:
-    cn = ['coefficient request issued', 'contraction of the next chunk done', 'barrier P', 'transform request issued', 'barrier X',
-          'partials written + requests landed', 'barrier Y']
-    wn = ['-', 'four items blended', 'barrier P', 'applied + stores issued', 'barrier X', '-', 'barrier Y']
+    cn = ['transform request issued (next chunk)', 'contraction done', 'partials written', 'barrier P', 'coefficient request issued (next chunk)',
+          'requests landed', 'barrier Y']
+    wn = ['-', 'four items blended', 'barrier P', 'applied + stores issued', '-', '-', 'barrier Y']
     for half, who, nm in ((0, 'wave 0 (contraction wave)', cn), (1, 'wave 4 (worker)', wn)):
         n = max(vb[7 + 8 * half] - base[7 + 8 * half], 1)
         print('  %s, %d middle chunks of workgroup 5, cumulative shader-clock cycles since the chunk start:' % (who, n))
