@@ -24,6 +24,7 @@
 //     apply T and store.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include <hip/hip_ext.h>
 #include "mvfit_device.h"
 
@@ -1016,6 +1017,10 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #endif
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (builtin arguments that must be constants)
+template <int... Ks, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Ks...>, F&& f) { (f(std::integral_constant<int, Ks>{}), ...); }
+
 // ---------------------------------------------------------------------------------------------------------
 // Resident pass of the asynchronous fit: ONE launch per (sub-batch) fit instead of a gate + a pass launch per closure round.
 //
@@ -1115,10 +1120,17 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         constexpr int Q = decltype(Q_)::value;
         const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u) * 72 + lane;
         static_assert(A_STRIDE == 288, "a chunk's transforms are one linear 36 KiB copy");
-        for (int i = wave; i < 32 * 288 / 256; i += VP_NT / 64) {
-            if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_0[i * 64], 16, 0, /*aux = sc1*/ 16);
-            else __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_1[i * 64], 16, 0, 16);
-        }
+        // consecutive KiB per wave (waves 0-3: five, waves 4-7: four); the instruction offset (0 .. 3 KiB) moves BOTH addresses, so
+        // four requests share one global address and one M0 - a request is then one or two instructions, not eight
+        const int a0 = wave < 4 ? 5 * wave : 4 * wave + 4;
+        const float4* g = asrc + a0 * 64;
+        static_for(std::make_integer_sequence<int, 5>{}, [&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if (k < 4 || wave < 4) {                                             // (uniform)
+                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(g + (k >> 2) * 256, &A_0[(a0 + (k & ~3)) * 64], 16, (k & 3) * 1024, /*aux = sc1*/ 16);
+                else __builtin_amdgcn_global_load_lds(g + (k >> 2) * 256, &A_1[(a0 + (k & ~3)) * 64], 16, (k & 3) * 1024, 16);
+            }
+        });
         if (wave == 7 && lane < 32) {
             const float4* tsrc = reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane;
             if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(tsrc, &tau_0[0], 16, 0, 16);
@@ -1127,8 +1139,13 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     auto request_coef = [&](unsigned slot, unsigned c, int lane) {
         const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
-        for (int i = 7 - wave; i < VP_NBLK * 2; i += VP_NT / 64)            // (waves 4-7, which carry one chain, take four)
-            __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_l[i * 64], 16, 0, 16);
+        static_assert(VP_NBLK * 2 == 28, "three KiB per wave 0-3, four per wave 4-7 (which carry one chain)");
+        const int c0 = wave < 4 ? 3 * wave : 4 * wave - 4;
+        const float4* g = csrc + c0 * 64;
+        static_for(std::make_integer_sequence<int, 4>{}, [&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            if (k < 3 || wave >= 4) __builtin_amdgcn_global_load_lds(g, &coef_l[c0 * 64], 16, k * 1024, 16);
+        });
     };
 
     // a (vertex pair, problem) item's finished vertices, kept in registers until their stores are issued
@@ -1465,10 +1482,14 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             constexpr int Q = decltype(Q_)::value;
             const float4* asrc = reinterpret_cast<const float4*>(RA.Amat) + ((size_t)slot * RA.rb + c * 32u) * 72 + lane;
             static_assert(A_STRIDE == 288, "a chunk's transforms are one linear 36 KiB copy");
-            for (int i = wave; i < 32 * 288 / 256; i += 4) {
-                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_0[i * 64], 16, 0, /*aux = sc1*/ 16);
-                else __builtin_amdgcn_global_load_lds(asrc + i * 64, &A_1[i * 64], 16, 0, 16);
-            }
+            // wave w: the nine consecutive KiB from 9 w on; the instruction offset (0 .. 3 KiB) moves BOTH addresses, so four
+            // requests share one global address and one M0 - a request is then two instructions, not eight
+            const float4* g = asrc + 9 * wave * 64;
+            static_for(std::make_integer_sequence<int, 9>{}, [&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(g + (k >> 2) * 256, &A_0[(9 * wave + (k & ~3)) * 64], 16, (k & 3) * 1024, /*aux = sc1*/ 16);
+                else __builtin_amdgcn_global_load_lds(g + (k >> 2) * 256, &A_1[(9 * wave + (k & ~3)) * 64], 16, (k & 3) * 1024, 16);
+            });
             if (wave == 3 && lane < 32) {
                 const float4* tsrc = reinterpret_cast<const float4*>(RA.tau) + ((size_t)slot * RA.rb + c * 32u) + lane;
                 if constexpr (Q == 0) __builtin_amdgcn_global_load_lds(tsrc, &tau_0[0], 16, 0, 16);
@@ -1477,7 +1498,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         };
         auto request_coef = [&](unsigned slot, unsigned c, int lane) {
             const float4* csrc = RA.coefH + ((size_t)slot * ((unsigned)RA.rb >> 5) + c) * (VP_NBLK * 2 * 64) + lane;
-            for (int i = wave; i < VP_NBLK * 2; i += 4) __builtin_amdgcn_global_load_lds(csrc + i * 64, &coef_s[i * 64], 16, 0, 16);
+            static_assert(VP_NBLK * 2 == 28, "seven KiB per contraction wave");
+            const float4* g = csrc + 7 * wave * 64;
+            static_for(std::make_integer_sequence<int, 7>{}, [&](auto K_) {
+                constexpr int k = decltype(K_)::value;
+                __builtin_amdgcn_global_load_lds(g + (k >> 2) * 256, &coef_s[(7 * wave + (k & ~3)) * 64], 16, (k & 3) * 1024, 16);
+            });
         };
         // the wave's three chains: small products first, one accumulator per plane.  The A operands of block g + 1 are read
         // into the SAME registers as soon as block g's MFMAs that take them have issued (an MFMA reads its operands at issue):
