@@ -603,7 +603,7 @@ def main():
     ap.add_argument('--round-mode', default='auto', choices=['auto', 'chained'],
                     help='chained: vertex pass -> step kernel per closure round also without the SDF term (mvfit_options::round_mode)')
     ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2, 3],
-                    help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 resident (mvfit_options)')
+                    help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 / 3 resident forms (mvfit_options.resident_pass)')
     ap.add_argument('--vposer-sets', type=int, default=0, help='decoder-helper sets of a VPoser fit (0 automatic; mvfit_options::vposer_sets)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline / prior variants')

@@ -36,7 +36,7 @@ for B in (32, 128):
         e["standalone_dispatches"] = used; e["rounds_per_dispatch"] = side["rounds_per_standalone_dispatch"]
         e["tiles_per_workgroup"] = side["tiles_per_workgroup"]
     e["traffic_bytes_per_round"] = (2.0 * e["FETCH_SIZE_KiB_per_round"] + e["WRITE_SIZE_KiB_per_round"]) * 1024.0
-    e["note"] = "stand-alone dispatches of lbs_vertex_pass_resident_kernel (100 rounds each from the ring a fit left behind); 2 x FETCH_SIZE + WRITE_SIZE; the fit's own dispatch is left out (rocprofv3 serialises kernels while collecting counters)"
+    e["note"] = "stand-alone dispatches of the resident kernel (lbs_vertex_pass_resident_kernel / _roles_kernel; 100 rounds each from the ring a fit left behind); 2 x FETCH_SIZE + WRITE_SIZE; the fit's own dispatch is left out (rocprofv3 serialises kernels while collecting counters)"
     res["RES_B%d" % B] = e
 json.dump(res, open("$OUT/pmc_resident.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
