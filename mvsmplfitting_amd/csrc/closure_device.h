@@ -1199,6 +1199,37 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     __syncthreads();
     PH_T(6);
     // ---- E8a: g_M = G_parent^T g_G (root: identity) ; g_R = g_Rm (+ g_coef) ----
+    // g_M element (joint j with parent pa, row mm, column c) = column mm of G_pa . column c of g_G_j
+    // g_M element (joint j with parent pa, row mm, column c) = column mm of G_pa . column c of g_G_j.  The value is made
+    // opaque before anything is added to it: the sum then contracts into FMAs on its own, i.e. to the same bits wherever it
+    // is used (inside a longer expression the surrounding additions would fuse with its products differently).
+    auto gm_elem = [&](int pa, int j, int mm, int c) -> float {
+        float v = L.pose.G[pa][mm] * L.gG[j][c] + L.pose.G[pa][4 + mm] * L.gG[j][4 + c] + L.pose.G[pa][8 + mm] * L.gG[j][8 + c];
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    constexpr int GJ_T0 = 320;                         // waves 5-6: idle in this phase (the g_M threads are waves 0-4)
+    static_assert(GJ_T0 >= NJ * 12 && GJ_T0 % 64 == 0 && GJ_T0 + NJ * 3 <= STEP_NT, "g_J totals on otherwise idle waves");
+    if (tid >= GJ_T0 && tid < GJ_T0 + NJ * 3) {
+        // total g_J[j][a] = E6's part + the translation column of the joint's own g_M - its children's (lbs.py:341-348: a
+        // child's relative translation is J_child - J_parent), with the g_M elements taken straight from g_G (the same
+        // products as the threads that store g_M): E9's g_beta is then a plain 72-long product per shape coefficient instead
+        // of a walk over child lists behind the next barrier.  Staged in L.gvp (dead since E7).  The first three children
+        // are read branch-free (an absent one = a zero row of g_G: subtracting +0 changes nothing), further ones in a loop.
+        const int i = tid - GJ_T0, j = i / 3, a = i - 3 * j;
+        const int c_lo = L.M.child_start[j], c_hi = L.M.child_start[j + 1];
+        int ch[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ch[k] = c_lo + k < c_hi ? L.M.child_list[min(c_lo + k, NJ - 1)] : NJ;      // (g_G rows 24..31 are zero)
+        float gj = L.gJ[j][a] + (j == 0 ? L.gG[0][4 * a + 3] : gm_elem(L.M.parents[j], j, a, 3));
+        float sub[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sub[k] = gm_elem(j, ch[k], a, 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gj -= sub[k];
+        for (int ci = c_lo + 3; ci < c_hi; ++ci) gj -= gm_elem(j, L.M.child_list[ci], a, 3);
+        L.gvp[i] = gj;
+    }
     if (tid < NJ * 12) {
         const int j = tid / 12, e = tid - 12 * j, mm = e >> 2, c = e & 3;
         float v;
@@ -1252,16 +1283,12 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     PH_T(7);
     // ---- E8b || E9: g_scale ; g_J -> g_beta ; Rodrigues adjoint + pose priors ----
     const float wp2 = W.pose_w * W.pose_w;
+    const long long t_e9 = PH_CLK();
     if (tid >= 256 && tid < 256 + 160) {
         // g_beta[l] = g_coef[207 + l] + sum_i J_S[i][l] g_J[i]  (+ shape prior): 16 lanes per l
         const int l = (tid - 256) >> 4, g = tid & 15;
         float s = 0.f;
-        for (int i = g; i < NJ * 3; i += 16) {
-            const int j = i / 3, a = i - 3 * j;
-            float gj = L.gJ[j][a] + L.gM[j][4 * a + 3];
-            for (int ci = L.M.child_start[j]; ci < L.M.child_start[j + 1]; ++ci) gj -= L.gM[L.M.child_list[ci]][4 * a + 3];
-            s = fmaf(L.M.J_S[i][l], gj, s);
-        }
+        for (int i = g; i < NJ * 3; i += 16) s = fmaf(L.M.J_S[i][l], L.gvp[i], s);      // (g_J totals: E8a)
         s = row16_sum(s);
         if (g == 0) {
             float gc = 0.f;
@@ -1271,6 +1298,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
         }
+        PH_W(40, 256, t_e9);
     } else if (tid == 448) {
         float s = 0.f;
 #pragma unroll
@@ -1332,8 +1360,10 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             }
         }
         L.gtheta[3 * tid] = gth[0]; L.gtheta[3 * tid + 1] = gth[1]; L.gtheta[3 * tid + 2] = gth[2];
+        PH_W(41, 0, t_e9);
     }
     __syncthreads();
+    PH_W(42, 0, t_e9);
     // assemble the flat gradient (frozen / unused slots are zero)
     if (tid < DPAD) {
         const int i = tid;

@@ -16,7 +16,12 @@ static __device__ long long g_dbg_last;
 #define PH_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_dbg[k] += now_ - g_dbg_last; g_dbg_last = now_; } } while (0)
 #define PH_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_last = clock64(); } while (0)
 #define PH_ADD(k, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[k] += (v); } while (0)
+// probe of another thread of workgroup 0: cycles since t0_ (a clock64() value taken by that thread) into slot k
+#define PH_CLK() clock64()
+#define PH_W(k, who, t0_) do { if (blockIdx.x == 0 && (int)threadIdx.x == (who)) g_dbg[k] += clock64() - (t0_); } while (0)
 #else
+#define PH_CLK() 0ll
+#define PH_W(k, who, t0_) do { } while (0)
 #define PH_T(k) do { } while (0)
 #define PH_T0() do { } while (0)
 #define PH_ADD(k, v) do { } while (0)

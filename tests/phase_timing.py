@@ -42,6 +42,7 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     lib.mvfit_debug_timing_adv(ab, 1)
     print('    inside advance (cycles per round): ' + ' | '.join('%s=%.0f' % (nm, ab[i]/n) for i, nm in enumerate(['entry->ls_first', 'gtd dot', 'wolfe checks->ls_return', 'ls_return->iter', 'iter->insert done', 'dir end->resume', 'resume->emit'])))
     lib.mvfit_debug_timing_helpers(hb, 1)
+    if not hb[2]: print('    E9 probes (cycles per round): g_beta lanes done=%.0f | Rodrigues adjoint lanes done=%.0f | barrier behind both=%.0f' % (hb[8]/n, hb[9]/n, hb[10]/n))
     if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
     if buf[15]:
         sub = [buf[16+i]/buf[15] for i in range(6)]
