@@ -775,8 +775,9 @@ __device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L,
     const int nks = fwd_slices(nc_pad, STEP_NT - 64);
     if (run_chain || !from_pass) {
         // wave 0: the kinematic chain; waves 1-7: the forward basis stream (k-split partial sums) - overlapped
+        const long long t_e2 = PH_CLK();
         if (tid < 64) { if (run_chain) chain_forward_wave(L, tid); PH_T(22); }
-        else if (!from_pass) contraction_forward(M, L, tid - 64, STEP_NT - 64);
+        else if (!from_pass) { contraction_forward(M, L, tid - 64, STEP_NT - 64); PH_W(60, 64, t_e2); PH_W(62, 448, t_e2); }
         __syncthreads();
     }
     PH_T(1);
@@ -1086,26 +1087,30 @@ __device__ __forceinline__ void chain_backward_wave(ClosureLds& L, int lane) {
 constexpr int BWD_SLICES = 8, BWD_CPS = NC_MAX / BWD_SLICES;     // up to 36 columns per slice
 __device__ __forceinline__ int bwd_slices(int) { return BWD_SLICES; }
 
-__device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+// CPS = compile-time bound of the columns per slice (the SMPL keypoint set: 28 of the array's 36 - the loop over the array's
+// length with a run-time bound held 144 VGPRs for 112 used and the scheduler then issued the stream in pieces)
+template <int CPS>
+__device__ __forceinline__ void contraction_backward_t(const DevModel& M, ClosureLds& L, int t, int nthreads) {
     constexpr int npq = KROWS >> 2;                 // 56 float4 row groups
     const int nc_pad = L.M.nc_pad;
-    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;     // columns per slice (multiple of 4)
+    const int cps = ((nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4;     // columns per slice (multiple of 4, <= CPS)
     for (int item = t; item < npq * BWD_SLICES; item += nthreads) {
         const int pq = item % npq, cs = (item / npq + (int)blockIdx.x) & (BWD_SLICES - 1);
         const int c0 = cs * cps;
         const float4* src = reinterpret_cast<const float4*>(M.pd_subT) + pq;
-        float4 v[BWD_CPS];
+        float4 v[CPS];
 #pragma unroll
-        for (int r = 0; r < BWD_CPS; ++r) {
+        for (int r = 0; r < CPS; ++r) {
             const int c = min(c0 + r, nc_pad - 1);              // clamped: surplus columns get a zero coefficient
-            if (r < cps) v[r] = src[(size_t)c * npq];
+            if (CPS == BWD_CPS ? r < cps : true) v[r] = src[(size_t)c * npq];
         }
         float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
 #pragma unroll
-        for (int r = 0; r < BWD_CPS; r += 2) {
+        for (int r = 0; r < CPS; r += 2) {
             if (r < cps) {
-                const float g0 = (c0 + r < nc_pad) ? L.gvp[c0 + r] : 0.f;
-                const float g1 = (c0 + r + 1 < nc_pad) ? L.gvp[c0 + r + 1] : 0.f;
+                // (columns past nc_pad: E5 stored zeros there - a conditional LDS read is a branch around the read, 28 of them
+                // were 3 k cycles of the phase)
+                const float g0 = L.gvp[c0 + r], g1 = L.gvp[c0 + r + 1];
                 acc0.x = fmaf(g0, v[r].x, acc0.x); acc0.y = fmaf(g0, v[r].y, acc0.y);
                 acc0.z = fmaf(g0, v[r].z, acc0.z); acc0.w = fmaf(g0, v[r].w, acc0.w);
                 acc1.x = fmaf(g1, v[r + 1].x, acc1.x); acc1.y = fmaf(g1, v[r + 1].y, acc1.y);
@@ -1115,6 +1120,12 @@ __device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureL
         float4* dst = reinterpret_cast<float4*>(L.scratch + cs * KROWS + 4 * pq);
         *dst = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
     }
+}
+
+__device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureLds& L, int t, int nthreads) {
+    constexpr int SMPL_CPS = 28;
+    if (((L.M.nc_pad >> 2) + BWD_SLICES - 1) / BWD_SLICES * 4 <= SMPL_CPS) contraction_backward_t<SMPL_CPS>(M, L, t, nthreads);      // uniform
+    else contraction_backward_t<BWD_CPS>(M, L, t, nthreads);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1152,6 +1163,8 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             L.gx[tid] = bq == 0 ? gx0 : (bq == 1 ? gx1 : gx2);
         }
         L.gvp[tid] = v;
+    } else if (tid < NC_MAX) {
+        L.gvp[tid] = 0.f;                     // surplus columns of the transposed contraction's slices (E7 reads them unconditionally)
     }
     __syncthreads();
     PH_T(4);
@@ -1193,8 +1206,9 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     // ---- E7: chain adjoint on wave 0 || transposed contraction on waves 1-7 ----
     // (measured: the two overlap - the one-wave walk up the tree, 5 k cycles, hides the 186 KB stream; the whole-workgroup
     // form of the adjoint, chain_backward_block, is shorter alone but runs behind the stream: +0.7-1.1 us per round)
+    const long long t_e7 = PH_CLK();
     if (tid < 64) { chain_backward_wave(L, tid); PH_T(23); }
-    else contraction_backward(M, L, tid - 64, STEP_NT - 64);
+    else { contraction_backward(M, L, tid - 64, STEP_NT - 64); PH_W(59, 64, t_e7); PH_W(61, 448, t_e7); }
     const int ncs = bwd_slices(STEP_NT - 64);
     __syncthreads();
     PH_T(6);
@@ -1298,7 +1312,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
         }
-        PH_W(40, 256, t_e9);
+        PH_W(56, 256, t_e9);
     } else if (tid == 448) {
         float s = 0.f;
 #pragma unroll
@@ -1360,10 +1374,10 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             }
         }
         L.gtheta[3 * tid] = gth[0]; L.gtheta[3 * tid + 1] = gth[1]; L.gtheta[3 * tid + 2] = gth[2];
-        PH_W(41, 0, t_e9);
+        PH_W(57, 0, t_e9);
     }
     __syncthreads();
-    PH_W(42, 0, t_e9);
+    PH_W(58, 0, t_e9);
     // assemble the flat gradient (frozen / unused slots are zero)
     if (tid < DPAD) {
         const int i = tid;

@@ -42,7 +42,11 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     lib.mvfit_debug_timing_adv(ab, 1)
     print('    inside advance (cycles per round): ' + ' | '.join('%s=%.0f' % (nm, ab[i]/n) for i, nm in enumerate(['entry->ls_first', 'gtd dot', 'wolfe checks->ls_return', 'ls_return->iter', 'iter->insert done', 'dir end->resume', 'resume->emit'])))
     lib.mvfit_debug_timing_helpers(hb, 1)
-    if not hb[2]: print('    E9 probes (cycles per round): g_beta lanes done=%.0f | Rodrigues adjoint lanes done=%.0f | barrier behind both=%.0f' % (hb[8]/n, hb[9]/n, hb[10]/n))
+    print('    E9 probes (cycles per round): g_beta lanes done=%.0f | Rodrigues adjoint lanes done=%.0f | barrier behind both=%.0f' % (ab[8]/n, ab[9]/n, ab[10]/n))
+    print('    basis streams (cycles per round, from the phase start): forward wave 1 / wave 7 done=%.0f / %.0f | transposed wave 1 / wave 7 done=%.0f / %.0f' % (ab[12]/n, ab[14]/n, ab[11]/n, ab[13]/n))
+    if not (flags & _lib.F_VPOSER):
+        nm = ['fast accept', 'fast resume', 'general: step start', 'general: first trial', 'general: bracket', 'general: zoom', 'general: behind a direction']
+        print('    optimiser calls (wave 0): ' + ' | '.join('%s %d x %.0f' % (nm[i], hb[2 * i + 1], hb[2 * i] / max(1, hb[2 * i + 1])) for i in range(7)) + ' cycles')
     if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
     if buf[15]:
         sub = [buf[16+i]/buf[15] for i in range(6)]

@@ -1,0 +1,8 @@
+set -u
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5k; rm -rf $O; mkdir -p $O
+timeout 300 python tools/ab_bits.py mvsmplfitting_amd/libmvfit_old.so mvsmplfitting_amd/libmvfit.so 2>&1 | grep -v amdgpu.ids | tail -4
+MVFIT_LIBRARY=$PWD/mvsmplfitting_amd/libmvfit_timing.so timeout 300 python tests/phase_timing.py > $O/phase_timing.log 2>&1; sed -n 2,12p $O/phase_timing.log | grep -E "basis streams|wave-0 chain|pose_prep=" | cut -c1-500
+for a in "" ""; do timeout 300 python bench.py $a --no-cpu-baseline --no-pmc --no-variants 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$a', d['value'], d['ms_per_step'], d.get('closure_rounds_per_fit'), d.get('final_loss_median'))"; done
