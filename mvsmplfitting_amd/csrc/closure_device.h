@@ -1311,13 +1311,27 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             s += gc;
             if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
+            L.grad[X_BETAS + l] = (W.flags & MVFIT_F_FIX_SHAPE) ? 0.f : s;
         }
         PH_W(56, 256, t_e9);
     } else if (tid == 448) {
         float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) s += L.gM[0][4 * (e / 3) + (e % 3)] * L.pose.R[0][e];
+        {
+            // products rounded one by one, then added in order (what the compiler's packed multiplies made of this sum when it
+            // stood alone; said explicitly, it no longer depends on the code around it)
+#pragma clang fp contract(off)
+            for (int e = 0; e < 9; ++e) s += L.gM[0][4 * (e / 3) + (e % 3)] * L.pose.R[0][e];
+        }
         L.gscale = s;
+        L.grad[X_SC] = (W.flags & MVFIT_F_FIX_SCALE) ? 0.f : s;
+    } else if (tid > 448 && tid < 449 + (DPAD - X_TR - 1)) {
+        // the slots of the flat gradient nobody else writes: translation (+ the SDF term's part), the embedding's own prior
+        // (fitting.py:328, d/dz |z|^2 w^2; the decoder's adjoint adds to it behind the barrier), zero padding
+        const int i = X_TR + (tid - 449) + (tid - 449 >= 3 ? 1 : 0);           // X_TR .. X_TR + 2, X_EMB .. DPAD - 1
+        float g = 0.f;
+        if (i < X_SC) { g = L.gtau[i - X_TR]; if (sdf_fac != 0.f) g = fmaf(sdf_fac, L.sdf_adj->gtau[i - X_TR], g); }
+        else if (i < DV) g = use_vp ? 2.f * L.opt.x[i] * wp2 : 0.f;
+        L.grad[i] = g;
     } else if (tid < NJ) {
         const float rx = L.pose.theta[3 * tid], ry = L.pose.theta[3 * tid + 1], rz = L.pose.theta[3 * tid + 2];
         const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
@@ -1374,23 +1388,14 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             }
         }
         L.gtheta[3 * tid] = gth[0]; L.gtheta[3 * tid + 1] = gth[1]; L.gtheta[3 * tid + 2] = gth[2];
+        // the flat gradient is written where its parts are made (global_orient | body_pose are contiguous; with VPoser the
+        // body pose is not a parameter: zeros)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L.grad[X_GO + 3 * tid + q] = (tid > 0 && use_vp) ? 0.f : gth[q];
         PH_W(57, 0, t_e9);
     }
     __syncthreads();
     PH_W(58, 0, t_e9);
-    // assemble the flat gradient (frozen / unused slots are zero)
-    if (tid < DPAD) {
-        const int i = tid;
-        float g = 0.f;
-        if (i < X_GO) g = (W.flags & MVFIT_F_FIX_SHAPE) ? 0.f : L.gbeta[i];
-        else if (i < X_BP) g = L.gtheta[i - X_GO];
-        else if (i < X_TR) g = use_vp ? 0.f : L.gtheta[3 + i - X_BP];
-        else if (i < X_SC) { g = L.gtau[i - X_TR]; if (sdf_fac != 0.f) g = fmaf(sdf_fac, L.sdf_adj->gtau[i - X_TR], g); }
-        else if (i == X_SC) g = (W.flags & MVFIT_F_FIX_SCALE) ? 0.f : L.gscale;
-        else if (i < DV) g = use_vp ? 2.f * L.opt.x[i] * wp2 : 0.f;              // fitting.py:328 (d/dz |z|^2 w^2)
-        L.grad[i] = g;
-    }
-    __syncthreads();
     if (use_vp) vposer_backward<REMOTE>(M, L, tid);
 }
 
