@@ -556,13 +556,16 @@ __device__ __forceinline__ void pose_prep_decode_inl(const DevModel& M, ClosureL
         if (tid < 3) L.pose.theta[tid] = L.opt.x[X_GO + tid];
         __syncthreads();
     } else {
-        if (tid < 72) L.pose.theta[tid] = L.opt.x[X_GO + tid];      // global_orient | body_pose are contiguous in x
-        __syncthreads();
+        // global_orient | body_pose are contiguous in x.  No barrier: pose_prep_elems reads the angles from x itself in this
+        // mode (the same values), the copy is for the later phases - which all sit behind pose_prep_elems' barrier
+        if (tid < 72) L.pose.theta[tid] = L.opt.x[X_GO + tid];
     }
 }
 
 // second half of E1 (force-inlined: the fit kernels keep a thread's prefetched basis rows in registers across it)
 __device__ __forceinline__ void pose_prep_elems(const DevModel& M, ClosureLds& L, uint32_t flags, int tid) {
+    // the axis-angle vectors: the decoder's output with VPoser (behind its barrier), else x's own slots (no copy to wait for)
+    const float* th = (flags & MVFIT_F_VPOSER) ? &L.pose.theta[0] : &L.opt.x[X_GO];
     if (tid < KROWS) {
         // blendshape coefficients: pose_feature (lbs.py:192), betas, zero pad
         const int p = tid;
@@ -570,7 +573,7 @@ __device__ __forceinline__ void pose_prep_elems(const DevModel& M, ClosureLds& L
         if (p < 207) {
             const int j = 1 + p / 9, e = p % 9;
             float R[9], rod[3];
-            rodrigues(&L.pose.theta[3 * j], R, rod);
+            rodrigues(&th[3 * j], R, rod);
             float sel = R[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
@@ -585,7 +588,7 @@ __device__ __forceinline__ void pose_prep_elems(const DevModel& M, ClosureLds& L
         const int j = i / 12, e = i - j * 12;
         if (e < 9) {
             float R[9], rod[3];
-            rodrigues(&L.pose.theta[3 * j], R, rod);
+            rodrigues(&th[3 * j], R, rod);
             float sel = R[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) sel = (e == q) ? R[q] : sel;
