@@ -827,10 +827,69 @@ __device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L,
     keypoints_from_xs(L, tid);
 }
 
+// the scalar terms of the loss out of the reduced sums (fixed order, float64 like the reference's float() of the tensors):
+// called by every thread (all get the total) or by one wave; `writer` stores the side results (L.total, L.loss_terms, the
+// dropped-prior flags, the SDF factor, the selected mixture)
+__device__ __forceinline__ double loss_combine(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, bool writer) {
+    const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
+    const bool use_gmm = !use_vp && (W.flags & MVFIT_F_PRIOR_GMM);
+    const int ndw = (V * NKP + 63) >> 6;
+    // ---- every thread: combine (fixed order) ----
+    double l_data = 0.0;
+    for (int w = 0; w < ndw; ++w) l_data += L.red_d[w];
+    const bool use_3d = (W.flags & MVFIT_F_USE_3D) != 0;
+    if (use_3d) l_data += L.red_d[STEP_NW];
+    l_data *= (double)W.data_w2;                                               // fitting.py:311-316, 319-324
+    const double sq = L.red_d[STEP_NW - 1], sqb = L.red_d[STEP_NW - 2], san = L.red_d[STEP_NW - 3];
+    const double wp2 = (double)W.pose_w * (double)W.pose_w;
+    double l_pose;
+    int dropped = 0;
+    if (use_vp) {
+        l_pose = sq * wp2;                                                    // fitting.py:327-329
+    } else {
+        double P;
+        if (use_gmm) {
+            int sel = 0;
+            float best = L.gmm_ll[0];
+            for (int m = 1; m < M.gmm_M; ++m) if (L.gmm_ll[m] < best) { best = L.gmm_ll[m]; sel = m; }
+            if (writer) L.gmm_sel = sel;
+            P = (double)best;
+        } else {
+            P = sq;                                                            // prior.py:92-97
+        }
+        P *= wp2;
+        if ((float)P > 5e4f) { P = 0.0; dropped |= 1; }                        // fitting.py:334-335
+        l_pose = P + sq * (16.0 * wp2);                                        // fitting.py:336-337
+    }
+    double l_shape = 0.0;
+    if (!(W.flags & MVFIT_F_FIX_SHAPE)) l_shape = sqb * (double)W.shape_w * (double)W.shape_w;   // :339-342
+    double l_angle = san * (double)W.bend_w;
+    if ((float)l_angle > 1e4f && !use_vp) { l_angle = 0.0; dropped |= 2; }     // fitting.py:349-350
+    // interpenetration term (fitting.py:352-393): pen = (w S / valid_people)^2 with S from sdf_term.hip
+    double l_coll = 0.0;
+    float sdf_fac = 0.f;
+    if (L.sdf_adj && W.coll_w > 0.f) {
+        const float S = L.sdf_adj->S;
+        const double ws = (double)W.coll_w * (double)S;
+        l_coll = ws * ws;
+        sdf_fac = 2.f * W.coll_w * W.coll_w * S;
+    }
+    const double total = l_data + l_pose + l_shape + l_angle + l_coll;
+    if (writer) {
+        L.sdf_fac = sdf_fac;
+        L.loss_terms[0] = (float)l_data; L.loss_terms[1] = (float)l_pose; L.loss_terms[2] = (float)l_shape;
+        L.loss_terms[3] = (float)l_angle; L.loss_terms[4] = (float)l_coll; L.loss_terms[5] = (float)total;
+        L.flags_dropped = dropped;
+        L.total = total;
+    }
+    return total;
+}
+
 // ---------------------------------------------------------------------------------------------
 // E4: SMPLifyLoss.forward (fitting.py:290-415, no SDF term) + gradient w.r.t. keypoints / priors.
 // Returns the total loss (same value in every thread).  Ends with __syncthreads.
 // ---------------------------------------------------------------------------------------------
+template <bool DEFER = false>
 __device__ __forceinline__ double loss_and_keypoint_grad(const DevModel& M, ClosureLds& L, int V, const DevWeights& W,
                                          bool want_grad, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
@@ -968,54 +1027,11 @@ __device__ __forceinline__ double loss_and_keypoint_grad(const DevModel& M, Clos
         }
     }
     __syncthreads();
-    // ---- every thread: combine (fixed order) ----
-    double l_data = 0.0;
-    for (int w = 0; w < ndw; ++w) l_data += L.red_d[w];
+    // the scalar terms are combined by every thread here (each then returns the total), or - DEFER - by one otherwise idle wave
+    // inside the adjoint's first phase (closure_backward), which leaves the total in L.total
+    double total = 0.0;
+    if constexpr (!DEFER) total = loss_combine(M, L, V, W, tid == 0);
     const bool use_3d = (W.flags & MVFIT_F_USE_3D) != 0;
-    if (use_3d) l_data += L.red_d[STEP_NW];
-    l_data *= (double)W.data_w2;                                               // fitting.py:311-316, 319-324
-    const double sq = L.red_d[STEP_NW - 1], sqb = L.red_d[STEP_NW - 2], san = L.red_d[STEP_NW - 3];
-    const double wp2 = (double)W.pose_w * (double)W.pose_w;
-    double l_pose;
-    int dropped = 0;
-    if (use_vp) {
-        l_pose = sq * wp2;                                                    // fitting.py:327-329
-    } else {
-        double P;
-        if (use_gmm) {
-            int sel = 0;
-            float best = L.gmm_ll[0];
-            for (int m = 1; m < M.gmm_M; ++m) if (L.gmm_ll[m] < best) { best = L.gmm_ll[m]; sel = m; }
-            if (tid == 0) L.gmm_sel = sel;
-            P = (double)best;
-        } else {
-            P = sq;                                                            // prior.py:92-97
-        }
-        P *= wp2;
-        if ((float)P > 5e4f) { P = 0.0; dropped |= 1; }                        // fitting.py:334-335
-        l_pose = P + sq * (16.0 * wp2);                                        // fitting.py:336-337
-    }
-    double l_shape = 0.0;
-    if (!(W.flags & MVFIT_F_FIX_SHAPE)) l_shape = sqb * (double)W.shape_w * (double)W.shape_w;   // :339-342
-    double l_angle = san * (double)W.bend_w;
-    if ((float)l_angle > 1e4f && !use_vp) { l_angle = 0.0; dropped |= 2; }     // fitting.py:349-350
-    // interpenetration term (fitting.py:352-393): pen = (w S / valid_people)^2 with S from sdf_term.hip
-    double l_coll = 0.0;
-    float sdf_fac = 0.f;
-    if (L.sdf_adj && W.coll_w > 0.f) {
-        const float S = L.sdf_adj->S;
-        const double ws = (double)W.coll_w * (double)S;
-        l_coll = ws * ws;
-        sdf_fac = 2.f * W.coll_w * W.coll_w * S;
-    }
-    const double total = l_data + l_pose + l_shape + l_angle + l_coll;
-    if (tid == 0) {
-        L.sdf_fac = sdf_fac;
-        L.loss_terms[0] = (float)l_data; L.loss_terms[1] = (float)l_pose; L.loss_terms[2] = (float)l_shape;
-        L.loss_terms[3] = (float)l_angle; L.loss_terms[4] = (float)l_coll; L.loss_terms[5] = (float)total;
-        L.flags_dropped = dropped;
-        L.total = total;
-    }
     if (want_grad && tid < 3) {
         float s = 0.f;
         for (int w = 0; w < ndw; ++w) s += L.red_f[w][tid];
@@ -1135,13 +1151,18 @@ __device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureL
 // Adjoint: g_kp -> grad[118]  (oracle/closure_np.py:_backward).
 // Ends with __syncthreads; L.grad holds the flat gradient.
 // ---------------------------------------------------------------------------------------------
-template <bool REMOTE = false>
+// DEFER: the loss's scalar terms were left uncombined by loss_and_keypoint_grad<true>; the last wave - idle in E5 - combines
+// them here, under E5 (400 cycles that every thread used to spend between the loss's barrier and this function's first one)
+template <bool REMOTE = false, bool DEFER = false>
 __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
     __syncthreads();                  // L.gkp (view sums) and L.gtau are written after E4's last barrier
-    const float sdf_fac = L.sdf_fac;
     // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
+    if constexpr (DEFER) {
+        static_assert(NC_MAX <= STEP_NT - 64, "E5's threads leave the last wave free");
+        if (tid >= STEP_NT - 64) loss_combine(M, L, V, W, tid == STEP_NT - 64);
+    }
     if (tid < nc_pad) {
         float v = 0.f;
         if (tid < nc) {
@@ -1171,6 +1192,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     }
     __syncthreads();
     PH_T(4);
+    const float sdf_fac = L.sdf_fac;       // (side results of the loss's combine: complete behind this barrier in either mode)
     // ---- E6: g_A = sum_s W[s][j] [g_x v_posed^T | g_x]: 16-lane row per joint, lanes stride s ----
     if (tid < NJ * 16) {
         const int j = tid >> 4, g = tid & 15;

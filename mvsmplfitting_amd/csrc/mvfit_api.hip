@@ -254,8 +254,10 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     const unsigned a_round = use_ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
     const int a_slot = use_ring ? (int)(a_round % (unsigned)ring.nslots) : 0;
     if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, tid);
-    const double total = loss_and_keypoint_grad(M, L, nviews, W, true, tid);
+    loss_and_keypoint_grad<true>(M, L, nviews, W, true, tid);          // (scalar terms combined under the adjoint's first phase)
     PH_T(3);
+    closure_backward<REMOTE, true>(M, L, nviews, W, tid);
+    const double total = L.total;
     if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
         const int k = L.opt.lbS.n_closure;                 // closures consumed so far = index of this one
         if (k < trace_cap) {
@@ -263,7 +265,6 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
             if (tid == 0) trace[(size_t)k * (DV + 1) + DV] = (float)total;
         }
     }
-    closure_backward<REMOTE>(M, L, nviews, W, tid);
     if (use_ring) publish_tag(ring, a_slot, pb, a_round, tid);             // the stores have long drained by now
     PH_T(8);
     float gnew[LB_EPL], xt[LB_EPL];

@@ -1,5 +1,5 @@
 """Developer tool: A/B bit comparison of two builds of libmvfit on the same inputs - closure gradients at random points and
-whole fits (rounds, final parameters).  python tools/ab_bits.py <lib A> <lib B> [vposer]"""
+whole fits (rounds, final parameters).  python tools/ab_bits.py <lib A> <lib B> [vposer|gmm]"""
 import os
 import sys
 
@@ -13,14 +13,16 @@ import bench  # noqa: E402
 
 la, lb = sys.argv[1], sys.argv[2]
 use_vp = len(sys.argv) > 3 and sys.argv[3] == 'vposer'
+use_gmm = len(sys.argv) > 3 and sys.argv[3] == 'gmm'
 B, V = 32, 8
 model = syn.make_body_model(0, skin_topk=4)
 res = []
 for lib in (la, lb):
-    eng = MvFit(model, vposer=syn.make_vposer_decoder() if use_vp else None, library=os.path.abspath(lib))
+    eng = MvFit(model, vposer=syn.make_vposer_decoder() if use_vp else None, gmm=syn.gmm_constants(syn.make_gmm()) if use_gmm else None,
+                library=os.path.abspath(lib))
     cams, gt, conf, x0 = bench.build_inputs(eng, syn, 0, B, 1, V)
     rng = np.random.RandomState(5)
-    flags = _lib.F_VPOSER if use_vp else 0
+    flags = _lib.F_VPOSER if use_vp else (_lib.F_PRIOR_GMM if use_gmm else 0)
     stages = stage_weights(1536.0, flags=flags)
     out = []
     for k in range(3):
