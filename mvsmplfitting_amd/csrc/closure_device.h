@@ -235,7 +235,8 @@ __device__ __forceinline__ void gemv4_partial(const float* __restrict__ W, int l
         for (int u = 0; u < U; ++u) w[u] = Wq[(size_t)min(i + u, i1 - 1) * ld4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float hv = (i + u < i1) ? h[min(i + u, i1 - 1)] : 0.f;
+            float hv = h[min(i + u, i1 - 1)];          // read first, select second: as "cond ? h[..] : 0" every read becomes a branch around it
+            hv = (i + u < i1) ? hv : 0.f;
             acc.x = fmaf(w[u].x, hv, acc.x); acc.y = fmaf(w[u].y, hv, acc.y);
             acc.z = fmaf(w[u].z, hv, acc.z); acc.w = fmaf(w[u].w, hv, acc.w);
         }
