@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void lbfgs_round(LbState* Sm, LbVecs<T>* Vl, const Lb
         (void)ph_in;
         if (which == 1) need = lb_fast_resume<T>(Sm, Vl, W, O, xt, lane);
         else if (!virt) need = lb_fast_accept<T>(Sm, Vl, Hh, W, O, fv, gv, lane);
-        if (need >= 0) { PH_W(32 + 2 * which, 0, t_call); PH_ADD(33 + 2 * which, 1); }      // [32,33] fast accept, [34,35] fast resume: cycles, calls
+        if (need >= 0) { PH_W(64 + 2 * which, 0, t_call); PH_ADD(65 + 2 * which, 1); }      // [64,65] fast accept, [66,67] fast resume: cycles, calls
 #ifdef MVFIT_LB_CHECK
         if (need >= 0) {           // the general machine on the snapshot must arrive at the same words (it rewrites the same history row / work vectors)
             T xt2[LB_EPL];
@@ -1110,9 +1110,9 @@ __device__ __forceinline__ void lbfgs_round(LbState* Sm, LbVecs<T>* Vl, const Lb
 #endif
         if (need < 0) {
             need = lbfgs_advance<T>(*Sm, Vl[lane], Hh, W, O, fv, gv, xt, lane, stage_final, virt);      // wave-uniform branch
-            // general machine: cycles and calls by the phase it was entered in ([36,37] step start, first trial, bracket, zoom,
-            // [44,45] behind a direction)
-            const int slot = 36 + 2 * min(ph_in, 4);
+            // general machine: cycles and calls by the phase it was entered in ([68,69] step start, first trial, bracket, zoom,
+            // [76,77] behind a direction)
+            const int slot = 68 + 2 * min(ph_in, 4);
             (void)slot;
             PH_W(slot, 0, t_call); PH_ADD(slot + 1, 1);
         }

@@ -2089,6 +2089,12 @@ extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing_adv(lon
     if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z), sizeof(long long) * 48); }
     return 0;
 }
+extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing_calls(long long* out16, int reset) {          // g_dbg[64..79]: optimiser calls by kind (lbfgs_round)
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16, sizeof(long long) * 64);
+    if (reset) { long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mvfit::g_dbg), z, sizeof(z), sizeof(long long) * 64); }
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int mvfit_debug_timing_helpers(long long* out16, int reset) {       // g_dbg[32..47]: decoder helper (set 0, slice 0)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out16, HIP_SYMBOL(mvfit::g_dbg), sizeof(long long) * 16, sizeof(long long) * 32);

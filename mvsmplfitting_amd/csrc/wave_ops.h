@@ -11,7 +11,7 @@ namespace mvfit {
 
 // developer build (-DMVFIT_TIMING): per-phase shader-clock accumulation of workgroup 0
 #ifdef MVFIT_TIMING
-static __device__ long long g_dbg[64];
+static __device__ long long g_dbg[96];
 static __device__ long long g_dbg_last;
 #define PH_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = clock64(); g_dbg[k] += now_ - g_dbg_last; g_dbg_last = now_; } } while (0)
 #define PH_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_last = clock64(); } while (0)

@@ -25,10 +25,12 @@ x0 = np.zeros((B,118), np.float32); x0[:,85]=1
 buf = (C.c_longlong*32)()
 hb = (C.c_longlong*16)()
 ab = (C.c_longlong*16)()
+cb = (C.c_longlong*16)()
 for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse', _lib.F_VPOSER|_lib.F_SPARSE_VERTS), ('vposer_sparse_helpers_off', _lib.F_VPOSER|_lib.F_SPARSE_VERTS)):
     eng.set_options(vposer_helpers=0 if name.endswith('off') else 1)
     lib.mvfit_debug_timing_helpers(hb, 1)
     lib.mvfit_debug_timing_adv(ab, 1)
+    lib.mvfit_debug_timing_calls(cb, 1)
     lib.mvfit_debug_timing(buf, 1)
     xf, st = eng.fit(x0, stage_weights(1536.0, flags=flags))
     lib.mvfit_debug_timing(buf, 1)
@@ -44,10 +46,10 @@ for name, flags in (('full',0), ('sparse',_lib.F_SPARSE_VERTS), ('vposer_sparse'
     lib.mvfit_debug_timing_helpers(hb, 1)
     print('    E9 probes (cycles per round): g_beta lanes done=%.0f | Rodrigues adjoint lanes done=%.0f | barrier behind both=%.0f' % (ab[8]/n, ab[9]/n, ab[10]/n))
     print('    basis streams (cycles per round, from the phase start): forward wave 1 / wave 7 done=%.0f / %.0f | transposed wave 1 / wave 7 done=%.0f / %.0f' % (ab[12]/n, ab[14]/n, ab[11]/n, ab[13]/n))
-    if not (flags & _lib.F_VPOSER):
-        nm = ['fast accept', 'fast resume', 'general: step start', 'general: first trial', 'general: bracket', 'general: zoom', 'general: behind a direction']
-        print('    optimiser calls (wave 0): ' + ' | '.join('%s %d x %.0f' % (nm[i], hb[2 * i + 1], hb[2 * i] / max(1, hb[2 * i + 1])) for i in range(7)) + ' cycles')
-    if hb[2]: print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
+    lib.mvfit_debug_timing_calls(cb, 1)
+    nm = ['fast accept', 'fast resume', 'general: step start', 'general: first trial', 'general: bracket', 'general: zoom', 'general: behind a direction']
+    print('    optimiser calls (wave 0): ' + ' | '.join('%s %d x %.0f' % (nm[i], cb[2 * i + 1], cb[2 * i] / max(1, cb[2 * i + 1])) for i in range(7)) + ' cycles')
+    if hb[2] and (flags & _lib.F_VPOSER): print('    decoder helper (set 0, slice 0): forward %.0f cycles per request (%d), adjoint %.0f (%d); poll iterations %d, with a request %d' % (hb[0]/max(1,hb[2]), hb[2], hb[1]/max(1,hb[3]), hb[3], hb[4], hb[5]))
     if buf[15]:
         sub = [buf[16+i]/buf[15] for i in range(6)]
         print('    compact direction (lb_direction_compact): %.0f cycles per call = ' % (sum(sub) + buf[11]/buf[15]) +
