@@ -1,5 +1,7 @@
 """Developer tool: A/B bit comparison of two builds of libmvfit on the same inputs - closure gradients at random points and
-whole fits (rounds, final parameters).  python tools/ab_bits.py <lib A> <lib B> [vposer|gmm]"""
+whole fits (rounds, final parameters).  python tools/ab_bits.py <lib A> <lib B> [vposer|gmm]
+The other build: `git stash; make -C mvsmplfitting_amd/csrc OUT=../libmvfit_old.so OBJDIR=build_old; git stash pop` (or a checkout of
+the commit to compare with); tools/ab_check.sh runs the three modes + the phase timing + three bench lines in one gpurun call."""
 import os
 import sys
 

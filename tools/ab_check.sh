@@ -1,3 +1,4 @@
+# gpurun driver: A/B bit comparison (tools/ab_bits.py, three modes) + phase timing + bench lines of the current build
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5j; rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+# gpurun driver: tests/phase_timing.py on the -DMVFIT_TIMING build -> gpurun_out/r5h/phase_timing.log
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5h; rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+# gpurun driver: profiles/r5_ab_bits.log, r5_phase_timing.log, r5_kernel_stats_configs3.csv
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5n; rm -rf $O; mkdir -p $O
