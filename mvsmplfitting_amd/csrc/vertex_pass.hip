@@ -1058,6 +1058,64 @@ __device__ __forceinline__ void wg_barrier_lds() {           // workgroup barrie
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- the polling wave of a resident workgroup (both resident kernels): wait for the operands of closure round r ----
+// Every problem of the sub-batch has published round r (tag >= r + 1) or finished before it (done_round <= r).  Verdicts:
+//   VR_GO      serve the round: ctl[1] = mask of the 32-problem chunks with a live problem;
+//   VR_DONE    every problem finished before this round: the fit is over;
+//   VR_TIMEOUT the operands did not arrive within 20 ms (wall clock): this workgroup leaves the launch;
+//   VR_LOST    a live problem's slot already holds a LATER round (this workgroup fell a whole ring behind - it was not resident
+//              in time, or the optimiser gave up waiting for it): the round is skipped, nothing is computed from operands of
+//              another round and nothing is stored; a workgroup that starts after the fit has ended runs through its rounds
+//              this way in a poll each instead of replaying them from stale slots.
+// Degradation is reported by EVERY workgroup (round 6; before, only workgroup 0 counted): stats[2] = the largest number of
+// (problem, round) operand sets any ONE workgroup lost (atomicMax of the workgroup's running total; all workgroups that keep
+// up report 0), stats[3] += 1 for every workgroup that timed out.  stats[0] / [1] (chunk passes run / skipped) stay
+// workgroup 0's: they describe the schedule, not a fault.
+enum : unsigned { VR_GO = 1u, VR_DONE = 2u, VR_TIMEOUT = 3u, VR_LOST = 4u };
+__device__ __forceinline__ void resident_poll(const ResidentArgs& RA, unsigned r, unsigned slot, unsigned nch, int lane, int wg,
+                                              unsigned* ctl, unsigned& lost_total) {
+    const unsigned want = r + 1u;
+    const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
+    const unsigned* dn = RA.done_round + RA.b_lo;
+    unsigned verdict = VR_GO, live_bits = 0u, missed = 0u;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+        live_bits = 0u; missed = 0u;
+        for (int p = lane; p < RA.n; p += 64) {
+            const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool live = d > r;                   // the problem evaluates (or evaluated) closure round r
+            ok = ok && (t >= want || !live);           // (a larger tag: a later round already overwrote the slot)
+            if (live) live_bits |= 1u << (p >> 5);
+            if (live && t > want) ++missed;
+        }
+        if (__all(ok)) break;
+        if (wall_clock64() - t0 > 2000000) { verdict = VR_TIMEOUT; break; }            // 20 ms at 100 MHz
+        __builtin_amdgcn_s_sleep(32);
+    }
+    unsigned mask = 0u;
+    for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
+    if (verdict == VR_GO && mask == 0u) verdict = VR_DONE;     // every problem finished before this round: the fit is over
+    if (verdict == VR_GO && __ballot(missed != 0u)) {          // operands overwritten before this workgroup read them
+        unsigned msum = missed;
+        for (int o = 32; o; o >>= 1) msum += __shfl_xor(msum, o);
+        lost_total += msum;
+        verdict = VR_LOST;
+        if (lane == 0) atomicMax(RA.stats + 2, lost_total);
+    }
+    if (lane == 0) {
+        ctl[0] = verdict; ctl[1] = mask;
+        const long long ts = wall_clock64();
+        ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
+        if (wg == 0 && verdict == VR_GO) {
+            atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
+            if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
+        }
+        if (verdict == VR_TIMEOUT) atomicAdd(RA.stats + 3, 1u);
+    }
+}
+
 template <int TPW, bool HALF>
 __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lbs_vertex_pass_resident_kernel(DevModel M, ResidentArgs RA) {
     // separate LDS objects (alias information for the wait-count pass, see above)
@@ -1166,55 +1224,20 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     };
 
+    unsigned lost_total = 0u;                                   // (polling wave) operand sets this workgroup lost so far
     for (unsigned r = 0; r < RA.max_rounds; ++r) {
         const unsigned slot = r % (unsigned)RA.nslots;
         // ---- wave 7: wait for the operands of closure round r (every problem: published, or finished before r) ----
-        if (wave == 7) {
-            const int lane = tid_k & 63;
-            const unsigned want = r + 1u;
-            const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
-            const unsigned* dn = RA.done_round + RA.b_lo;
-            unsigned verdict = 1u, live_bits = 0u, missed = 0u;
-            const long long t0 = wall_clock64();
-            for (;;) {
-                bool ok = true;
-                live_bits = 0u; missed = 0u;
-                for (int p = lane; p < RA.n; p += 64) {
-                    const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool live = d > r;                   // the problem evaluates (or evaluated) closure round r
-                    ok = ok && (t >= want || !live);           // (a larger tag: a later round already overwrote the slot)
-                    if (live) live_bits |= 1u << (p >> 5);
-                    if (live && t > want) ++missed;
-                }
-                if (__all(ok)) break;
-                if (wall_clock64() - t0 > 2000000) { verdict = 3u; break; }            // 20 ms at 100 MHz
-                __builtin_amdgcn_s_sleep(32);
-            }
-            unsigned mask = 0u;
-            for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
-            if (verdict == 1u && mask == 0u) verdict = 2u;     // every problem finished before this round: the fit is over
-            const unsigned long long miss_b = __ballot(missed != 0u);
-            if (lane == 0) {
-                ctl[0] = verdict; ctl[1] = mask;
-                const long long ts = wall_clock64();
-                ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
-                if (wg == 0 && verdict == 1u) {
-                    atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
-                    if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
-                }
-                if (wg == 0 && verdict == 3u) atomicAdd(RA.stats + 3, 1u);
-            }
-            if (wg == 0 && miss_b) {                           // operands overwritten before this pass read them
-                unsigned msum = missed;
-                for (int o = 32; o; o >>= 1) msum += __shfl_xor(msum, o);
-                if (lane == 0) atomicAdd(RA.stats + 2, msum);
-            }
-        }
+        if (wave == 7) resident_poll(RA, r, slot, nch, tid_k & 63, wg, ctl, lost_total);
         __syncthreads();
         const unsigned verdict = ctl[0];
         unsigned mask = ctl[1];
-        if (verdict != 1u) break;                              // uniform
+        if (verdict == VR_LOST) {                              // uniform: skip the round (see resident_poll)
+            __syncthreads();                                   // (every wave has read ctl before wave 7 polls the next round)
+            if (tid_k == 0) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (verdict != VR_GO) break;                           // uniform
         float* vout = (RA.capture_verts && (int)r == RA.capture_round) ? RA.capture_verts : RA.verts;
 
         // ---- the round's first live chunk: nothing to overlap its operands with ----
@@ -1460,6 +1483,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     //   Y (apply done / next operands landed).
     if (wave < 4) {
         // ======================================== contraction waves ========================================
+#if defined(VPX) && (VPX & 1)
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const int t_w = wave & 1, kh_w = (wave >> 1) & 1;                      // this wave's tile and K half
         float4 bh[3][VP_BPW], bl[HALF ? 1 : 3][HALF ? 1 : VP_BPW];
         {
@@ -1508,6 +1534,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // the wave's three chains: small products first, one accumulator per plane.  The A operands of block g + 1 are read
         // into the SAME registers as soon as block g's MFMAs that take them have issued (an MFMA reads its operands at issue):
         // the lo words under six MFMAs, the hi words under the next block's first three - no second operand set (registers)
+        // (round 6: a second operand set - block g + 1's words requested before block g's nine MFMAs - measured: the same 3.0 k
+        // cycles per 63 MFMAs, i.e. the operand reads are not what holds the stream at 49 cycles per MFMA; 256 VGPRs: not kept)
         auto contract = [&](floatx16 (&acc)[3], int lane) {
 #pragma unroll
             for (int kc = 0; kc < 3; ++kc) {
@@ -1551,7 +1579,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             __syncthreads();                                                  // (S) wave 7's verdict
             const unsigned verdict = ctl[0];
             unsigned mask = ctl[1];
-            if (verdict != 1u) break;                                         // uniform
+            if (verdict == VR_LOST) { __syncthreads(); continue; }            // (S') round skipped (see resident_poll)
+            if (verdict != VR_GO) break;                                      // uniform
             int lane = tid_k & 63;
             asm volatile("" : "+v"(lane));                                    // (opaque copy: no address hoisting out of the round loop)
             unsigned c = (unsigned)__builtin_ctz(mask);
@@ -1608,7 +1637,11 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     }
 
     // ================================================ workers ================================================
+#if defined(VPX) && (VPX & 4)
+    const bool store_nt = false;
+#else
     const bool store_nt = VP_NT_LOADS && !(RA.flags & 2u);
+#endif
     const float inv_scale = 1.0f / M.bs_scale;
     {
         const int wt = tid_k - 256;
@@ -1616,59 +1649,45 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         else if (wt < 128) sj_l[wt - 64] = __builtin_bit_cast(i32x4, M.wsp_j[(size_t)min(wg * TPW + ((wt - 64) >> 5), M.ntiles - 1) * TILE_V + (wt & 31)]);
     }
     __syncthreads();
+    // Round 6: the two vertices of a thread's pair mostly hang on the SAME four joints (neighbours in the mesh: 93 % of the pairs
+    // of the synthetic body, most of SMPL's) - then the second vertex blends the transform rows the first one fetched (other
+    // weights, the same rows: the same products in the same order, bit-identical) and the pair costs 24 LDS gathers instead of
+    // 48.  The gathers were the blend phase's bound: 4 worker waves x 96 ds_read_b128 = 3.1 k cycles of LDS port per chunk
+    // (profiles/r5_pmc_lds_resident.json: 2.9 k measured) against 1.8 k cycles of FMA issue.
+    bool pair_same[TPW];
+    {
+        const int vp2 = (tid_k - 256) & 15;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const i32x4 a = sj_l[t * 32 + 2 * vp2], b = sj_l[t * 32 + 2 * vp2 + 1];
+            pair_same[t] = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+        }
+    }
+    unsigned lost_total = 0u;                                   // (polling wave) operand sets this workgroup lost so far
     for (unsigned r = 0; r < RA.max_rounds; ++r) {
         const unsigned slot = r % (unsigned)RA.nslots;
         // ---- wave 7: wait for the operands of closure round r (every problem: published, or finished before r) ----
-        if (wave == 7) {
-            const int lane = tid_k & 63;
-            const unsigned want = r + 1u;
-            const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
-            const unsigned* dn = RA.done_round + RA.b_lo;
-            unsigned verdict = 1u, live_bits = 0u, missed = 0u;
-            const long long t0 = wall_clock64();
-            for (;;) {
-                bool ok = true;
-                live_bits = 0u; missed = 0u;
-                for (int p = lane; p < RA.n; p += 64) {
-                    const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool live = d > r;
-                    ok = ok && (t >= want || !live);
-                    if (live) live_bits |= 1u << (p >> 5);
-                    if (live && t > want) ++missed;
-                }
-                if (__all(ok)) break;
-                if (wall_clock64() - t0 > 2000000) { verdict = 3u; break; }            // 20 ms at 100 MHz
-                __builtin_amdgcn_s_sleep(32);
-            }
-            unsigned mask = 0u;
-            for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
-            if (verdict == 1u && mask == 0u) verdict = 2u;
-            const unsigned long long miss_b = __ballot(missed != 0u);
-            if (lane == 0) {
-                ctl[0] = verdict; ctl[1] = mask;
-                const long long ts = wall_clock64();
-                ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
-                if (wg == 0 && verdict == 1u) {
-                    atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
-                    if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
-                }
-                if (wg == 0 && verdict == 3u) atomicAdd(RA.stats + 3, 1u);
-            }
-            if (wg == 0 && miss_b) {
-                unsigned msum = missed;
-                for (int o = 32; o; o >>= 1) msum += __shfl_xor(msum, o);
-                if (lane == 0) atomicAdd(RA.stats + 2, msum);
-            }
-        }
+        if (wave == 7) resident_poll(RA, r, slot, nch, tid_k & 63, wg, ctl, lost_total);
         __syncthreads();                                                      // (S)
         const unsigned verdict = ctl[0];
         unsigned mask = ctl[1];
-        if (verdict != 1u) break;                                             // uniform
+        if (verdict == VR_LOST) {                                             // uniform: skip the round (see resident_poll)
+            __syncthreads();                                                  // (S') every wave has read ctl
+            if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (verdict != VR_GO) break;                                          // uniform
         float* vout = (RA.capture_verts && (int)r == RA.capture_round) ? RA.capture_verts : RA.verts;
         unsigned c = (unsigned)__builtin_ctz(mask);
         mask &= mask - 1u;
+#ifdef MVFIT_TIMING
+        const long long t_round = clock64();                                  // whole rounds (tests/vp_resident_timeline.py): S -> Q -> end
+        const bool t_full = __popc(ctl[1]) == 4;
+#endif
         wg_barrier_lds();                                                     // (Q)
+#ifdef MVFIT_TIMING
+        if (t_full) VP_T(4, t_round);
+#endif
         unsigned par = 0u;                                                    // transform buffer of the chunk being blended
         for (;;) {
             const int cn = mask ? __builtin_ctz(mask) : -1;
@@ -1684,9 +1703,13 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             // ---- four items per thread = (vertex pair vp2) x (problems q, q + 16) x (tiles 0, 1): blend all four (the
             //      transforms are then free for the next chunk's request) ----
             const int wt = tid - 256, vp2 = wt & 15, q = wt >> 4;
+            // (the blend as packed FMAs - v_pk_fma_f32 on (x, y) / (z, w) halves, 216 instead of 413 FMA instructions - measured
+            // SLOWER in round 6: 15.4 instead of 13.8 us per round; a packed fp32 FMA does not issue faster than two scalar ones
+            // here and the weight pairs cost 50 moves)
             float tr[4][2][3][4];                                             // [item = 2 t + e][vertex][row][4]
 #pragma unroll
-            for (int t = 0; t < TPW; ++t)
+            for (int t = 0; t < TPW; ++t) {
+                f32x4 rows[2][4][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f32x4 spw = sw_l[t * 32 + 2 * vp2 + i];
@@ -1695,17 +1718,19 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     const int jq[4] = {spj.x, spj.y, spj.z, spj.w};
                     // one vertex of the tile for BOTH of the thread's problems: 24 transform rows requested before the first
                     // product (one worker wave per SIMD: the latency of the LDS gathers is hidden by loads in flight, not by
-                    // other waves); ascending joint order per item: the non-zero products of the dense blend in the same order
-                    f32x4 rows[2][4][3];
+                    // other waves); ascending joint order per item: the non-zero products of the dense blend in the same order.
+                    // The pair's second vertex keeps the first one's rows when it hangs on the same joints (pair_same)
+                    if (i == 0 || !pair_same[t]) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                        for (int e = 0; e < 2; ++e)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const int at = (q + 16 * e) * (A_STRIDE / 4) + jq[u] * 3 + k;
-                                rows[e][u][k] = par ? A_1[at] : A_0[at];      // (uniform)
-                            }
+                                for (int k = 0; k < 3; ++k) {
+                                    const int at = (q + 16 * e) * (A_STRIDE / 4) + jq[u] * 3 + k;
+                                    rows[e][u][k] = par ? A_1[at] : A_0[at];      // (uniform)
+                                }
+                    }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -1731,16 +1756,45 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             const f32x4 tq0 = par ? tau_1[q] : tau_0[q], tq1 = par ? tau_1[q + 16] : tau_0[q + 16];
             VPW_T(1);
             wg_barrier_lds();                                                 // (P)
             VPW_T(2);
             // ---- K halves combined (fixed order), scale undone, T applied, "+ transl", stores straight from registers ----
+            // (24 contiguous bytes per item - vertices 2 vp2, 2 vp2 + 1 -, 8-byte aligned: even vertex count, checked by the host)
+            auto store_item = [&](const float (&o)[6], int t, int e, int tq) {
+                const int vbase = (wg * TPW + t) * TILE_V, vq = tq & 15;
+                const int b_me = RA.b_lo + (int)c * 32 + (tq >> 4) + 16 * e;
+                const int nv_ok = b_me < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;
+                float* dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vq) * 3;
+#if defined(VPX) && (VPX & 2)
+                if (o[0] == 1.2345e-30f) dst[0] = o[1] + o[2] + o[3] + o[4] + o[5];      // (experiment: no stores)
+#else
+                if (nv_ok >= 2) {
+                    const f32x2 q0 = {o[0], o[1]}, q1 = {o[2], o[3]}, q2 = {o[4], o[5]};
+                    if (store_nt) {
+                        __builtin_nontemporal_store(q0, reinterpret_cast<f32x2*>(dst));
+                        __builtin_nontemporal_store(q1, reinterpret_cast<f32x2*>(dst + 2));
+                        __builtin_nontemporal_store(q2, reinterpret_cast<f32x2*>(dst + 4));
+                    } else {
+                        *reinterpret_cast<f32x2*>(dst) = q0; *reinterpret_cast<f32x2*>(dst + 2) = q1; *reinterpret_cast<f32x2*>(dst + 4) = q2;
+                    }
+                } else if (nv_ok == 1) {
+                    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+                }
+#endif
+            };
+            // (Round 6, measured on the stores - a chunk's 24.6 KB cost the workers ~1 k of the apply's 2.2 k cycles: 14.0 -> 11.9 us
+            // per round WITHOUT them.  16 + 8 bytes per item, lane-pair 16-byte words by DPP, whole 1 KiB lines per instruction
+            // staged through the dead transform buffer (3.2 k), the last tile's stores behind (Y) (the wave blocks there instead),
+            // plain instead of non-temporal: none faster than three 8-byte stores per item - the CU's write path takes ~10 bytes
+            // per clock whatever the shape; profiles/r6_progress.md)
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tile = wg * TPW + t;
                 if (tile >= M.ntiles) break;                                  // uniform
-                const int vbase = tile * TILE_V, pt = t * (2 * 3 * 32 * 33);
+                const int pt = t * (2 * 3 * 32 * 33);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int bb = q + 16 * e;
@@ -1761,22 +1815,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                             o[3 * i + k] = fmaf(tr[2 * t + e][i][k][0], vp[0], fmaf(tr[2 * t + e][i][k][1], vp[1],
                                                 fmaf(tr[2 * t + e][i][k][2], vp[2], tr[2 * t + e][i][k][3]))) + tau3[k];
                     }
-                    const int b_me = RA.b_lo + (int)c * 32 + bb;
-                    const int nv_ok = b_me < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vp2 : 0;
-                    float* dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vp2) * 3;
-                    if (nv_ok >= 2) {
-                        // 24 contiguous bytes (vertices 2 vp2, 2 vp2 + 1), 8-byte aligned (even vertex count, checked by the host)
-                        const f32x2 q0 = {o[0], o[1]}, q1 = {o[2], o[3]}, q2 = {o[4], o[5]};
-                        if (store_nt) {
-                            __builtin_nontemporal_store(q0, reinterpret_cast<f32x2*>(dst));
-                            __builtin_nontemporal_store(q1, reinterpret_cast<f32x2*>(dst + 2));
-                            __builtin_nontemporal_store(q2, reinterpret_cast<f32x2*>(dst + 4));
-                        } else {
-                            *reinterpret_cast<f32x2*>(dst) = q0; *reinterpret_cast<f32x2*>(dst + 2) = q1; *reinterpret_cast<f32x2*>(dst + 4) = q2;
-                        }
-                    } else if (nv_ok == 1) {
-                        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
-                    }
+                    store_item(o, t, e, wt);
                 }
             }
             VPW_T(3);
@@ -1790,6 +1829,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             c = (unsigned)cn;
             par ^= 1u;
         }
+#ifdef MVFIT_TIMING
+        if (t_full) { VP_T(5, t_round); if (blockIdx.x == 5 && tid_k == 256) g_vp[8] += 1; }
+#endif
         // every operand of this round has been read (the contraction waves waited for their requests before the last (Y))
         if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (RA.log && r < (unsigned)RA.log_rounds) {                          // uniform (mvfit_profile only)

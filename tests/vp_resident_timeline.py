@@ -35,6 +35,10 @@ if form == 3:
         n = max(vb[7 + 8 * half] - base[7 + 8 * half], 1)
         print('  %s, %d middle chunks of workgroup 5, cumulative shader-clock cycles since the chunk start:' % (who, n))
         print('     ' + ' | '.join('%s=%.0f' % (nm[i], (vb[i + 8 * half] - base[i + 8 * half]) / n) for i in range(7) if nm[i] != '-'))
+    nr = max(vb[8] - base[8], 1)
+    print('  whole rounds with four live chunks (%d, worker wave): verdict -> first operands landed (barrier Q) %.0f cycles, -> round end %.0f '
+          'cycles; alone %.2f us per round -> the shader clock runs at >= %.2f GHz (the poll is not in the cycles)'
+          % (nr, (vb[12] - base[12]) / nr, (vb[13] - base[13]) / nr, alone * 1e3, (vb[13] - base[13]) / nr / (alone * 1e3) * 1e-3))
 else:
     names = ['contraction + partials written', 'barrier 1', 'next chunk requested', 'tile 0 blended / applied / stored', 'last tile done',
              'operand + store wait', 'closing barrier']
