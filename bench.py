@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 CONST_BYTES = 82680 + 826800 + 17114760 + 661440      # v_template + shapedirs + posedirs + lbs_weights
 PER_PROBLEM_BYTES = 2032 + 82680                      # (betas, pose_feature, A, transl) in + vertices out
-PMC_JSON = os.path.join(ROOT, 'profiles', 'r4_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
+PMC_JSON = os.path.join(ROOT, 'profiles', 'r6_pmc.json')     # written by tools/pmc_vertex_pass.py from rocprofv3 --pmc passes
 # the imported reference itself (PyTorch CPU, create_fitting_closure + LBFGSLs + run_fitting) timed in the survey's
 # build container (it cannot travel to the GPU box): closures/s inside L-BFGS, 8 vCPUs
 SURVEY_REFERENCE_CLOSURES_PER_S = (74.0, 125.0)
@@ -66,7 +66,7 @@ def bytes_fwd(B, skin_topk=0, half_basis=False):
 
 
 def pmc_file():
-    for fn in (PMC_JSON, os.path.join(ROOT, 'profiles', 'r2_pmc.json')):
+    for fn in (PMC_JSON, os.path.join(ROOT, 'profiles', 'r5_pmc.json')):
         if os.path.isfile(fn):
             return fn
     return None
@@ -156,19 +156,42 @@ def measure_pmc_resident(B, timeout_s=120):
         shutil.rmtree(out, ignore_errors=True)
 
 
+SHADER_CLOCK_GHZ = 2.4           # MI355X_MICROARCH.md peak engine clock (the resident kernels were measured at ~2.0-2.05 GHz effective)
+FP32_VALU_TFLOPS = 157.3         # vector fp32 peak of the chip; per CU: / 256
+
+
+def true_bound(B, form, workgroups, half_basis=False):
+    """What a closure round of the RESIDENT vertex pass cannot be faster than, whatever the schedule (last review, item 1c):
+    the largest of
+      hbm    the bytes a round really moves (SURVEY 8(d)'s per-problem figure: operands in + 82,680 B of vertices out per problem;
+             the 18.2 MB of constants are read once per FIT) / 8 TB/s;
+      mfma   the matrix-pipe issue time of the busiest SIMD: 32 cycles per v_mfma_f32_32x32x16_f16, 21 per contraction chain
+             (14 with the half-width basis); form 1 (one tile per workgroup) puts 6 chains on 4 SIMDs - two on the busiest -,
+             form 3 (two tiles, role-split) 3 chains on every SIMD; per 32-problem chunk;
+      valu   the pass's fp32 vector work (skinning blend 4 x 12 FMAs, K halves combined, T applied, "+ transl": 130 flop per
+             vertex and problem) / the fp32 vector peak of the CUs the pass runs on.
+    Returns dict(us, which, components_us)."""
+    nch = -(-B // 32)
+    per_chain = 14 if half_basis else 21
+    chains_busiest = 2 if form == 1 else 3
+    comp = dict(hbm=PER_PROBLEM_BYTES * B / (HBM_PEAK_GBS * 1e9) * 1e6,
+                mfma=nch * chains_busiest * per_chain * 32 / (SHADER_CLOCK_GHZ * 1e3),
+                valu=6890 * B * 130 / (FP32_VALU_TFLOPS * 1e12 * max(workgroups, 1) / 256) * 1e6)
+    which = max(comp, key=comp.get)
+    return dict(us=comp[which], which=which, components_us={k: round(v, 3) for k, v in comp.items()})
+
+
 def resident_round_us(pp, round_period_us):
-    """The "launch duration" of a closure round of the resident pass, from the stamps of one profiled fit.  While the pass
-    keeps up with the optimiser (a round is served before the next one is published) that is the round's service SPAN: last
-    workgroup's stores acknowledged - first workgroup saw the operands.  When the passes are the slower side the workgroups
-    drift apart by up to the ring's depth, rounds overlap and the span says nothing about the pass; the rate-defining figure
-    is then the SLOWEST workgroup's own service time of the round.  Returns (us, which)."""
-    span, slow = pp['round_span_ms'] * 1e3, pp['slowest_workgroup_ms'] * 1e3
-    if round_period_us is None or span <= round_period_us:
-        return span, 'span'
-    return slow, 'slowest_workgroup'
+    """The "launch duration" of a closure round of the resident pass, from the stamps of one profiled fit: the round's service
+    SPAN - last workgroup's stores acknowledged minus first workgroup saw the operands.  Always the span (round 6; the earlier
+    lines switched to the slowest workgroup's own service time when the pass was the slower side - two figures under one key);
+    the slowest workgroup's time is reported next to it (`slowest_workgroup_us`, `frac_slowest_workgroup`), and `pass_keeps_up`
+    says whether a round is served before the optimiser publishes the next (else the workgroups drift apart by up to the ring's
+    depth, rounds overlap and the span overstates the pass).  Returns (us, 'span')."""
+    return pp['round_span_ms'] * 1e3, 'span'
 
 
-def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=None):
+def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=None, half_basis=False):
     """roofline object of the RESIDENT vertex pass (one launch per fit; csrc/vertex_pass.hip): the "launch duration" of a
     closure round is its service span stamped inside the kernel during one complete profiled fit - last workgroup's vertex
     stores acknowledged minus first workgroup saw the round's operands (wall clock, 10 ns) - because a per-round launch no
@@ -182,17 +205,28 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
     # once from HBM) - SURVEY 8(d)'s per-problem figure; the 18.2 MB of constants cross the memory system once per FIT
     moved = PER_PROBLEM_BYTES * B
     table = measure_pmc_resident(B) if with_pmc else None
+    tb = true_bound(B, pp['form'], pp['workgroups'], half_basis)
+    slow_us = pp['slowest_workgroup_ms'] * 1e3
     roof = dict(bound='hbm', kernel=pp['kernel'],
                 achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+                frac_basis='SURVEY 8(d) algorithmic bytes per LAUNCH (constants re-read every round) / avg_launch_us / 8 TB/s - the '
+                           'figure of the earlier rounds, kept for continuity; it is NOT the HBM utilisation of the resident pass, '
+                           'which reads the constants once per fit: see bound_true / frac_true and frac_of_peak_for_bytes_moved',
+                # the honest figure: the largest hardware floor of a round / the measured round
+                bound_true=tb['which'], bound_true_us=round(tb['us'], 3), bound_true_components_us=tb['components_us'],
+                frac_true=round(tb['us'] / (span_ms * 1e3), 4),
+                bound_true_note='max(bytes moved per round / 8 TB/s, matrix-pipe issue time of the busiest SIMD at %.1f GHz, fp32 '
+                                'vector flops / peak of the %d CUs the pass holds); the rest of the round is latency: the operands '
+                                'cannot be requested before the tags flip (poll + sc1 LDS-DMA ~1.5 us), one dependent MFMA chain, '
+                                'the CU write path (DESIGN 4.1)' % (SHADER_CLOCK_GHZ, pp['workgroups']),
                 algorithmic_bytes=nbytes, avg_launch_us=round(span_ms * 1e3, 2), avg_launch_is=which,
-                avg_launch_note=('resident pass: no per-round launch exists; this is the in-fit service span of a closure round '
-                                 '(max over workgroups of stores acknowledged - min over workgroups of operands seen), mean over '
-                                 'the %d rounds of one complete profiled fit' % pp['rounds_stamped']) if which == 'span' else
-                                ('resident pass, slower than the optimiser at this size: the workgroups drift apart and rounds overlap, '
-                                 'so the figure is the SLOWEST workgroup\'s own service time of a round (stores acknowledged - operands '
-                                 'seen), mean over the %d rounds of one complete profiled fit; round_span_us is reported beside it'
-                                 % pp['rounds_stamped']),
-                round_span_us=round(pp['round_span_ms'] * 1e3, 2), slowest_workgroup_us=round(pp['slowest_workgroup_ms'] * 1e3, 2),
+                avg_launch_note='resident pass: no per-round launch exists; this is the in-fit service span of a closure round '
+                                '(max over workgroups of stores acknowledged - min over workgroups of operands seen), mean over '
+                                'the %d rounds of one complete profiled fit' % pp['rounds_stamped'],
+                pass_keeps_up=None if round_period_us is None else bool(span_ms * 1e3 <= round_period_us),
+                optimiser_round_period_us=None if round_period_us is None else round(round_period_us, 2),
+                round_span_us=round(pp['round_span_ms'] * 1e3, 2), slowest_workgroup_us=round(slow_us, 2),
+                frac_slowest_workgroup=round(nbytes / (slow_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if slow_us > 0 else None,
                 workgroup_busy_us=round(pp['workgroup_busy_ms'] * 1e3, 2),
                 alone_per_round_us=round(alone_ms * 1e3, 2),
                 frac_alone=round(nbytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -205,6 +239,7 @@ def resident_roofline(eng, B, nbytes, pr, pp, passes, with_pmc, round_period_us=
                            'per fit, so frac can exceed what the bytes actually moved per round (bytes_moved_per_round_algorithmic) '
                            'would give - the pass is latency-bound, not bandwidth-bound',
                 traffic=None if table is None else table['traffic_bytes_per_round'],
+                frac_of_peak_for_traffic=None if table is None else round(table['traffic_bytes_per_round'] / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 traffic_source=None if table is None else
                 ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate passes collected in this run on %d '
                  'stand-alone dispatches of the resident kernel serving %d closure rounds from the ring (2 x FETCH_SIZE + WRITE_SIZE, '
@@ -478,6 +513,10 @@ def vertex_pass_variants(MvFit, syn, model, views, skin_topk):
                 avg_launch_us=round(ms * 1e3, 2), avg_launch_is=which, rounds=pr['vertex_pass_launches'],
                 round_span_us=round(pp['round_span_ms'] * 1e3, 2), slowest_workgroup_us=round(pp['slowest_workgroup_ms'] * 1e3, 2),
                 frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                frac_true=(round(true_bound(128, pp['form'], pp['workgroups'], env.get('contraction') == 'half_basis')['us'] / (ms * 1e3), 4)
+                           if pp['tiles_per_workgroup'] and ms > 0 else None),
+                bound_true=(true_bound(128, pp['form'], pp['workgroups'], env.get('contraction') == 'half_basis')
+                            if pp['tiles_per_workgroup'] else None),
                 workgroups=pp['workgroups'], workgroup_busy_us=round(pp['workgroup_busy_ms'] * 1e3, 2),
                 alone_per_round_us=round(min(eng.profile_resident_pass_ms(100) for _ in range(3)) * 1e3, 2) if pp['tiles_per_workgroup'] else None,
                 passes=stt['passes'],
@@ -751,9 +790,10 @@ def main():
         n_iter += int(nit_t.sum().item())
     n_max = int(counts[-1][0].max().item())
 
-    # max-over-ranks time, totals, per-rank busy time
+    # max-over-ranks time, totals, per-rank busy time, the form the vertex passes took on every rank
     tot_closure, tot_iter, tmax = n_closure, n_iter, dt
     busy_all = [round(1e3 * busy / args.steps, 3)]
+    form_all = [int(eng.pass_profile()['form'])] if not (args.sparse or sdf) else [None]
     if world > 1:
         import torch.distributed as dist
         red = torch.tensor([float(n_closure), float(n_iter), float(lost[0]), float(lost[1])], device=dev, dtype=torch.float64)
@@ -763,6 +803,10 @@ def main():
         bz = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(bz, torch.tensor([busy / args.steps * 1e3], device=dev, dtype=torch.float64))
         busy_all = [round(float(b.item()), 3) for b in bz]
+        if form_all[0] is not None:
+            fz = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(fz, torch.tensor([float(form_all[0])], device=dev, dtype=torch.float64))
+            form_all = [int(f.item()) for f in fz]
         assert gathered.shape[0] == total_frames
         tot_closure, tot_iter, tmax = int(red[0].item()), int(red[1].item()), float(tm.item())
         lost = [int(red[2].item()), int(red[3].item())]
@@ -799,7 +843,8 @@ def main():
         if resident:
             roof = resident_roofline(eng, B_pass, nbytes, pr, pp, passes,
                                      with_pmc=rank == 0 and world == 1 and not args.no_pmc and standard,
-                                     round_period_us=1e6 * tmax / args.steps / max(n_max, 1))
+                                     round_period_us=1e6 * tmax / args.steps / max(n_max, 1) / max(-(-B // B_pass), 1),
+                                     half_basis=half_basis)
         ms_b2b = min(eng.profile_vertex_pass_ms(64, as_in_async_fit=in_fit) for _ in range(3))
         ms_plain = min(eng.profile_vertex_pass_ms(64) for _ in range(3))
         ms_fit = pr['vertex_pass_ms'] if pr['vertex_pass_launches'] > 0 else ms_b2b
@@ -919,6 +964,10 @@ def main():
             'vertex_passes_lost_in_timed_fits': {'missed': lost[0], 'timed_out': lost[1]},
             'decoder_helpers_last_fit': decoder,
             'per_rank_busy_ms_per_step': busy_all,
+            # form of the vertex passes on every rank (mvfit_options::resident_pass: 1 / 3 = the resident pass, one launch per fit;
+            # 0 = a gate + a pass launch per closure round - expected only under --single-device, --resident-pass 0, dense skinning
+            # rows or the exact-fp32 contraction)
+            'per_rank_resident_form': form_all,
             # ranks that exchanged the results over RCCL in this run (0: one rank, or a gloo dry run) - no curve beyond one GPU
             # has been measured on hardware by the build sessions (one GPU per gpurun box)
             'rccl_ranks_seen': world if (world > 1 and args.dist_backend == 'nccl') else 0,
@@ -932,8 +981,15 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         if lost[0] or lost[1]:
-            out['invalid_reason'] = ('%d vertex passes lost their operands / %d gates timed out in the timed fits: "a full pass per '
-                                     'closure" does not hold for this run' % (lost[0], lost[1]))
+            out['invalid_reason'] = ('%d vertex passes lost their operands / %d waits given up in the timed fits (summed over the ranks): '
+                                     '"a full pass per closure" does not hold for this run' % (lost[0], lost[1]))
+        expect_resident = (args.resident_pass != 0 and not (args.single_device and world > 1) and bool(args.skin_topk) and
+                           args.skin_topk <= 4 and args.contraction != 'exact_fp32' and form_all[0] is not None)
+        if form_all[0] is not None and (len(set(form_all)) > 1 or (expect_resident and 0 in form_all)):
+            # never a quiet fallback: a rank that ran its passes as per-round launches (its fit did not get the CUs the resident
+            # pass needs - a shared device, a CU mask - or an earlier fit on its ctx timed out) measures another code path
+            out['invalid_reason'] = (out.get('invalid_reason', '') + ' ' if out.get('invalid_reason') else '') + \
+                ('ranks ran different vertex-pass forms or fell back to per-round launches: per_rank_resident_form = %s' % form_all)
         if demo:
             out['reference_fit'] = dict(final_loss_fp32=float(g['fit_final32']), final_loss_fp64=float(g['fit_final64']),
                                         closures_fp32=int(g['fit_ncl32'].sum()), closures_fp64=int(g['fit_ncl64'].sum()),

@@ -149,7 +149,8 @@ typedef struct mvfit_options {
                                       * next to the optimiser's), 0 a gate + a pass launch per closure round, 1 / 2 resident with
                                       * that many vertex tiles per workgroup, 3 resident with two tiles per workgroup and the
                                       * workgroup split into contraction and worker waves (a forced value that does not fit
-                                      * stalls the fit).
+                                      * stalls the fit; round 6: forms 1 and 3 are the automatic choices - 216 workgroups beside
+                                      * <= 36 optimiser workgroups, 108 beside <= 144 -, form 2 was dropped: it maps to 3).
                                       * The resident pass assumes what the path's deployment gives it - one process per GPU
                                       * (SURVEY 8(e)): a fit's ~250 workgroups are resident together.  Processes (or concurrent
                                       * ctxs) that SHARE a device should set 0: waiting for one another's CUs they would exhaust
@@ -161,11 +162,19 @@ typedef struct mvfit_options {
                                       * to the walk); 0: the walk over every face for every vertex / voxel */
     int32_t vposer_helpers;          /* 1 (default): the single-launch fits decode VPoser on helper workgroups; 0: in the
                                       * problems' own workgroups (another summation order: last-bit differences) */
-    int32_t vposer_sets;             /* 0: automatic; n: helper sets of a launch (clamped to what the problems need / fit) */
+    int32_t vposer_sets;             /* 0: automatic (16 sets for <= 32 problems, else 8; asynchronous fits take 8 where 16 would
+                                      * leave no CUs for the resident vertex pass); n: helper sets of a launch (clamped to what
+                                      * the problems need / fit).  Results do not depend on it */
     int32_t closure_vposer_helpers;  /* 1: mvfit_closure (MVFIT_F_VPOSER, no SDF term, B <= 160) decodes on helper workgroups
                                       * of its own launch - the decoder arithmetic of the fits, for parity tests (0) */
-    int32_t pass_kernel;             /* per-round launch kernels at more than 32 problems: 0 automatic (two-role pipeline),
-                                      * 1 one workgroup per (tile, chunk), 2 lock-step chunk loop */
+    int32_t pass_kernel;             /* per-round launch kernels at more than 32 problems: 0 automatic (two-role pipeline; dense
+                                      * skinning rows: the lock-step chunk loop), 1 one workgroup per (tile, chunk); 2 = 0 (the
+                                      * lock-step loop for <= 4 weights per vertex was dropped in round 6) */
+    int32_t sdf_service;             /* 1 (default): in a two-phase fit (sdf_two_phase) the stages WITH the SDF term also run in the
+                                      * single-launch optimiser kernel, which asks for the term every closure round - gate ->
+                                      * vertex pass -> term kernels per round on the pass stream, the pull-back answers through
+                                      * memory (fitting.py:352-393 unchanged: the same kernels compute the same S and adjoint);
+                                      * 0: those stages as chained rounds (pass -> term -> step kernel launch per round) */
 } mvfit_options;
 void mvfit_options_default(mvfit_options* opts);
 
@@ -238,8 +247,17 @@ int mvfit_fit(mvfit_ctx* ctx, const mvfit_weights* stage_weights, const mvfit_lb
               float* params, float* final_loss, int32_t* n_closure, int32_t* n_iter);
 
 /* Counters of the vertex passes of the last mvfit_fit in its asynchronous mode (all zero in the other modes):
- * out4 = { chunk passes (32 problems x 6890 vertices) run, chunk passes skipped because all their problems had finished, pose operands overwritten before
- * their pass read them (expected 0), passes that gave up waiting for their operands (expected 0) }. */
+ *   out4[0]  chunk passes (32 problems x 6890 vertices) run;
+ *   out4[1]  chunk passes skipped because all their problems had finished;
+ *   out4[2]  pose operands lost (expected 0): per-round launches - (problem, round) operand sets overwritten before their pass
+ *            read them; resident pass - the LARGEST number of (problem, round) operand sets any one of its workgroups found
+ *            overwritten (every workgroup reports; such a round is skipped by that workgroup, never computed from another
+ *            round's operands);
+ *   out4[3]  waits given up (expected 0): gate kernels / resident workgroups that waited 20 ms for operands and left + problems
+ *            whose optimiser waited 20 ms for the ring's back-pressure and stopped honouring it.
+ * A non-zero out4[2] or out4[3] means "every closure round got its full vertex pass" does not hold for that fit (the fitted
+ * parameters never depend on the passes); with mvfit_options::resident_pass = -1 the ctx then runs its later fits with
+ * per-round launches (until mvfit_set_options is called). */
 int mvfit_fit_stats(mvfit_ctx* ctx, uint32_t* out4);
 
 /* Counters of the decoder helpers of the last mvfit_fit.  With MVFIT_F_VPOSER the single-launch fits (asynchronous and

@@ -66,6 +66,11 @@ struct VpBlock {                    // VPoser decoder state of the current trial
 static_assert(sizeof(ObsBlock) % 16 == 0 && sizeof(PoseBlock) % 16 == 0 && sizeof(OptBlock) % 16 == 0 && sizeof(VpBlock) % 16 == 0,
               "16-byte blocks");
 
+// The SDF term's per-problem result (SdfAdj, sdf_term.hip) is written by ANOTHER kernel - in the chained rounds a launch
+// boundary earlier, in the service rounds of the single-launch fit (round 6) while this kernel runs, on CUs of any XCD: read at
+// agent scope (sc1: past this CU's L1 and this XCD's L2, which may hold the previous round's line).
+__device__ __forceinline__ float sdf_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct ClosureLds {
     ModelLds M;                     // model constants
     __attribute__((aligned(16))) ObsBlock obs;
@@ -98,7 +103,8 @@ struct ClosureLds {
     unsigned vp_seq;                // decoder service (vposer_service.h): number of the last request of this problem
     int vp_remote;                  // 1: the decoder layers run on the launch's helper workgroups
     const SdfAdj* sdf_adj;          // SDF term of this problem (sdf_term.hip), or null
-    float sdf_fac, sdf_pad;         // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
+    float sdf_fac;                  // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
+    unsigned sh_sdf_ok;             // service rounds: the answer arrived (0: timed out)
     double total;
     double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
@@ -870,7 +876,7 @@ __device__ __forceinline__ double loss_combine(const DevModel& M, ClosureLds& L,
     double l_coll = 0.0;
     float sdf_fac = 0.f;
     if (L.sdf_adj && W.coll_w > 0.f) {
-        const float S = L.sdf_adj->S;
+        const float S = sdf_ld(&L.sdf_adj->S);
         const double ws = (double)W.coll_w * (double)S;
         l_coll = ws * ws;
         sdf_fac = 2.f * W.coll_w * W.coll_w * S;
@@ -1214,7 +1220,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
         if (g == 0) {
             if (sdf_fac != 0.f) {                          // + the SDF term's dense-vertex part of g_A
 #pragma unroll
-                for (int e = 0; e < 12; ++e) acc[e] = fmaf(sdf_fac, L.sdf_adj->gA[j * 12 + e], acc[e]);
+                for (int e = 0; e < 12; ++e) acc[e] = fmaf(sdf_fac, sdf_ld(&L.sdf_adj->gA[j * 12 + e]), acc[e]);
             }
             // A_j = [Gr_j | Gt_j - Gr_j J_j]:  g_Gt = g_At ; g_Gr = g_Ar - g_At J^T ; g_J = -Gr^T g_At
             const float J0 = L.pose.J[j][0], J1 = L.pose.J[j][1], J2 = L.pose.J[j][2];
@@ -1285,7 +1291,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
             else {
                 float gc = 0.f;
                 for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 9 * (j - 1) + 3 * mm + c];
-                if (sdf_fac != 0.f) gc = fmaf(sdf_fac, L.sdf_adj->gcoef[9 * (j - 1) + 3 * mm + c], gc);
+                if (sdf_fac != 0.f) gc = fmaf(sdf_fac, sdf_ld(&L.sdf_adj->gcoef[9 * (j - 1) + 3 * mm + c]), gc);
                 gr = v + gc;
             }
             L.gR[j][3 * mm + c] = gr;
@@ -1333,7 +1339,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
         if (g == 0) {
             float gc = 0.f;
             for (int k = 0; k < ncs; ++k) gc += L.scratch[k * KROWS + 207 + l];
-            if (sdf_fac != 0.f) gc = fmaf(sdf_fac, L.sdf_adj->gcoef[207 + l], gc);
+            if (sdf_fac != 0.f) gc = fmaf(sdf_fac, sdf_ld(&L.sdf_adj->gcoef[207 + l]), gc);
             s += gc;
             if (!(W.flags & MVFIT_F_FIX_SHAPE)) s += 2.f * L.opt.x[X_BETAS + l] * W.shape_w * W.shape_w;
             L.gbeta[l] = s;
@@ -1355,7 +1361,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
         // (fitting.py:328, d/dz |z|^2 w^2; the decoder's adjoint adds to it behind the barrier), zero padding
         const int i = X_TR + (tid - 449) + (tid - 449 >= 3 ? 1 : 0);           // X_TR .. X_TR + 2, X_EMB .. DPAD - 1
         float g = 0.f;
-        if (i < X_SC) { g = L.gtau[i - X_TR]; if (sdf_fac != 0.f) g = fmaf(sdf_fac, L.sdf_adj->gtau[i - X_TR], g); }
+        if (i < X_SC) { g = L.gtau[i - X_TR]; if (sdf_fac != 0.f) g = fmaf(sdf_fac, sdf_ld(&L.sdf_adj->gtau[i - X_TR]), g); }
         else if (i < DV) g = use_vp ? 2.f * L.opt.x[i] * wp2 : 0.f;
         L.grad[i] = g;
     } else if (tid < NJ) {
@@ -1466,7 +1472,8 @@ __device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRin
     // not cover this round (it grows by ~nslots between two reads when the passes keep up: a few polls per fit).  Only this
     // wave waits - it idles through the loss phase anyway; when the passes are slower than the optimiser the whole
     // workgroup ends up waiting for it at the next barrier, i.e. the optimiser runs at the passes' rate.  Bounded by the
-    // wall clock (20 ms): a stuck pass stream cannot hang the fit (the overwritten slot is then counted as missed).
+    // wall clock (20 ms): a stuck pass stream cannot hang the fit (the give-up is counted in stats[3]; a resident workgroup that
+    // finds its slot overwritten skips the round and counts the lost operand sets in stats[2]).
     if (round >= (unsigned)R.nslots) {
         const unsigned need = round - (unsigned)R.nslots + 1u;
         unsigned have = L.sh_pass_done;
@@ -1482,7 +1489,11 @@ __device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRin
                 if (have >= need) break;
                 // timed out: stop waiting for the passes for the rest of this fit (the overwritten slots are counted as
                 // missed by the pass and fit() reports them) instead of stalling 20 ms in every further round
-                if (wall_clock64() - t0 > 2000000) { have = 0xffffffffu; break; }
+                if (wall_clock64() - t0 > 2000000) {
+                    have = 0xffffffffu;
+                    if (l == 0) atomicAdd(R.stats + 3, 1u);       // never silent: this problem gave up on the back-pressure (mvfit_fit_stats)
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(16);
             }
             if (l == 0) L.sh_pass_done = have;
@@ -1524,6 +1535,43 @@ __device__ __forceinline__ void publish_tag(const AsyncRing& R, int slot, int b,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if ((tid & 63) == 0) __hip_atomic_store(R.tag + (size_t)slot * R.Bpad + b, round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SDF term as a service beside the single-launch fit (round 6; fitting.py:352-393).  In a stage with coll_loss_weight > 0 the
+// loss needs S = sum of phi over ALL 6890 vertices of the trial point and its adjoint (SdfAdj).  The optimiser kernel stays
+// resident (state and history in LDS, compact direction) and asks for them: in such a round the publishing wave writes, on top
+// of the ring operands, the float32 coefficients the pull-back contracts with (the chained rounds' coefT layout) and the
+// problem's gate word, drains its stores and publishes the tag AT ONCE; the host has queued gate -> vertex pass -> SDF front
+// -> pull-back for the round on the pass stream; the pull-back's reducing workgroup publishes the answer tag behind its
+// write-through result, and the workgroup continues with the loss.  Per round: one memory hop to the gate kernel, three
+// launches, one hop back - no optimiser state reload, no step-kernel launch, the forward of the trial point already done.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish_sdf_request(const ClosureLds& L, const DevPose& P, int* gate, int b, int on, int tid) {
+    const int l = tid - 64 * PUBLISH_WAVE;
+    if (l < 0 || l >= 64) return;
+    if (on) {
+        float* ct = P.coefT + (size_t)(b >> 5) * KROWS * 32 + (b & 31);
+        for (int p = l; p < KROWS; p += 64) __hip_atomic_store(ct + p * 32, L.coef[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (l == 0) __hip_atomic_store(gate + b, on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait for the answer of round `want - 1` (the publishing wave polls with s_sleep, everybody else sleeps at the barrier).
+// Bounded by the wall clock (200 ms): returns false when the answer never came (the host stopped queueing rounds, a launch
+// failed) - the caller ends the problem with an error status, never with a silently missing term.
+__device__ __forceinline__ bool sdf_answer_wait(ClosureLds& L, const unsigned* tag, unsigned want, int tid) {
+    if ((tid >> 6) == PUBLISH_WAVE) {
+        unsigned ok = 1u;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (wall_clock64() - t0 > 20000000) { ok = 0u; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if ((tid & 63) == 0) L.sh_sdf_ok = ok;
+    }
+    __syncthreads();
+    return L.sh_sdf_ok != 0u;
 }
 
 }  // namespace mvfit

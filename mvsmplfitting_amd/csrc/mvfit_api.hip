@@ -32,7 +32,7 @@ hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t strea
 hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
-                           void* cull);
+                           void* cull, unsigned* answer_tag = nullptr, unsigned answer = 0u);
 size_t sdf_cull_bytes(int B, int num_faces);
 size_t sdf_op_ws_bytes(int B, int num_faces);
 bool sdf_op_uses_lists(int num_faces);
@@ -71,6 +71,7 @@ struct FitBuffers {
     VpBlock* vp;             // [B] VPoser decoder state of the current trial point (handed from launch to launch)
     const SdfAdj* sdf_adj;   // SDF term per problem (null: term not configured)
     int* sdf_gate;           // [B] 1 while the problem's current stage has coll_loss_weight > 0 and it is not done
+    unsigned* sdf_tag;       // [B] service rounds of the single-launch fit: answer tag (round + 1) written behind the SdfAdj
     float* trace;            // [B][trace_cap][DV + 1] (x_trial, loss) of the first closures of a fit (mvfit_fit_trace); may be null
     int trace_cap;
 };
@@ -226,11 +227,15 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // LEAN: the stage flags carry none of VPoser / GMM / 3-D term (the host checks) - said to the compiler as a fact about
 // the flag word, which lets it drop those branches from the round: 13 KB less code to stream through the instruction
 // cache every round (86 -> 73 KB), 1.2-1.6 % per fit (speed only: the result does not depend on it)
-template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false>
+// SDFS: the launch serves stages with the SDF term by asking for it (closure_device.h: publish_sdf_request / sdf_answer_wait);
+// sv = {pass operands of the chained layout (coefT), gate words, answer tags, global problem index, round offset of the launch}
+struct SdfService { const DevPose* P; int* gate; const unsigned* tag; int b; int round0; };
+template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false, bool SDFS = false>
 __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
-                          const AsyncRing& ring = AsyncRing{}, bool use_ring = false, int pb = 0) {
+                          const AsyncRing& ring = AsyncRing{}, bool use_ring = false, int pb = 0,
+                          const SdfService& sv = SdfService{nullptr, nullptr, nullptr, 0, 0}) {
     DevWeights W = L.sw[L.sh_stage];
     W.flags = __builtin_amdgcn_readfirstlane(W.flags);
     if constexpr (LEAN) {
@@ -251,9 +256,25 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     PH_T(2);
     // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
-    const unsigned a_round = use_ring ? (unsigned)L.opt.lbS.n_closure : 0u;      // closures consumed so far = this round
+    const unsigned a_round = use_ring ? (unsigned)(L.opt.lbS.n_closure - (SDFS ? sv.round0 : 0)) : 0u;      // closures consumed so far (in this launch) = this round
     const int a_slot = use_ring ? (int)(a_round % (unsigned)ring.nslots) : 0;
     if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, tid);
+    bool sdf_round = false;
+    if constexpr (SDFS) {
+        // a stage that carries the interpenetration term: ask for S and its adjoint at this trial point (the tag goes out at
+        // once: the round's passes and the term's kernels are queued behind it) and wait for the answer
+        sdf_round = use_ring && L.sdf_adj != nullptr && W.coll_w > 0.f;           // block-uniform
+        if (use_ring) publish_sdf_request(L, *sv.P, sv.gate, sv.b, sdf_round ? 1 : 0, tid);
+        if (sdf_round) {
+            publish_tag(ring, a_slot, pb, a_round, tid);
+            if (!sdf_answer_wait(L, sv.tag + sv.b, a_round + 1u, tid)) {
+                // never a silently missing term: the problem ends here (final loss NaN), the host fails the fit (stats[3])
+                if (tid == 0) { atomicAdd(ring.stats + 3, 1u); L.opt.lbS.status = 1; L.sh_status = 1; }
+                __syncthreads();
+                return true;
+            }
+        }
+    }
     loss_and_keypoint_grad<true>(M, L, nviews, W, true, tid);          // (scalar terms combined under the adjoint's first phase)
     PH_T(3);
     closure_backward<REMOTE, true>(M, L, nviews, W, tid);
@@ -265,7 +286,7 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
             if (tid == 0) trace[(size_t)k * (DV + 1) + DV] = (float)total;
         }
     }
-    if (use_ring) publish_tag(ring, a_slot, pb, a_round, tid);             // the stores have long drained by now
+    if (use_ring && !sdf_round) publish_tag(ring, a_slot, pb, a_round, tid);             // the stores have long drained by now
     PH_T(8);
     float gnew[LB_EPL], xt[LB_EPL];
     const int D = dact(use_vp);
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 // history ring lives in LDS behind the closure workspace.
 // REMOTE: the launch carries VPoser decoder helpers behind the problems' workgroups (vposer_service.h); launches without
 // them run the instantiation that has no trace of the service.
-template <bool REMOTE, bool REUSE, bool LEAN>
+template <bool REMOTE, bool REUSE, bool LEAN, bool SDFS = false>
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
                                                                  int max_rounds, AsyncRing ring, int b_lo, int done_target,
@@ -394,13 +415,23 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     float* hist = reinterpret_cast<float*>(smem_raw + (LEAN ? persistent_tail_offset(false) : persistent_tail_offset(vp_mode)));   // [2][100][ldh]
     float* rinv = hist + 2 * LB_HIST * ldh;                                              // [LB_RPACK]
     const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + nprob): one sub-batch of mvfit_fit
-    prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid);
+    prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid, SDFS && F.sdf_adj ? F.sdf_adj + b : nullptr);
     opts_in(L, SW, O, tid);
     __syncthreads();
+    // closure rounds of THIS launch count from 0 (ring slots, tags, done_round): a service launch continues fits whose problems
+    // have spent different numbers of closures in the stages before it
+    const int round0 = SDFS ? L.opt.lbS.n_closure : 0;
     if (L.opt.lbS.status != 0) {
         if (REMOTE && tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
-        if (tid == 0 && ring.tag)           // finished in an earlier launch: no pass waits for this problem
-            __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && ring.tag) {         // finished in an earlier launch: no pass waits for this problem
+            __hip_atomic_store(ring.done_round + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (SDFS) {                     // (the host counts the problems that left this launch)
+                __hip_atomic_store(F.sdf_gate + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int left = atomicAdd(F.n_done + 1, 1) + 1;
+                atomicAdd(F.n_done + 2, 1);
+                if (left == done_target) __hip_atomic_store(ring.host_done, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
     if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
@@ -429,9 +460,10 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round<REMOTE, REUSE, LEAN, true>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
+        done = fit_round<REMOTE, REUSE, LEAN, true, SDFS>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
-                         ring, ring.tag != nullptr, (int)blockIdx.x);       // ring slots: sub-batch-relative problem index
+                         ring, ring.tag != nullptr, (int)blockIdx.x,        // ring slots: sub-batch-relative problem index
+                         SdfService{&P, F.sdf_gate, F.sdf_tag, b, round0});
         if (done) break;                                  // block-uniform
         if (L.sh_stage != stage_prev) {
             // a new stage starts with a fresh optimiser (non_linear_solver.py:172): its history is empty, and the branch-free
@@ -448,8 +480,10 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
     // passes of later rounds have nothing to wait for from this problem - whatever ended the launch for it (finished, paused
     // at a stage boundary, or the round cap: the resident pass ends when every problem has said so)
-    if (tid == 0 && ring.tag)
-        __hip_atomic_store(ring.done_round + b, (unsigned)L.opt.lbS.n_closure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && ring.tag) {
+        __hip_atomic_store(ring.done_round + b, (unsigned)(L.opt.lbS.n_closure - round0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (SDFS) __hip_atomic_store(F.sdf_gate + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0 && (done || paused)) {
         if (done) atomicAdd(F.n_done, 1);
         const int left = atomicAdd(F.n_done + 1, 1) + 1;
@@ -629,6 +663,7 @@ struct mvfit_ctx {
     mvfit_options opt{};               // precision / path selectors (include/mvfit.h); the library reads no environment variable
     int n_cu = 0;                      // compute units of the device (residency of the resident vertex pass)
     int resident_tpw = 0;              // tiles per workgroup of the resident pass in the last asynchronous fit (0: per-round launches)
+    bool resident_auto_off = false;    // automatic resident_pass: a fit on this ctx timed out waiting - later fits use per-round launches
     unsigned long long* d_vp_log = nullptr;     // mvfit_profile: per-round stamps of the resident pass [kVpLogRounds][grid][2]
     size_t vp_log_words = 0;
     double res_span_ms = 0.0, res_busy_ms = 0.0, res_slowest_ms = 0.0;   // per round: service span / mean workgroup busy time / slowest workgroup (last profiled fit)
@@ -717,6 +752,7 @@ extern "C" void mvfit_options_default(mvfit_options* o) {
     o->sdf_two_phase = 1;
     o->sdf_face_lists = 1;
     o->vposer_helpers = 1;
+    o->sdf_service = 1;
 }
 
 // a caller's struct (possibly shorter: an older header) over the defaults; range checks
@@ -761,6 +797,7 @@ extern "C" int mvfit_set_options(mvfit_ctx* c, const mvfit_options* opts) {
         if (o.sdf_face_lists != c->opt.sdf_face_lists) c->sdf_cull_refused = false;
     }
     c->opt = o;
+    c->resident_auto_off = false;                        // (an explicit call re-arms the automatic resident_pass choice)
     return MVFIT_OK;
 }
 
@@ -1193,7 +1230,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.rinv, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
-                  c->d_sdf_adj, c->d_sdf_cull, c->F.sdf_gate, c->F.vp, c->d_gt3d, c->d_c3d};
+                  c->d_sdf_adj, c->d_sdf_cull, c->F.sdf_gate, c->F.sdf_tag, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
     {
         void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats, c->ring.pass_done};
@@ -1275,6 +1312,7 @@ extern "C" int mvfit_set_problems(mvfit_ctx* c, int B, int V, int cam_batched, c
         HIP_OK(c, hipMalloc(&c->F.stage_final, (size_t)B * MVFIT_MAX_STAGES * 8));
         HIP_OK(c, hipMalloc(&c->F.n_done, 12));
         HIP_OK(c, hipMalloc(&c->F.sdf_gate, (size_t)B * 4));
+        HIP_OK(c, hipMalloc(&c->F.sdf_tag, (size_t)Bpad * 4));
         HIP_OK(c, hipMalloc(&c->F.vp, (size_t)B * sizeof(VpBlock)));
         HIP_OK(c, hipMalloc(&c->d_gt3d, (size_t)B * NKP * 3 * 4));
         HIP_OK(c, hipMalloc(&c->d_c3d, (size_t)B * NKP * 4));
@@ -1662,24 +1700,37 @@ static bool vps_enabled(const mvfit_ctx* c, const StageWeights& SW) {
     return (SW.w[0].flags & MVFIT_F_VPOSER) && c->vps_mem && c->opt.vposer_helpers != 0;
 }
 
-// decoder-helper sets a single-launch fit of n problems carries (0: none)
-static int persistent_nsets(const mvfit_ctx* c, const StageWeights& SW, int n) {
+static int resident_tiles_per_wg(const mvfit_ctx* c, int opt_grid);
+
+// decoder-helper sets a single-launch fit of n problems carries (0: none).  with_passes: the launch is an asynchronous fit
+// (vertex passes beside it) - the automatic choice then keeps the RESIDENT pass: 16 sets next to <= 32 problems are 160
+// optimiser-kernel workgroups, which leave no room for the pass's 108; 8 sets (96 workgroups) do, and measure the same closure
+// rate (the mode is bound by the decoder hand-offs, profiles/r5_progress.md) - so the shipped yaml's default mode no longer
+// runs its passes as per-round launches (round 6).  Results do not depend on the number of sets (fixed summation order).
+static int persistent_nsets(const mvfit_ctx* c, const StageWeights& SW, int n, bool with_passes) {
     if (!(vps_enabled(c, SW) && n <= kVpsMaxSparse)) return 0;
     // few problems: 16 sets (two problems per helper at 32: less queueing behind another problem's request)
     const int cap = n <= 32 ? VPS_MAX_SETS : kVpsSets;
     // at least ceil(n / VPS_PMAX) sets: a set has VPS_PMAX request / answer slots (the knob cannot push problems past them)
     const int need = (n + VPS_PMAX - 1) / VPS_PMAX;
-    return std::max(need, std::min(c->opt.vposer_sets > 0 ? std::min(c->opt.vposer_sets, cap) : cap, n));
+    int want = c->opt.vposer_sets > 0 ? std::min(c->opt.vposer_sets, cap) : cap;
+    if (c->opt.vposer_sets <= 0 && with_passes && want > kVpsSets) {
+        const int full = std::max(need, std::min(want, n)), half = std::max(need, std::min(kVpsSets, n));
+        if (!resident_tiles_per_wg(c, n + full * VPS_SLICES) && resident_tiles_per_wg(c, n + half * VPS_SLICES)) want = kVpsSets;
+    }
+    return std::max(need, std::min(want, n));
 }
 // workgroups of that launch: one per problem + the helpers behind them, one CU each (LDS)
-static int persistent_grid(const mvfit_ctx* c, const StageWeights& SW, int n) { return n + persistent_nsets(c, SW, n) * VPS_SLICES; }
+static int persistent_grid(const mvfit_ctx* c, const StageWeights& SW, int n, bool with_passes) {
+    return n + persistent_nsets(c, SW, n, with_passes) * VPS_SLICES;
+}
 
 static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, const AsyncRing& R, int b_lo,
-                             int b_hi, int done_target, int pause_stage) {
+                             int b_hi, int done_target, int pause_stage, bool sdfs = false) {
     const int n = b_hi - b_lo;
     DevModel M = c->M;
     int grid = n;
-    if (const int nsets = persistent_nsets(c, SW, n)) {
+    if (const int nsets = persistent_nsets(c, SW, n, R.tag != nullptr)) {
         HIP_OK(c, hipMemsetAsync(c->vps_mem, 0, c->vps_words * 8, c->stream));
         M.vps.req = c->vps_mem;
         M.vps.resp = c->vps_mem + (size_t)VPS_MAX_SETS * VPS_PMAX * VPS_GRAN;
@@ -1691,7 +1742,10 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
         c->vps_stats[0] += 1;
     }
     const bool lean = !(SW.w[0].flags & (MVFIT_F_VPOSER | MVFIT_F_PRIOR_GMM | MVFIT_F_USE_3D));    // (flags are the same in all stages)
-    auto kern = M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true, false> : fit_persistent_kernel<true, false, false>)
+    // (service launches - the stages with the SDF term, mvfit_options::sdf_service - have their own instantiations: the other
+    // kernels carry no trace of the service; MVFIT_F_REUSE_OUTER_VALUE fits keep the chained rounds, see mvfit_fit)
+    auto kern = sdfs ? (M.vps.nsets ? fit_persistent_kernel<true, false, false, true> : fit_persistent_kernel<false, false, false, true>)
+                : M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true, false> : fit_persistent_kernel<true, false, false>)
                 : O.reuse_outer ? (lean ? fit_persistent_kernel<false, true, true> : fit_persistent_kernel<false, true, false>)
                 : lean ? fit_persistent_kernel<false, false, true> : fit_persistent_kernel<false, false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds((SW.w[0].flags & MVFIT_F_VPOSER) != 0), c->stream, M,
@@ -1710,28 +1764,40 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
 // worker waves (lbs_vertex_pass_resident_roles_kernel)
 static int resident_grid(const mvfit_ctx* c, int form) {
     if (!form) return 0;
-    const int tiles = form == 3 ? 2 : form;
+    const int tiles = form >= 2 ? 2 : 1;
     return (c->M.ntiles + tiles - 1) / tiles;
 }
 
 static int resident_tiles_per_wg(const mvfit_ctx* c, int opt_grid) {
     if (!c->M.bs_h2 || !c->M.wsp_w || (c->M.nv & 1)) return 0;      // (the resident pass stores vertex pairs: even vertex count)
-    if (c->opt.resident_pass >= 0) return c->opt.resident_pass;
+    if (c->opt.resident_pass >= 0) return c->opt.resident_pass == 2 ? 3 : c->opt.resident_pass;      // (form 2 was dropped: it maps to 3)
+    // automatic mode: a fit on this ctx whose resident workgroups (or whose optimiser) gave up waiting has shown that the launch
+    // does not get the CUs the choice assumes (a shared device, a CU mask): later fits use the per-round launches
+    if (c->resident_auto_off) return 0;
     const int room = c->n_cu - 4 - opt_grid;           // (4 CUs of slack: nothing in HIP promises that every CU takes a workgroup)
     if (c->M.ntiles <= room) return 1;
     if ((c->M.ntiles + 1) / 2 <= room) return 3;       // two tiles per workgroup, contraction / worker roles (15-20 % faster than form 2)
     return 0;
 }
 
-static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1) {
+// sdf_service: the launch continues fits that are paused in front of their first stage with the SDF term; every closure round
+// of such a stage asks for the term (closure_device.h: publish_sdf_request): per round the pass stream carries gate -> vertex
+// pass -> the term's kernels (launch_sdf_term, whose pull-back publishes the answer tag) - per-round launches by construction
+// (the term's kernels need the round's vertices complete: a launch boundary).
+static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, int* seen_out, int pause_stage = MVFIT_MAX_STAGES + 1,
+                     bool sdf_service = false) {
     const int B = c->B;
     // More problems than the optimiser gets CUs (one workgroup per CU, >= 96 CUs left to the passes): time-sliced in
     // sub-batches of whole 32-problem chunks, one after the other - every sub-batch is the same asynchronous fit (problems
     // are independent: the results do not depend on the slicing, tests/test_gpu_large_batch.py).
-    const bool want_resident = resident_tiles_per_wg(c, 0) != 0;
-    const int maxb = vps_enabled(c, SW) ? kVpsMaxAsync : (want_resident ? kResidentMaxB : kAsyncMaxB);
-    const int nsub = (B + maxb - 1) / maxb;
-    const int per = ((B + nsub - 1) / nsub + 31) / 32 * 32;
+    // (the sub-batch size follows from the form the passes REALLY take for the optimiser grid it gives: 128 problems beside the
+    // resident pass, 160 when the passes run as per-round launches anyway - dense skinning rows, a forced resident_pass = 0, ...)
+    const bool dbg_nopass = debug_hook("MVFIT_DEBUG_NOPASS") != 0;          // (hooks build only)
+    auto sub_batch = [&](int maxb) { const int nsub = (B + maxb - 1) / maxb; return ((B + nsub - 1) / nsub + 31) / 32 * 32; };
+    int per = sub_batch(vps_enabled(c, SW) ? kVpsMaxAsync : kResidentMaxB);
+    int tpw = (dbg_nopass || sdf_service) ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per), true));
+    if (!tpw && !vps_enabled(c, SW)) per = sub_batch(kAsyncMaxB);
+
     int rc = ensure_async(c, per);
     if (rc) return rc;
     AsyncRing R = c->ring;
@@ -1740,8 +1806,6 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     // polled words: re-initialised every call
     HIP_OK(c, hipMemsetAsync(R.done_round, 0xff, (size_t)c->Bpad * 4, c->stream));
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
-    const bool dbg_nopass = debug_hook("MVFIT_DEBUG_NOPASS") != 0;          // (hooks build only)
-    const int tpw = dbg_nopass ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per)));
     const int res_grid = resident_grid(c, tpw);
     if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
     c->resident_tpw = tpw;
@@ -1766,10 +1830,16 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         HIP_OK(c, hipMemsetAsync(R.tag, 0, (size_t)kRingSlots * rb * 4, c->stream));
         HIP_OK(c, hipMemsetAsync(R.pass_done, 0, 4 * kPassWords, c->stream));
         HIP_OK(c, hipMemsetAsync(c->F.n_done + 1, 0, 4, c->stream));
+        if (sdf_service) {
+            // per sub-batch: no answer yet, and no gate open - a problem opens its own in front of every round's tag (the gates of
+            // the problems outside this sub-batch stay shut: the term's kernels cover all problems up to b_hi)
+            HIP_OK(c, hipMemsetAsync(c->F.sdf_tag, 0, (size_t)c->Bpad * 4, c->stream));
+            HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, 0, (size_t)B * 4, c->stream));
+        }
         if (log_on) HIP_OK(c, hipMemsetAsync(c->d_vp_log, 0, c->vp_log_words * 8, c->stream));      // (a profiled fit keeps the last sub-batch's stamps)
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
-        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi - b_lo, pause_stage);
+        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi - b_lo, pause_stage, sdf_service);
         if (rc) return rc;
         int k = 0;
         if (tpw) {
@@ -1817,6 +1887,15 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                 }
                 if (e == hipSuccess) e = launch_vertex_pass(c->M, P, b_hi, vout, c->opt.pass_kernel, c->pass_stream, ea, eb);
                 if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "vertex pass launch: %s", hipGetErrorString(e));
+                if (sdf_service) {
+                    // the term at the round's vertices for the problems whose gate word is set (written by the optimiser in
+                    // front of the round's tag); transforms from the ring slot, float32 coefficients from the chained layout
+                    DevPose Ps = P;
+                    Ps.coefT = c->P.coefT;
+                    e = launch_sdf_term(c->M, Ps, vout, b_hi, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate, c->d_sdf_box,
+                                        c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, c->pass_stream, c->d_sdf_cull, c->F.sdf_tag, r + 1u);
+                    if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "SDF term launch: %s", hipGetErrorString(e));
+                }
             }
             HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
             if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
@@ -1834,6 +1913,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     HIP_OK(c, hipMemcpyAsync(c->h_done + 1, c->F.n_done + 2, 4, hipMemcpyDeviceToHost, c->stream));   // problems that left, all sub-batches
     HIP_OK(c, hipStreamSynchronize(c->stream));
     *seen_out = c->h_done[0];
+    if (tpw && c->opt.resident_pass < 0 && c->async_stats[3]) c->resident_auto_off = true;
     if (log_on) {
         // per round: service span = last workgroup's stores drained - first workgroup saw the operands; busy = a workgroup's own
         // drained - seen (wall clock, 100 MHz)
@@ -1926,6 +2006,12 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     while (lead < o->num_stages && !(sw[lead].coll_loss_weight > 0.f)) ++lead;
     const bool two_phase = any_sdf && lead >= 1 && lead < o->num_stages && c->M.bs_h2 != nullptr && !serial &&
                            c->opt.sdf_two_phase != 0;
+    // Round 6: the stages that carry the term run in the single-launch kernel too, with the term as a service (fit_async with
+    // sdf_service; also when the FIRST stage carries it: no lead phase then).  mvfit_options::sdf_service = 0 keeps the chained
+    // rounds - pass -> term -> step kernel per round -, which stay the checker of this path and the structure of profiled fits
+    // and of MVFIT_F_REUSE_OUTER_VALUE fits; sdf_two_phase = 0 (chained rounds in every stage) switches it off as well
+    const bool service = any_sdf && c->M.bs_h2 != nullptr && !serial && c->opt.sdf_two_phase != 0 && c->opt.sdf_service != 0 &&
+                         !O.reuse_outer && !c->profile;
     for (unsigned& v : c->async_stats) v = 0;
     for (unsigned& v : c->vps_stats) v = 0;
     if (c->vps_mem) HIP_OK(c, hipMemsetAsync(c->vps_mem + c->vps_words, 0, 8, c->stream));
@@ -1934,7 +2020,7 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
     HIP_OK(c, hipMemsetAsync(c->F.sdf_gate, sw[0].coll_loss_weight > 0.f ? 1 : 0, (size_t)B * 4, c->stream));
     hipLaunchKernelGGL(fit_init_kernel, dim3(B), dim3(STEP_NT), step_lds(), c->stream, c->M, (const ObsBlock*)c->d_obs, c->P, c->F,
                        (const float*)params,
-                       sw[0].flags, (sparse || async || two_phase) ? 0 : 1);
+                       sw[0].flags, (sparse || async || two_phase || service) ? 0 : 1);
     HIP_OK(c, hipGetLastError());
     int* h_done = c->h_done;
     *h_done = 0;
@@ -1953,6 +2039,27 @@ extern "C" int mvfit_fit(mvfit_ctx* c, const mvfit_weights* sw, const mvfit_lbfg
             HIP_OK(c, hipGetLastError());
             return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished the stages without the SDF term", cap);
         }
+    }
+    if (service) {
+        unsigned lead_stats[4];
+        for (int i = 0; i < 4; ++i) lead_stats[i] = c->async_stats[i];
+        int seen = 0;
+        HIP_OK(c, hipMemsetAsync(c->F.n_done + 1, 0, 8, c->stream));
+        rc = fit_async(c, SW, O, cap, &seen, MVFIT_MAX_STAGES + 1, true);
+        if (rc) return rc;
+        *h_done = seen;
+        hipLaunchKernelGGL(fit_finish_kernel, dim3(B), dim3(128), 0, c->stream, c->F, params, final_loss, n_closure, n_iter, B,
+                           o->num_stages);
+        HIP_OK(c, hipGetLastError());
+        // a gate that timed out lets the term's kernels run on another round's operands, a problem whose answer never came ends
+        // with a NaN loss: neither is a result
+        const unsigned sv_lost = c->async_stats[2], sv_gave_up = c->async_stats[3];
+        for (int i = 0; i < 4; ++i) c->async_stats[i] += lead_stats[i];               // mvfit_fit_stats: the whole fit
+        if (sv_lost || sv_gave_up)
+            return fail(c, MVFIT_E_STATE, "SDF service rounds degraded (%u operand sets lost, %u waits given up): the fit is not valid - "
+                        "is the GPU shared?  (mvfit_options::sdf_service = 0 runs these stages as chained rounds)", sv_lost, sv_gave_up);
+        if (seen < B) return fail(c, MVFIT_E_STATE, "fit hit the round cap (%d) before all problems finished", cap);
+        return MVFIT_OK;
     }
     if (async) {
         int seen = 0;

@@ -862,7 +862,8 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
                                                                   const SdfBox* __restrict__ box,
                                                                   const SdfEntry* __restrict__ entries,
                                                                   const SdfChunk* __restrict__ chunks, SdfAdj* __restrict__ part,
-                                                                  int* __restrict__ tickets, SdfAdj* __restrict__ out) {
+                                                                  int* __restrict__ tickets, SdfAdj* __restrict__ out,
+                                                                  unsigned* __restrict__ answer_tag, unsigned answer) {
     __shared__ int sh_pref[SDF_NC + 1];
     __shared__ float sh_box[4];                                      // box adjoint: d S / d centre (3), d S / d scale
     __shared__ __attribute__((aligned(16))) float sh_coef[KROWS];
@@ -980,15 +981,25 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
     // LAST adds the eight partials in slice order (deterministic whoever it is) - the former third kernel, without its
     // launch.  Hand-off as the guide prescribes for other-CU data: agent-scope (sc1) stores, this wave's stores drained
     // before the workgroup barrier in front of the ticket, agent-scope loads on the reading side.
+    // The result goes out with agent-scope (write-through) stores: in the service rounds of the single-launch fit its reader is
+    // an optimiser workgroup that is RUNNING, on any XCD (closure_device.h: sdf_ld); behind them - drained, workgroup barrier -
+    // the answer tag of the round (null in the chained rounds, where a launch boundary is the hand-off).
+    auto publish_answer = [&]() {
+        if (!answer_tag) return;                                     // uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(answer_tag + b, answer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (small) {
         SdfAdj& R = out[b];
-        if (tid < KROWS) R.gcoef[tid] = acc; else R.gA[tid - KROWS] = acc;
-        if (tid < 3) R.gtau[tid] = gtv;
+        __hip_atomic_store(tid < KROWS ? &R.gcoef[tid] : &R.gA[tid - KROWS], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 3) __hip_atomic_store(&R.gtau[tid], gtv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             double S = 0.0;
             for (int c = 0; c < SDF_NC; ++c) S += chunks[(size_t)b * SDF_NC + c].S;
-            R.S = (float)S;
+            __hip_atomic_store(&R.S, (float)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        publish_answer();
         return;
     }
     SdfAdj& O = part[(size_t)b * SDF_NS + y];
@@ -1008,14 +1019,15 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_pullback_kernel(DevModel M, De
         if (tid < 3) rgt += __hip_atomic_load(&p[yy].gtau[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SdfAdj& R = out[b];
-    if (tid < KROWS) R.gcoef[tid] = racc; else R.gA[tid - KROWS] = racc;
-    if (tid < 3) R.gtau[tid] = rgt;
+    __hip_atomic_store(tid < KROWS ? &R.gcoef[tid] : &R.gA[tid - KROWS], racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 3) __hip_atomic_store(&R.gtau[tid], rgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
         double S = 0.0;
         for (int c = 0; c < SDF_NC; ++c) S += chunks[(size_t)b * SDF_NC + c].S;
-        R.S = (float)S;
+        __hip_atomic_store(&R.S, (float)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(tickets + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next round (a launch boundary away)
     }
+    publish_answer();
 }
 
 // work area behind `entries`: [B][nv] SdfEntry | [B][SDF_NS] SdfAdj slice partials | [B][SDF_NC] SdfChunk | [B] tickets
@@ -1028,7 +1040,7 @@ size_t sdf_work_bytes(int B, int nv) { return sdf_ticket_offset(B, nv) + (size_t
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
-                           void* cull) {
+                           void* cull, unsigned* answer_tag, unsigned answer) {
     static_assert(SDF_ADJ_NT == KROWS + NJ * 12, "thread per output of the pull-back");
     unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
     SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
@@ -1058,7 +1070,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
                            reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G);
     }
     hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
-                       reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part, tickets, adj);
+                       reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part, tickets, adj, answer_tag, answer);
     return hipGetLastError();
 }
 

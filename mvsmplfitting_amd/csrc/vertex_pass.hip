@@ -1848,17 +1848,18 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     if (tid_k == 256) __hip_atomic_store(RA.wg_round + wg, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// tpw = tiles per workgroup (1 or 2); grid = ceil(ntiles / tpw) workgroups, all of which must be resident
+// form 1: one tile per workgroup (lbs_vertex_pass_resident_kernel<1>); form 3 (and the former form 2, which it replaced: the
+// one-tile kernel's code with two tiles was 30 % slower and is no longer instantiated - round 6): two tiles per workgroup,
+// contraction / worker roles.  grid = ceil(ntiles / tiles) workgroups, all of which must be resident
 hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream) {
-    if (tpw == 3) {                  // two tiles per workgroup, contraction / worker roles
+    if (tpw >= 2) {
         const dim3 grid((M.ntiles + 1) / 2);
         hipLaunchKernelGGL(M.half_basis ? lbs_vertex_pass_resident_roles_kernel<true> : lbs_vertex_pass_resident_roles_kernel<false>,
                            grid, dim3(VP_NT), 0, stream, M, RA);
         return hipGetLastError();
     }
-    const dim3 grid((M.ntiles + tpw - 1) / tpw);
-    auto kern = tpw == 1 ? (M.half_basis ? lbs_vertex_pass_resident_kernel<1, true> : lbs_vertex_pass_resident_kernel<1, false>)
-                         : (M.half_basis ? lbs_vertex_pass_resident_kernel<2, true> : lbs_vertex_pass_resident_kernel<2, false>);
+    const dim3 grid(M.ntiles);
+    auto kern = M.half_basis ? lbs_vertex_pass_resident_kernel<1, true> : lbs_vertex_pass_resident_kernel<1, false>;
     hipLaunchKernelGGL(kern, grid, dim3(VP_NT), 0, stream, M, RA);       // (static LDS)
     return hipGetLastError();
 }
@@ -1904,9 +1905,11 @@ hipError_t launch_vertex_pass(const DevModel& M, const DevPose& P, int B, float*
             const dim3 g1(M.ntiles, 1);
             // models with <= 4 weights per vertex and an even vertex count: the two-role pipeline (pass_kernel 2 keeps
             // the lock-step chunk loop, which also serves dense skinning rows)
-            if (M.wsp_w && (M.nv & 1) == 0 && pass_kernel != 2)
+            // (round 6: the lock-step loop's <= 4-weights instantiation is gone - pass_kernel 2 was its only selector; an odd
+            // vertex count with <= 4 weights takes one workgroup per (tile, chunk))
+            if (M.wsp_w && (M.nv & 1) == 0)
                 vp_launch(lbs_vertex_pass_pipe_kernel, g1, vertex_pass_pipe_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
-            else if (M.wsp_w) vp_launch(lbs_vertex_pass_split_loop_kernel<true>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
+            else if (M.wsp_w) vp_launch(lbs_vertex_pass_split_kernel<true>, grid, vertex_pass_split_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
             else vp_launch(lbs_vertex_pass_split_loop_kernel<false>, g1, vertex_pass_split_loop_lds_bytes(), stream, ev_start, ev_stop, M, P, B, verts);
         }
         return hipGetLastError();
@@ -1930,9 +1933,6 @@ hipError_t vertex_pass_configure() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_lds_bytes());
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_split_loop_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vertex_pass_split_loop_lds_bytes());
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(lbs_vertex_pass_pipe_kernel),

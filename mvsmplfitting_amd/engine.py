@@ -141,7 +141,7 @@ class MvFit:
 
     def set_options(self, **values):
         """Change run-time selectors between calls (round_mode, resident_pass, sdf_two_phase, sdf_face_lists, vposer_helpers,
-        vposer_sets, closure_vposer_helpers, pass_kernel); returns the previous values of the ones changed."""
+        vposer_sets, closure_vposer_helpers, pass_kernel, sdf_service); returns the previous values of the ones changed."""
         cur = _lib.Options()
         self._check(self._lib.mvfit_get_options(self._ctx, C.byref(cur)))
         old = {k: int(getattr(cur, k)) for k in values}
@@ -465,9 +465,8 @@ class MvFit:
         span, busy, slowest = C.c_double(), C.c_double(), C.c_double()
         self._check(self._lib.mvfit_pass_profile(self._ctx, C.byref(tpw), C.byref(wgs), C.byref(n), C.byref(span), C.byref(busy),
                                                  C.byref(slowest)))
-        form = tpw.value               # 0 per-round launches; 1 / 2 tiles per workgroup, every wave does everything; 3 two tiles, role-split
-        kernel = {0: None, 1: 'lbs_vertex_pass_resident_kernel<1>', 2: 'lbs_vertex_pass_resident_kernel<2>',
-                  3: 'lbs_vertex_pass_resident_roles_kernel'}[form]
+        form = tpw.value               # 0 per-round launches; 1 one tile per workgroup; 3 two tiles, role-split (form 2 was dropped)
+        kernel = {0: None, 1: 'lbs_vertex_pass_resident_kernel<1>', 3: 'lbs_vertex_pass_resident_roles_kernel'}[form]
         return dict(form=form, tiles_per_workgroup=2 if form == 3 else form, kernel=kernel, workgroups=wgs.value, rounds_stamped=n.value,
                     round_span_ms=span.value, workgroup_busy_ms=busy.value, slowest_workgroup_ms=slowest.value)
 

@@ -31,7 +31,11 @@ from oracle.make_golden_sdf_term import bind_reference_sdf_module           # no
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 TRACE_LEN = 120
 FIT_CASES = ['l2_s3_v6', 'l2_top4_v8']
-COLL_W = {2: 1000.0, 3: 4500.0}
+# round 6: the VPoser branch (cfg_files/fit_smpl.yaml:35-37) with the term - 'vp_s0_v8' over the two stages that carry it (like
+# the cases above), and 'vp_s0_v8/yaml4' over ALL FOUR yaml stages (coll_loss_weights 0, 0, 1000, 4500): the device's lead
+# stages, the hand-over at the stage boundary and the service rounds in one fit
+VP_CASES = [('vp_s0_v8', (2, 3)), ('vp_s0_v8/yaml4', (0, 1, 2, 3))]
+COLL_W = {0: 0.0, 1: 0.0, 2: 1000.0, 3: 4500.0}
 
 
 def main():
@@ -63,11 +67,70 @@ def main():
         for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'):
             out[name + '/' + k] = t[name + '/' + k]
         out[name + '/model_checksum'] = np.float64(syn.model_checksum(model))
+    for key, stage_ids in VP_CASES:
+        name = key.split('/')[0]
+        cfg = CASES[name]
+        model = syn.make_body_model(0, skin_topk=cfg.get('skin_topk'), kp_regressor=lsp)
+        vpw = syn.make_vposer_decoder(**cfg['vp'])
+        cams = tuple(t[name + '/' + k] for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'))
+        x0 = np.asarray(t[name + '/x'], np.float64)
+        st_v = [dict(stage_weights(st), coll_loss_weight=COLL_W[st]) for st in stage_ids]
+        rp = ri.RefProblem(model, cams, t[name + '/gt_xy'], t[name + '/conf'], dtype='float32', use_vposer=True, vposer_weights=vpw,
+                           interpenetration=True)
+        final, xf, ncl, trace = run_reference_fit(rp, x0, st_v)
+        print(key, 'float32 closures/stage', ncl, 'final', final, 'first losses', trace[:3, -1], flush=True)
+        out[key + '/trace32'] = trace[:TRACE_LEN]
+        out[key + '/ncl32'] = np.asarray(ncl)
+        out[key + '/final32'] = np.float64(final)
+        out[key + '/xf32'] = xf
+        out[key + '/x0'] = x0
+        out[key + '/stage_index'] = np.asarray(stage_ids)
+        out[key + '/gt_xy'] = t[name + '/gt_xy']
+        out[key + '/conf'] = t[name + '/conf']
+        for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'):
+            out[key + '/' + k] = t[name + '/' + k]
+        out[key + '/model_checksum'] = np.float64(syn.model_checksum(model))
     out['stage_index'] = np.asarray([2, 3])
     out['coll_w'] = np.asarray([COLL_W[2], COLL_W[3]])
     np.savez_compressed(os.path.join(GOLD, 'fit_sdf.npz'), **out)
     print('wrote', os.path.join(GOLD, 'fit_sdf.npz'))
 
 
+def spread(n=24):
+    """python -m oracle.make_golden_sdf_fit spread [n]: the reference's own float32 fits of the two VPoser cases from n starts = the
+    recorded start and n - 1 copies perturbed by 1e-6 (relative) -> tests/golden/fit_sdf_vp_spread.npz (x0 [n, 49] and final32 [n]
+    per case).  These fits have several optima (3.6 k / 4.6 k / 12.2 k / 13.8 k were all seen on the device from the one recorded
+    start): which one a float32 program ends on is decided by its last bits, so the device's end point is held against the
+    reference's own spread (tests/test_gpu_trajectory.py), like the demo and the real-caller VPoser case."""
+    assert ri.available() and sdf_ref.available(), 'needs /root/reference and oracle/_ref (make -C oracle)'
+    bind_reference_sdf_module()
+    lsp = ri.real_lsp_regressor()
+    t = dict(np.load(os.path.join(GOLD, 'sdf_term_ref.npz')))
+    out = {}
+    for key, stage_ids in VP_CASES:
+        name = key.split('/')[0]
+        cfg = CASES[name]
+        model = syn.make_body_model(0, skin_topk=cfg.get('skin_topk'), kp_regressor=lsp)
+        vpw = syn.make_vposer_decoder(**cfg['vp'])
+        cams = tuple(t[name + '/' + k] for k in ('cam_R', 'cam_t', 'cam_f', 'cam_c'))
+        x0 = np.repeat(np.asarray(t[name + '/x'], np.float64)[None], n, 0)
+        x0[1:] *= 1.0 + 1e-6 * np.random.default_rng(17).standard_normal(x0[1:].shape)
+        st_v = [dict(stage_weights(st), coll_loss_weight=COLL_W[st]) for st in stage_ids]
+        finals, ncls = [], []
+        for i in range(n):
+            rp = ri.RefProblem(model, cams, t[name + '/gt_xy'], t[name + '/conf'], dtype='float32', use_vposer=True, vposer_weights=vpw,
+                               interpenetration=True)
+            final, xf, ncl, trace = run_reference_fit(rp, x0[i], st_v)
+            finals.append(final); ncls.append(sum(ncl))
+            print(key, i, 'final', final, 'closures', ncl, flush=True)
+        out[key + '/x0'] = x0
+        out[key + '/final32'] = np.asarray(finals, np.float64)
+        out[key + '/ncl32'] = np.asarray(ncls)
+    np.savez_compressed(os.path.join(GOLD, 'fit_sdf_vp_spread.npz'), **out)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'spread':
+        spread(int(sys.argv[2]) if len(sys.argv) > 2 else 24)
+    else:
+        main()

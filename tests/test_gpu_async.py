@@ -101,14 +101,15 @@ def _capture(eng, x0, stages, round_index, resident):
     return cap.cpu().numpy(), xf.cpu().numpy(), st['n_closure'].cpu().numpy(), eng.pass_profile()
 
 
-@pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 2, 9), (33, None, 1, 140),
+@pytest.mark.parametrize('B,resident,tpw,round_index', [(5, None, 1, 9), (5, None, 1, 140), (5, 2, 3, 9), (33, None, 1, 140),
                                                         (70, None, 3, 9), (70, None, 3, 140), (128, None, 3, 31),
-                                                        (5, 3, 3, 9), (33, 3, 3, 140), (70, 2, 2, 9), (70, 2, 2, 140), (128, 2, 2, 31)])
+                                                        (5, 3, 3, 9), (33, 3, 3, 140), (97, 3, 3, 140)])
 def test_resident_pass_is_bit_identical_to_the_per_round_launches(B, resident, tpw, round_index):      # tpw: the expected form
     """The resident pass (one launch per fit, the tiles' basis stationary in registers, rounds served from the ring) writes
-    the SAME BITS as the gate + pass launches per closure round: 1 and 2 tiles per workgroup (form 2: every wave does everything;
-    form 3, the automatic choice beside more than 36 optimiser workgroups: contraction waves + worker waves), one chunk / ragged
-    chunks / four chunks, before and after the ring wrapped; and it does not perturb the optimiser either."""
+    the SAME BITS as the gate + pass launches per closure round: one tile per workgroup (form 1) and two tiles with contraction
+    waves + worker waves (form 3, the automatic choice beside more than 36 optimiser workgroups; an explicit 2 - the dropped
+    two-tile form of the one-tile kernel - maps to it), one chunk / ragged chunks / four chunks, before and after the ring
+    wrapped; and it does not perturb the optimiser either."""
     eng, x0 = _setup(B=B)
     stages = eng_stage_weights(1536.0, flags=0)
     cap_l, x_l, ncl_l, prof_l = _capture(eng, x0, stages, round_index, 0)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from mvsmplfitting_amd import _lib
+from mvsmplfitting_amd import synthetic as syn
 from tests.gpu_helpers import from118, make_engine, to118
 from tests.helpers import GOLD, body_model
 
@@ -94,13 +95,14 @@ def test_demo_four_stage_fit(sparse):
 
 @pytest.mark.parametrize('sparse', [False, True])
 def test_demo_fit_spread_against_the_reference_spread(sparse):
-    """The SAME 48 starts (the reference's initial guess + 47 copies perturbed by 1e-6, relative) fitted by the reference itself
-    in float32 (tests/golden/demo_spread48.npz: 46 fits in 34.2 k ... 39.9 k, 2 at 44.4 k) and by the device in one batch.
-    Which optimum a start reaches is chaotic in the last bits, so the two are compared as distributions: the device's share of
-    fits outside the main band must be compatible with the reference's (one-sided Fisher exact test at the 1 % level), its
-    median and its worst fit must not be worse than the reference's (2 %), and the effort must be comparable."""
+    """The SAME 192 starts (the reference's initial guess + 191 copies perturbed by 1e-6, relative) fitted by the reference itself
+    in float32 (tests/golden/demo_spread192.npz, oracle/make_golden_demo_spread.py: 183 fits in 34.1 k ... 40.3 k, 9 at 44.4 k) and
+    by the device in one batch.  Which optimum a start reaches is chaotic in the last bits, so the two are compared as
+    distributions: the device's share of fits outside the main band must be compatible with the reference's - Fisher's exact
+    test, TWO-sided, 5 % level (round 6: 192 starts instead of 48 and a one-sided 1 % level, which could not tell 4 % from 20 %) -,
+    its median and its worst fit must not be worse than the reference's (2 %), and the effort must be comparable."""
     g, vpw, model, cams, stages = _load()
-    sp = np.load(os.path.join(GOLD, 'demo_spread48.npz'))
+    sp = np.load(os.path.join(GOLD, 'demo_spread192.npz'))
     x0, ref = sp['x0'].astype(np.float32), sp['final32']
     n = x0.shape[0]
     eng = make_engine(model, vpw)
@@ -115,12 +117,42 @@ def test_demo_fit_spread_against_the_reference_spread(sparse):
           'closures reference %d (median), device %d' % (n, np.median(ref), ref.max(), out_ref, np.median(dev), dev.max(), out_dev,
                                                        int(np.median(sp['ncl32'].sum(1))), int(np.median(ncl))))
     assert np.isfinite(dev).all()
-    # the shares outside the band as two samples of one distribution: Fisher's exact test, one-sided (device worse), 1 % level
-    # (2 of 48 for the reference; measured on the device: 6 of 48 with the full vertex pass - p = 0.13)
     from scipy.stats import fisher_exact
-    p_worse = fisher_exact([[out_dev, n - out_dev], [out_ref, n - out_ref]], alternative='greater')[1]
-    print('    share outside the band: device %d / %d vs reference %d / %d, one-sided Fisher p = %.3f' % (out_dev, n, out_ref, n, p_worse))
-    assert p_worse >= 0.01, (out_dev, out_ref, p_worse, np.sort(dev), np.sort(ref))
+    p_two = fisher_exact([[out_dev, n - out_dev], [out_ref, n - out_ref]], alternative='two-sided')[1]
+    print('    share outside the band: device %d / %d vs reference %d / %d, two-sided Fisher p = %.3f' % (out_dev, n, out_ref, n, p_two))
+    assert p_two >= 0.05, (out_dev, out_ref, p_two, np.sort(dev)[-30:], np.sort(ref)[-12:])
     assert np.median(dev) <= 1.02 * np.median(ref) and dev.max() <= 1.02 * ref.max(), (np.sort(dev), np.sort(ref))
     assert 0.5 * np.median(sp['ncl32'].sum(1)) <= np.median(ncl) <= 2.0 * np.median(sp['ncl32'].sum(1))
+    eng.close()
+
+
+def test_configs1_fit_spread_against_the_reference_spread():
+    """Fit-level parity on the HEADLINE workload as a comparison of distributions (round 6): 4 frames of BASELINE configs[1]
+    (seeds 1000 ...; L2 pose prior, yaml stages) from 24 starts each - the bench's start and 23 copies perturbed by 1e-6 -, fitted
+    by the reference itself in float32 (tests/golden/configs1_spread.npz, oracle/make_golden_configs1_spread.py) and by the
+    device in one batch of 96.  These problems are well conditioned: the reference's 24 fits of a frame end within 3e-5 ...
+    7e-4 (relative) of one another.  Per frame: the device's median inside the reference's own [min, max] widened by its width,
+    no device fit worse than the reference's worst by more than that width, and a comparable effort."""
+    sp = np.load(os.path.join(GOLD, 'configs1_spread.npz'))
+    d = np.load(os.path.join(GOLD, 'lsp_regressor.npz'))
+    model = syn.make_body_model(0, skin_topk=4, kp_regressor=(d['rows'], d['cols'], d['vals']))
+    assert np.array_equal(np.array(syn.model_checksum(model)), sp['model_checksum'])
+    nf, ns = sp['final32'].shape
+    eng = make_engine(model)
+    cams = syn.make_camera_ring(8)
+    eng.set_problems(cams, np.repeat(sp['gt_xy'], ns, 0), np.repeat(sp['conf'], ns, 0))
+    from mvsmplfitting_amd.engine import stage_weights
+    xf, st = eng.fit(sp['x0'].reshape(nf * ns, 118).astype(np.float32), stage_weights(1536.0))
+    dev = st['final_loss'].cpu().numpy().astype(np.float64).reshape(nf, ns)
+    ncl = st['n_closure'].cpu().numpy().reshape(nf, ns)
+    assert np.isfinite(dev).all()
+    for f in range(nf):
+        ref, rn = sp['final32'][f], sp['ncl32'][f].sum(1)
+        width = max(ref.max() - ref.min(), 1e-5 * abs(np.median(ref)))
+        print('configs[1] frame %d, %d starts: reference %.4f ... %.4f (median %.4f, closures median %d); device %.4f ... %.4f (median '
+              '%.4f, closures median %d)' % (f, ns, ref.min(), ref.max(), np.median(ref), np.median(rn), dev[f].min(), dev[f].max(),
+                                             np.median(dev[f]), np.median(ncl[f])))
+        assert ref.min() - width <= np.median(dev[f]) <= ref.max() + width, (f, np.sort(dev[f]), np.sort(ref))
+        assert dev[f].max() <= ref.max() + width, (f, np.sort(dev[f]), np.sort(ref))
+        assert 0.6 * np.median(rn) <= np.median(ncl[f]) <= 1.5 * np.median(rn), (f, ncl[f], rn)
     eng.close()

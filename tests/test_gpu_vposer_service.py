@@ -123,3 +123,34 @@ def test_a_fit_whose_helpers_never_answer_falls_back_to_the_local_decoder():
     assert bad['stats']['launches'] == 1 and bad['stats']['answers_timed_out'] == B and bad['stats']['helpers_gave_up'] == 5 * 8, bad['stats']
     assert np.array_equal(bad['x'], off['x']) and np.array_equal(bad['final'], off['final']) and np.array_equal(bad['ncl'], off['ncl'])
     eng.close()
+
+
+def test_vposer_fit_of_32_problems_takes_the_resident_pass_and_writes_the_same_bits():
+    """The reference's default mode (cfg_files/fit_smpl.yaml:35-37, use_vposer) at <= 32 problems: 16 helper sets would leave no
+    CUs for the resident vertex pass (32 + 128 + 108 workgroups), so the automatic choice takes 8 sets and the role-split
+    resident pass (round 6; before, this mode ran its passes as per-round launches).  Against resident_pass = 0 (16 sets, gate +
+    pass launch per round): the same fit bit for bit - a problem's result does not depend on the number of sets - and the SAME
+    vertices from the pass of a round before and of a round after the ring wrapped."""
+    eng = MvFit(syn.make_body_model(0, skin_topk=4), vposer=syn.make_vposer_decoder())
+    B = 32
+    x0 = _problems(eng, B)[0]
+    stages = stage_weights(1536.0, flags=_lib.F_VPOSER)
+    res = {}
+    for resident in (0, -1):
+        eng.set_options(resident_pass=resident)
+        caps = []
+        for rnd in (9, 140):
+            cap = eng.capture_pass(rnd)
+            xf, st = eng.fit(x0, stages)
+            eng.capture_pass(None)
+            assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0, st['passes']
+            assert st['decoder'] == dict(launches=1, answers_timed_out=0, helpers_gave_up=0), st['decoder']
+            caps.append(cap.cpu().numpy())
+        res[resident] = dict(x=xf.cpu().numpy(), ncl=st['n_closure'].cpu().numpy(), caps=caps, form=eng.pass_profile()['form'])
+    assert res[0]['form'] == 0 and res[-1]['form'] == 3, (res[0]['form'], res[-1]['form'])
+    assert np.array_equal(res[0]['x'], res[-1]['x']) and np.array_equal(res[0]['ncl'], res[-1]['ncl'])
+    for rnd, a, b in zip((9, 140), res[0]['caps'], res[-1]['caps']):
+        have = rnd < res[0]['ncl']
+        assert have.any() and np.isfinite(b[have]).all()
+        assert np.array_equal(a[have], b[have]), (rnd, np.abs(a[have] - b[have]).max())
+    eng.close()
