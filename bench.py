@@ -644,6 +644,8 @@ def main():
     ap.add_argument('--resident-pass', type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help='vertex passes of the asynchronous fit: -1 automatic, 0 per-round launches, 1 / 2 / 3 resident forms (mvfit_options.resident_pass)')
     ap.add_argument('--vposer-sets', type=int, default=0, help='decoder-helper sets of a VPoser fit (0 automatic; mvfit_options::vposer_sets)')
+    ap.add_argument('--work-queue', type=int, default=1, choices=[0, 1],
+                    help='more problems than optimiser workgroups: 1 one launch with a work queue (default), 0 sub-batches (mvfit_options.work_queue)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-variants', action='store_true', help='skip the extra vertex-pass roofline / prior variants')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the rocprofv3 PMC passes (traffic then comes from profiles/*_pmc.json)')
@@ -717,7 +719,7 @@ def main():
         B = persons * (hi - lo)
         total = persons * total_frames
     eng_options = dict(contraction='half_basis' if half_basis else args.contraction, round_mode=1 if args.round_mode == 'chained' else 0,
-                       resident_pass=args.resident_pass, vposer_sets=args.vposer_sets)
+                       resident_pass=args.resident_pass, vposer_sets=args.vposer_sets, work_queue=args.work_queue)
     if args.single_device and world > 1 and args.resident_pass == -1:
         # the dry run of the N-rank path puts N processes on ONE GPU: the resident pass assumes that a fit's workgroups (the
         # optimiser's + the pass's, ~250 CUs) are resident together, which several processes sharing the device cannot all have

@@ -175,6 +175,10 @@ typedef struct mvfit_options {
                                       * vertex pass -> term kernels per round on the pass stream, the pull-back answers through
                                       * memory (fitting.py:352-393 unchanged: the same kernels compute the same S and adjoint);
                                       * 0: those stages as chained rounds (pass -> term -> step kernel launch per round) */
+    int32_t work_queue;              /* 1 (default): an asynchronous fit of more problems than optimiser workgroups (128 beside the
+                                      * resident vertex pass) is ONE launch whose workgroups take the next unfitted problem when
+                                      * theirs has finished; 0: sub-batches one after the other.  A problem's result does not depend
+                                      * on it (problems are independent) */
 } mvfit_options;
 void mvfit_options_default(mvfit_options* opts);
 

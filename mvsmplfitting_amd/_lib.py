@@ -62,7 +62,7 @@ class Options(C.Structure):
     _fields_ = [('struct_size', C.c_uint32), ('contraction', C.c_int32), ('dense_skinning', C.c_int32),
                 ('round_mode', C.c_int32), ('resident_pass', C.c_int32), ('sdf_two_phase', C.c_int32),
                 ('sdf_face_lists', C.c_int32), ('vposer_helpers', C.c_int32), ('vposer_sets', C.c_int32),
-                ('closure_vposer_helpers', C.c_int32), ('pass_kernel', C.c_int32), ('sdf_service', C.c_int32)]
+                ('closure_vposer_helpers', C.c_int32), ('pass_kernel', C.c_int32), ('sdf_service', C.c_int32), ('work_queue', C.c_int32)]
 
 
 EXPORTS = ['mvfit_create', 'mvfit_destroy', 'mvfit_last_error', 'mvfit_sync', 'mvfit_set_problems', 'mvfit_set_joints3d',

@@ -105,6 +105,7 @@ struct ClosureLds {
     const SdfAdj* sdf_adj;          // SDF term of this problem (sdf_term.hip), or null
     float sdf_fac;                  // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
     unsigned sh_sdf_ok;             // service rounds: the answer arrived (0: timed out)
+    int sh_next;                    // work queue: the problem this workgroup takes next
     double total;
     double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
@@ -1463,7 +1464,9 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 constexpr int PUBLISH_WAVE = 3;      // idle in the loss phase that follows (data term: waves 0-1 at <= 7 views; 3-D term and priors: waves 5-7)
 
-__device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int tid) {
+// b = the workgroup's ring row (sub-batch-relative), prob = the global index of the problem it is fitting (the passes write the
+// round's vertices there: rows take new problems when theirs has finished)
+__device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int prob, int tid) {
     // All 129 words go out from ONE wave, which also stores the tag later: the hand-off needs no workgroup barrier.
     const int l = tid - 64 * PUBLISH_WAVE;
     if (l < 0 || l >= 64) return;
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRin
         const unsigned word = (((unsigned)slot * (Bp >> 5) + chunk) * (KROWS / 16) + G) * 2 + hl;
         store16_sc1(rs_c, (word * 64 + 32 * h + ((unsigned)b & 31)) * 16, v);
     } else if (l == 56) {
-        store16_sc1(rs_t, ((unsigned)slot * Bp + (unsigned)b) * 16, make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], 0.f));
+        store16_sc1(rs_t, ((unsigned)slot * Bp + (unsigned)b) * 16, make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], __builtin_bit_cast(float, prob)));
     }
 }
 

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // SDFS: the launch serves stages with the SDF term by asking for it (closure_device.h: publish_sdf_request / sdf_answer_wait);
 // sv = {pass operands of the chained layout (coefT), gate words, answer tags, global problem index, round offset of the launch}
 struct SdfService { const DevPose* P; int* gate; const unsigned* tag; int b; int round0; };
-template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false, bool SDFS = false>
+template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false, bool SDFS = false, bool ROFF = SDFS>
 __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int nviews, const LbHist<float>& H,
                           bool from_pass, bool have_pose, double* stage_final, int tid,
                           LbGramLds GL = LbGramLds{nullptr, 0, 0}, float* trace = nullptr, int trace_cap = 0,
@@ -256,9 +256,11 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     PH_T(2);
     // asynchronous fit: the 6890-vertex pass of THIS trial point is already queued on the other CUs and waits for the
     // operands (coefficients, skinning transforms, translation: all complete here) in the ring slot of this round
-    const unsigned a_round = use_ring ? (unsigned)(L.opt.lbS.n_closure - (SDFS ? sv.round0 : 0)) : 0u;      // closures consumed so far (in this launch) = this round
+    // closures consumed so far by this ring row = this round (sv.round0: the problem's closures before this launch, minus the
+    // rounds the row spent on earlier problems of the launch - refill)
+    const unsigned a_round = use_ring ? (unsigned)(L.opt.lbS.n_closure - (ROFF ? sv.round0 : 0)) : 0u;
     const int a_slot = use_ring ? (int)(a_round % (unsigned)ring.nslots) : 0;
-    if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, tid);
+    if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, sv.b, tid);
     bool sdf_round = false;
     if constexpr (SDFS) {
         // a stage that carries the interpenetration term: ask for S and its adjoint at this trial point (the tag goes out at
@@ -395,11 +397,14 @@ __global__ __launch_bounds__(STEP_NT) void fit_step_kernel(DevModel M, const Obs
 // history ring lives in LDS behind the closure workspace.
 // REMOTE: the launch carries VPoser decoder helpers behind the problems' workgroups (vposer_service.h); launches without
 // them run the instantiation that has no trace of the service.
-template <bool REMOTE, bool REUSE, bool LEAN, bool SDFS = false>
+// QUEUE: the launch has a work queue (more problems than ring rows): its own instantiations - the loop over a row's problems around
+// the round loop costs the round loop registers (22 instead of 7 spilled, +12 % instructions), which launches without a queue do
+// not pay
+template <bool REMOTE, bool REUSE, bool LEAN, bool SDFS = false, bool QUEUE = false>
 __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, const ObsBlock* __restrict__ obs, int nviews,
                                                                  StageWeights SW, LbOpts O, DevPose P, FitBuffers F,
                                                                  int max_rounds, AsyncRing ring, int b_lo, int done_target,
-                                                                 int pause_stage) {
+                                                                 int pause_stage, int* queue, int b_end) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (REMOTE && (int)blockIdx.x >= M.vps.nprob) {
         // decoder helper of this launch (vposer_service.h): workgroups behind the problems' ones; set = blockIdx % nsets
@@ -414,17 +419,30 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     const int ldh = LEAN ? kHistLdFull : persistent_hist_ld(vp_mode);
     float* hist = reinterpret_cast<float*>(smem_raw + (LEAN ? persistent_tail_offset(false) : persistent_tail_offset(vp_mode)));   // [2][100][ldh]
     float* rinv = hist + 2 * LB_HIST * ldh;                                              // [LB_RPACK]
-    const int b = b_lo + (int)blockIdx.x, tid = threadIdx.x;      // problems [b_lo, b_lo + nprob): one sub-batch of mvfit_fit
+    const int tid_k = threadIdx.x;
+    const int row = b_lo + (int)blockIdx.x;                        // this workgroup's ring row / done_round word
+    int b = row;                                                   // problems [b_lo, b_lo + nprob): one sub-batch of mvfit_fit ...
+    // ... and, with a work queue (round 6: `queue` counts the problems handed out, b_end = one past the last), whatever problem
+    // the workgroup takes when its own has finished: more problems than optimiser workgroups overlap in ONE launch instead of
+    // running as sub-batches one after the other, and a workgroup whose problem converged early does not idle through the
+    // tail of the slowest.  The ring row keeps counting closure rounds across its problems (rounds_before); the passes write a
+    // round's vertices to the problem the row held in that round (its index travels in the translation word's spare lane).
+    int rounds_before = 0, slot_rounds = 0;
+  for (;;) {
+    // (opaque per problem: nothing derived from the thread index is invariant across this loop - hoisted into its preheader, the
+    // prologue's and epilogue's addresses would be live through every round loop: 179 spilled registers, 1.55 -> 1.42 M closures/s)
+    int tid = tid_k;
+    if constexpr (QUEUE) asm volatile("" : "+v"(tid));
     prologue(L, M, obs + b, nullptr, F.opt + b, nullptr, nullptr, nullptr, tid, SDFS && F.sdf_adj ? F.sdf_adj + b : nullptr);
     opts_in(L, SW, O, tid);
     __syncthreads();
     // closure rounds of THIS launch count from 0 (ring slots, tags, done_round): a service launch continues fits whose problems
     // have spent different numbers of closures in the stages before it
-    const int round0 = SDFS ? L.opt.lbS.n_closure : 0;
+    const int round0 = (SDFS || QUEUE) ? L.opt.lbS.n_closure - rounds_before : 0;
     if (L.opt.lbS.status != 0) {
         if (REMOTE && tid == 0 && L.vp_remote) vps_store(vps_request_slot(M.vps), 0.f, 1u << 2 | VPS_BYE);
         if (tid == 0 && ring.tag) {         // finished in an earlier launch: no pass waits for this problem
-            __hip_atomic_store(ring.done_round + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ring.done_round + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (SDFS) {                     // (the host counts the problems that left this launch)
                 __hip_atomic_store(F.sdf_gate + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int left = atomicAdd(F.n_done + 1, 1) + 1;
@@ -455,15 +473,15 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
     __syncthreads();
     bool done = false, paused = false;
     int stage_prev = L.sh_stage;
-    for (int round = 0; max_rounds <= 0 || round < max_rounds; ++round) {
+    for (; max_rounds <= 0 || slot_rounds < max_rounds; ++slot_rounds) {
         // opaque copy of the thread index: keeps the compiler from hoisting every tid-derived address
         // of the closure out of the round loop (which costs >256 live VGPRs and spills)
         int t = tid;
         asm volatile("" : "+v"(t));
-        done = fit_round<REMOTE, REUSE, LEAN, true, SDFS>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
+        done = fit_round<REMOTE, REUSE, LEAN, true, SDFS, SDFS || QUEUE>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring, ring.tag != nullptr, (int)blockIdx.x,        // ring slots: sub-batch-relative problem index
-                         SdfService{&P, F.sdf_gate, F.sdf_tag, b, round0});
+                         SdfService{&P, F.sdf_gate, F.sdf_tag, b, round0});      // (b: also the row's problem index for the passes)
         if (done) break;                                  // block-uniform
         if (L.sh_stage != stage_prev) {
             // a new stage starts with a fresh optimiser (non_linear_solver.py:172): its history is empty, and the branch-free
@@ -478,10 +496,18 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         if (L.sh_stage >= pause_stage) { paused = true; break; }
     }
     store_block16(F.opt + b, &L.opt, sizeof(OptBlock), tid);
-    // passes of later rounds have nothing to wait for from this problem - whatever ended the launch for it (finished, paused
-    // at a stage boundary, or the round cap: the resident pass ends when every problem has said so)
+    // the next problem of the batch, if the launch has a queue and this one is finished (a paused problem or the round cap ends
+    // the workgroup): decided here, before the row says "nothing more comes"
+    int b_next = -1;
+    if (QUEUE && queue && done) {                                       // uniform
+        if (tid == 0) L.sh_next = atomicAdd(queue, 1);
+        __syncthreads();
+        if (L.sh_next < b_end) b_next = L.sh_next;
+    }
+    // passes of later rounds have nothing to wait for from this row - whatever ended the launch for it (finished, paused at a
+    // stage boundary, or the round cap: the resident pass ends when every row has said so)
     if (tid == 0 && ring.tag) {
-        __hip_atomic_store(ring.done_round + b, (unsigned)(L.opt.lbS.n_closure - round0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b_next < 0) __hip_atomic_store(ring.done_round + row, (unsigned)(L.opt.lbS.n_closure - round0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (SDFS) __hip_atomic_store(F.sdf_gate + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0 && (done || paused)) {
@@ -514,6 +540,11 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         if (SW.w[0].flags & MVFIT_F_VPOSER) store_block16(F.vp + b, L.vp_pre1, sizeof(VpBlock), tid);
         if (tid == 0 && F.sdf_adj) F.sdf_gate[b] = L.sw[L.sh_stage].coll_w > 0.f ? 1 : 0;
     }
+    if (!QUEUE || b_next < 0) break;
+    rounds_before = L.opt.lbS.n_closure - round0;                      // the row's rounds so far
+    b = b_next;
+    __syncthreads();                                                   // (every thread is done with the finished problem's LDS image)
+  }
 }
 
 __global__ void fit_finish_kernel(FitBuffers F, float* __restrict__ params, float* __restrict__ final_loss,
@@ -663,6 +694,8 @@ struct mvfit_ctx {
     mvfit_options opt{};               // precision / path selectors (include/mvfit.h); the library reads no environment variable
     int n_cu = 0;                      // compute units of the device (residency of the resident vertex pass)
     int resident_tpw = 0;              // tiles per workgroup of the resident pass in the last asynchronous fit (0: per-round launches)
+    int* d_queue = nullptr;            // work queue of a single-launch fit with more problems than rows: next problem to hand out
+    int h_queue0 = 0;
     bool resident_auto_off = false;    // automatic resident_pass: a fit on this ctx timed out waiting - later fits use per-round launches
     unsigned long long* d_vp_log = nullptr;     // mvfit_profile: per-round stamps of the resident pass [kVpLogRounds][grid][2]
     size_t vp_log_words = 0;
@@ -753,6 +786,7 @@ extern "C" void mvfit_options_default(mvfit_options* o) {
     o->sdf_face_lists = 1;
     o->vposer_helpers = 1;
     o->sdf_service = 1;
+    o->work_queue = 1;
 }
 
 // a caller's struct (possibly shorter: an older header) over the defaults; range checks
@@ -1263,6 +1297,7 @@ extern "C" void mvfit_destroy(mvfit_ctx* c) {
     if (c->ev_init) hipEventDestroy(c->ev_init);
     if (c->pass_stream) hipStreamDestroy(c->pass_stream);
     if (c->h_async_done) hipHostFree(c->h_async_done);
+    if (c->d_queue) hipFree(c->d_queue);
     for (auto& e : c->ev_vp) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->ev_step) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete c;
@@ -1662,6 +1697,7 @@ static int ensure_async(mvfit_ctx* c, int rb) {
         for (hipEvent_t& e : c->ev_batch) HIP_OK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_OK(c, hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming));
         HIP_OK(c, hipHostMalloc(&c->h_async_done, 64));
+        HIP_OK(c, hipMalloc(&c->d_queue, 64));
     }
     AsyncRing& R = c->ring;
     if (R.tag && R.Bpad >= rb) return MVFIT_OK;
@@ -1726,7 +1762,7 @@ static int persistent_grid(const mvfit_ctx* c, const StageWeights& SW, int n, bo
 }
 
 static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int cap, const AsyncRing& R, int b_lo,
-                             int b_hi, int done_target, int pause_stage, bool sdfs = false) {
+                             int b_hi, int done_target, int pause_stage, bool sdfs = false, int* queue = nullptr, int b_end = 0) {
     const int n = b_hi - b_lo;
     DevModel M = c->M;
     int grid = n;
@@ -1745,11 +1781,12 @@ static int launch_persistent(mvfit_ctx* c, const StageWeights& SW, const LbOpts&
     // (service launches - the stages with the SDF term, mvfit_options::sdf_service - have their own instantiations: the other
     // kernels carry no trace of the service; MVFIT_F_REUSE_OUTER_VALUE fits keep the chained rounds, see mvfit_fit)
     auto kern = sdfs ? (M.vps.nsets ? fit_persistent_kernel<true, false, false, true> : fit_persistent_kernel<false, false, false, true>)
+                : queue ? (lean ? fit_persistent_kernel<false, false, true, false, true> : fit_persistent_kernel<false, false, false, false, true>)
                 : M.vps.nsets ? (O.reuse_outer ? fit_persistent_kernel<true, true, false> : fit_persistent_kernel<true, false, false>)
                 : O.reuse_outer ? (lean ? fit_persistent_kernel<false, true, true> : fit_persistent_kernel<false, true, false>)
                 : lean ? fit_persistent_kernel<false, false, true> : fit_persistent_kernel<false, false, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_NT), persistent_lds((SW.w[0].flags & MVFIT_F_VPOSER) != 0), c->stream, M,
-                       (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage);
+                       (const ObsBlock*)c->d_obs, c->V, SW, O, c->P, c->F, cap, R, b_lo, done_target, pause_stage, queue, b_end);
     HIP_OK(c, hipGetLastError());
     return MVFIT_OK;
 }
@@ -1797,7 +1834,13 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     int per = sub_batch(vps_enabled(c, SW) ? kVpsMaxAsync : kResidentMaxB);
     int tpw = (dbg_nopass || sdf_service) ? 0 : resident_tiles_per_wg(c, persistent_grid(c, SW, std::min(B, per), true));
     if (!tpw && !vps_enabled(c, SW)) per = sub_batch(kAsyncMaxB);
-
+    // Round 6: more problems than optimiser workgroups run as ONE launch with a work queue when the resident pass serves it (its
+    // workgroups follow a ring row through the problems it takes; the per-round launch kernels address problems by row): `per`
+    // rows, a row takes the next unfitted problem when its own has finished - no serial sub-batches, no idle tail per sub-batch.
+    // (Not with decoder helpers: their request slots belong to problems; not in service launches.)
+    const bool refill = tpw != 0 && !vps_enabled(c, SW) && !sdf_service && B > per && c->opt.work_queue != 0 && !O.reuse_outer;
+    if (refill) per = kResidentMaxB;
+    const int launch_cap = refill ? (int)std::min<long long>((long long)cap * ((B + per - 1) / per + 1), 1 << 30) : cap;
     int rc = ensure_async(c, per);
     if (rc) return rc;
     AsyncRing R = c->ring;
@@ -1808,6 +1851,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
     HIP_OK(c, hipMemsetAsync(R.stats, 0, 16, c->stream));
     const int res_grid = resident_grid(c, tpw);
     if (res_grid > kPassWords) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d workgroups > %d back-pressure words", res_grid, kPassWords);
+    if (tpw && per > kResidentMaxB) return fail(c, MVFIT_E_ARG, "resident vertex pass: %d ring rows > %d", per, kResidentMaxB);
     c->resident_tpw = tpw;
     R.npass = tpw ? res_grid : 1;
     c->res_rounds = 0; c->res_span_ms = c->res_busy_ms = c->res_slowest_ms = 0.0;
@@ -1821,8 +1865,9 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             c->vp_log_words = words;
         }
     }
-    for (int b_lo = 0; b_lo < B; b_lo += per) {
-        const int b_hi = std::min(B, b_lo + per);
+    for (int b_lo = 0; b_lo < B; b_lo += refill ? B : per) {
+        const int b_hi = std::min(B, b_lo + per);                 // (refill: the rows of the one launch)
+        const int n_target = refill ? B : b_hi - b_lo;            // problems that leave this launch
         *h_done = 0;
         // per sub-batch: its tags (the slots are reused by other problems), the pass counter and the count of problems
         // that left the launch (finished or paused) - a sub-batch that stops at the round cap does not keep the later ones
@@ -1839,7 +1884,11 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
         if (log_on) HIP_OK(c, hipMemsetAsync(c->d_vp_log, 0, c->vp_log_words * 8, c->stream));      // (a profiled fit keeps the last sub-batch's stamps)
         HIP_OK(c, hipEventRecord(c->ev_init, c->stream));
         HIP_OK(c, hipStreamWaitEvent(c->pass_stream, c->ev_init, 0));
-        rc = launch_persistent(c, SW, O, cap, R, b_lo, b_hi, b_hi - b_lo, pause_stage, sdf_service);
+        if (refill) {
+            c->h_queue0 = b_hi;                                   // problems [0, rows) start on their rows, the queue hands out the rest
+            HIP_OK(c, hipMemcpyAsync(c->d_queue, &c->h_queue0, 4, hipMemcpyHostToDevice, c->stream));
+        }
+        rc = launch_persistent(c, SW, O, launch_cap, R, b_lo, b_hi, n_target, pause_stage, sdf_service, refill ? c->d_queue : nullptr, B);
         if (rc) return rc;
         int k = 0;
         if (tpw) {
@@ -1854,7 +1903,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             RA.nslots = kRingSlots; RA.rb = (int)rb;
             RA.b_lo = b_lo; RA.n = b_hi - b_lo;
             RA.flags = (unsigned)debug_hook("MVFIT_DEBUG_NT_OFF");         // (hooks build only) bit 1 = plain vertex stores
-            RA.max_rounds = (unsigned)cap;
+            RA.max_rounds = (unsigned)launch_cap;
             hipError_t e = launch_vertex_pass_resident(c->M, RA, tpw, c->pass_stream);
             if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "resident vertex pass launch: %s", hipGetErrorString(e));
             HIP_OK(c, hipEventRecord(c->ev_batch[0], c->pass_stream));
@@ -1899,8 +1948,8 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
             }
             HIP_OK(c, hipEventRecord(c->ev_batch[k & 3], c->pass_stream));
             if (k >= 2) HIP_OK(c, hipEventSynchronize(c->ev_batch[(k - 2) & 3]));
-            if (*h_done >= b_hi - b_lo) break;
-            if ((k + 1) * kPassBatch >= cap) break;
+            if (*h_done >= n_target) break;
+            if ((k + 1) * kPassBatch >= launch_cap) break;
         }
         }
         // behind the optimiser kernel (all problems of the sub-batch, or the round cap) the ctx stream continues behind the

@@ -1077,25 +1077,32 @@ __device__ __forceinline__ void resident_poll(const ResidentArgs& RA, unsigned r
     const unsigned want = r + 1u;
     const unsigned* tg = RA.tag + (size_t)slot * RA.rb;
     const unsigned* dn = RA.done_round + RA.b_lo;
-    unsigned verdict = VR_GO, live_bits = 0u, missed = 0u;
+    unsigned verdict = VR_GO, missed = 0u;
+    unsigned rows_live[4] = {0u, 0u, 0u, 0u};                  // per 32-row chunk: the rows whose problem evaluates round r
     const long long t0 = wall_clock64();
     for (;;) {
         bool ok = true;
-        live_bits = 0u; missed = 0u;
-        for (int p = lane; p < RA.n; p += 64) {
-            const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool live = d > r;                   // the problem evaluates (or evaluated) closure round r
-            ok = ok && (t >= want || !live);           // (a larger tag: a later round already overwrote the slot)
-            if (live) live_bits |= 1u << (p >> 5);
-            if (live && t > want) ++missed;
+        missed = 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                          // (at most 128 rows: kResidentMaxB, checked by the host)
+            const int p = lane + 64 * j;
+            bool live = false;
+            if (p < RA.n) {
+                const unsigned t = __hip_atomic_load(tg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned d = __hip_atomic_load(dn + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                live = d > r;                                  // the row's problem evaluates (or evaluated) closure round r
+                ok = ok && (t >= want || !live);               // (a larger tag: a later round already overwrote the slot)
+                if (live && t > want) ++missed;
+            }
+            const unsigned long long bal = __ballot(live);
+            rows_live[2 * j] = (unsigned)bal; rows_live[2 * j + 1] = (unsigned)(bal >> 32);
         }
         if (__all(ok)) break;
         if (wall_clock64() - t0 > 2000000) { verdict = VR_TIMEOUT; break; }            // 20 ms at 100 MHz
         __builtin_amdgcn_s_sleep(32);
     }
     unsigned mask = 0u;
-    for (unsigned c = 0; c < nch; ++c) mask |= (__ballot((live_bits >> c) & 1u) != 0ull) ? (1u << c) : 0u;
+    for (unsigned c = 0; c < nch; ++c) mask |= rows_live[c & 3u] != 0u ? (1u << c) : 0u;
     if (verdict == VR_GO && mask == 0u) verdict = VR_DONE;     // every problem finished before this round: the fit is over
     if (verdict == VR_GO && __ballot(missed != 0u)) {          // operands overwritten before this workgroup read them
         unsigned msum = missed;
@@ -1108,6 +1115,9 @@ __device__ __forceinline__ void resident_poll(const ResidentArgs& RA, unsigned r
         ctl[0] = verdict; ctl[1] = mask;
         const long long ts = wall_clock64();
         ctl[2] = (unsigned)ts; ctl[3] = (unsigned)((unsigned long long)ts >> 32);
+        // the live rows of every chunk: a dead row of a live chunk (its problem finished earlier) is not stored - its ring slot
+        // holds whatever an earlier round, or an earlier fit, left there (round 6: the destination is the slot's own problem word)
+        ctl[4] = rows_live[0]; ctl[5] = rows_live[1]; ctl[6] = rows_live[2]; ctl[7] = rows_live[3];
         if (wg == 0 && verdict == VR_GO) {
             atomicAdd(RA.stats + 0, (unsigned)__popc(mask));
             if (nch > (unsigned)__popc(mask)) atomicAdd(RA.stats + 1, nch - (unsigned)__popc(mask));
@@ -1316,11 +1326,16 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             VPR_T(2);
             // (e) all waves: skinning blend (lbs.py:209-213), K halves combined in a fixed order, scale undone, T applied,
             //     "+ transl"; stores straight from registers (the last tile's: behind the closing barrier)
-            const int b_me = RA.b_lo + (int)c * 32 + bb;
-            const bool b_ok = b_me < RA.b_lo + RA.n;
+            const bool b_ok = ((ctl[4 + c] >> bb) & 1u) != 0u;     // (the row's problem evaluates this round)
             f32x4 tq;
             if constexpr (P == 0) tq = tau_0[bb]; else tq = tau_1[bb];
             const float tau3[3] = {tq.x, tq.y, tq.z};
+            // the problem this ring row held in this round (the translation word's spare lane; rows take new problems from the
+            // launch's work queue when theirs has finished - mvfit_api.hip: fit_persistent_kernel)
+            // (through a float rvalue: __builtin_bit_cast applied to the swizzle expression `tq.w` itself reads the VECTOR's first
+            // four bytes - element x - with this compiler, ROCm 7.2 clang; found as a memory fault, confirmed on a ten-line kernel)
+            const float tq_w = tq.w;
+            const int b_me = __builtin_bit_cast(int, tq_w);
             Pending last;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
@@ -1396,9 +1411,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 int t2 = tid_k;
                 asm volatile("" : "+v"(t2));
                 const int tile = min(wg * TPW + TPW - 1, M.ntiles - 1), vbase = tile * TILE_V, vq = t2 & 15;
-                const int bq = RA.b_lo + (int)c * 32 + (t2 >> 4);
-                last.dst = vout + ((size_t)bq * M.nv + vbase + 2 * vq) * 3;
-                last.nv_ok = bq < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;
+                last.dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vq) * 3;      // (b_me, b_ok: kept across the barrier)
+                last.nv_ok = b_ok ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;      // (b_ok: read before the barrier - wave 7 may be polling the next round by now)
                 issue_stores(last);
             }
         };
@@ -1763,10 +1777,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             VPW_T(2);
             // ---- K halves combined (fixed order), scale undone, T applied, "+ transl", stores straight from registers ----
             // (24 contiguous bytes per item - vertices 2 vp2, 2 vp2 + 1 -, 8-byte aligned: even vertex count, checked by the host)
-            auto store_item = [&](const float (&o)[6], int t, int e, int tq) {
+            // (b_me: the problem the ring row held in this round - the translation word's spare lane, see the kernel above;
+            // rows whose problem does not evaluate this round are not stored)
+            const unsigned live_rows = ctl[4 + c];
+            auto store_item = [&](const float (&o)[6], int t, int e, int tq, int b_me) {
                 const int vbase = (wg * TPW + t) * TILE_V, vq = tq & 15;
-                const int b_me = RA.b_lo + (int)c * 32 + (tq >> 4) + 16 * e;
-                const int nv_ok = b_me < RA.b_lo + RA.n ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;
+                const int nv_ok = ((live_rows >> ((tq >> 4) + 16 * e)) & 1u) ? min(TILE_V, M.nv - vbase) - 2 * vq : 0;
                 float* dst = vout + ((size_t)b_me * M.nv + vbase + 2 * vq) * 3;
 #if defined(VPX) && (VPX & 2)
                 if (o[0] == 1.2345e-30f) dst[0] = o[1] + o[2] + o[3] + o[4] + o[5];      // (experiment: no stores)
@@ -1815,7 +1831,8 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                             o[3 * i + k] = fmaf(tr[2 * t + e][i][k][0], vp[0], fmaf(tr[2 * t + e][i][k][1], vp[1],
                                                 fmaf(tr[2 * t + e][i][k][2], vp[2], tr[2 * t + e][i][k][3]))) + tau3[k];
                     }
-                    store_item(o, t, e, wt);
+                    const float row_prob = e ? tq1.w : tq0.w;             // (a float rvalue first: see the kernel above)
+                    store_item(o, t, e, wt, __builtin_bit_cast(int, row_prob));
                 }
             }
             VPW_T(3);

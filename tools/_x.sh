@@ -1,5 +1,16 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/sdfsvc; rm -rf $O; mkdir -p $O
-timeout 300 python bench.py --config configs2 --steps 3 --warmup 1 --no-pmc --no-cpu-baseline --no-variants > $O/bench_configs2.json.log 2> $O/bench_configs2.err; tail -3 $O/bench_configs2.err; python -c "
-import json; d=json.loads(open('$O/bench_configs2.json.log').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['closure_rounds_per_fit'], d['final_loss_median'], d['vertex_passes_last_fit'])"
-timeout 1200 python -m pytest tests/test_gpu_trajectory.py tests/test_gpu_sdf_term.py tests/test_gpu_sdf_cull.py -q -s -k "vposer_fits_with_the_sdf" > $O/tests.log 2>&1; tail -15 $O/tests.log
+O=gpurun_out/refill; rm -rf $O; mkdir -p $O
+for CFG in "--frames 32" "--frames 256" "--frames 256 --work-queue 0" "--config configs3" "--prior gmm"; do
+  N=$(echo $CFG | tr -d ' -'); timeout 400 python bench.py $CFG --steps 5 --warmup 1 --no-pmc --no-cpu-baseline --no-variants > $O/bench_$N.json.log 2> $O/bench_$N.err
+done
+python - <<PY
+import json, glob
+for f in sorted(glob.glob('$O/bench*.json.log')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d.get('roofline') or {}
+        print(f.split('/')[-1], d['value'], d['ms_per_step'], d['closure_rounds_per_fit'], r.get('kernel'), r.get('avg_launch_us'), r.get('frac'), d.get('vertex_passes_last_fit'), d.get('invalid_reason'))
+    except Exception as e:
+        print(f, 'unreadable', e, open(f.replace('.json.log','.err')).read()[-600:])
+PY
+timeout 900 python -m pytest tests/test_gpu_large_batch.py tests/test_gpu_async.py -q -x > $O/tests.log 2>&1; tail -6 $O/tests.log
