@@ -312,6 +312,32 @@ def demo_inputs(syn):
     return g, vpw, model, cams, g['gt_xy'][None].astype(np.float32), g['conf'][None].astype(np.float32), x0
 
 
+def demo_spread_timing(eng, g, stages, n=48):
+    """The demo frame's fit time as a MEDIAN over starts: the reference's initial guess and 47 copies perturbed by 1e-6 (the first
+    48 starts of tests/golden/demo_spread192.npz, the reference's own spread recording), each fitted ALONE (one problem + its
+    decoder helpers, like `value`'s run) - the single trajectory of the default start moves by +-35 % in closures with the last
+    bit of one gradient word, the median over 48 starts does not."""
+    fn = os.path.join(ROOT, 'tests', 'golden', 'demo_spread192.npz')
+    if not os.path.isfile(fn):
+        return None
+    x0s = np.load(fn)['x0'][:n].astype(np.float32)
+    ms, ncl, fl = [], [], []
+    for i in range(x0s.shape[0]):
+        xd = torch.tensor(x0s[i:i + 1], device=eng.device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        xf, st = eng.fit(xd, stages)
+        torch.cuda.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0)); ncl.append(int(st['n_closure'][0])); fl.append(float(st['final_loss'][0]))
+    ms, ncl = np.asarray(ms), np.asarray(ncl)
+    return dict(starts=int(x0s.shape[0]), ms_per_fit_median=round(float(np.median(ms)), 3), ms_per_fit_min=round(float(ms.min()), 3),
+                ms_per_fit_max=round(float(ms.max()), 3), closures_median=int(np.median(ncl)), closures_min=int(ncl.min()),
+                closures_max=int(ncl.max()), us_per_round_median=round(float(np.median(1e3 * ms / np.maximum(ncl, 1))), 2),
+                final_loss_median=round(float(np.median(fl)), 1),
+                note='each start fitted alone, wall clock around mvfit_fit; the starts of the reference\'s own spread recording '
+                     '(oracle/make_golden_demo_spread.py)')
+
+
 def cpu_model_name():
     try:
         with open('/proc/cpuinfo') as fh:
@@ -961,6 +987,10 @@ def main():
             'lbfgs_iters_per_s': round(tot_iter / tmax, 1),
             'closures_per_fit_per_frame': round(tot_closure / args.steps / total, 1),
             'closure_rounds_per_fit': n_max,      # = closures of the slowest frame of rank 0's batch
+            # the figure that compares builds (last review, item 4): time of one closure round of the batch = ms_per_step / rounds of
+            # the slowest problem.  closures/s of a mode moves with the LENGTH of that problem's chaotic trajectory (VPoser: +-12 %
+            # with the last bit of one gradient word); the time per round does not
+            'us_per_round': {args.prior: round(1e3 * (1e3 * tmax / args.steps) / max(n_max, 1), 2)},
             'final_loss_median': float(np.median(fl)),
             'vertex_passes_last_fit': passes,
             'vertex_passes_lost_in_timed_fits': {'missed': lost[0], 'timed_out': lost[1]},
@@ -992,7 +1022,12 @@ def main():
             # pass needs - a shared device, a CU mask - or an earlier fit on its ctx timed out) measures another code path
             out['invalid_reason'] = (out.get('invalid_reason', '') + ' ' if out.get('invalid_reason') else '') + \
                 ('ranks ran different vertex-pass forms or fell back to per-round launches: per_rank_resident_form = %s' % form_all)
+        for k_, v_ in (('vposer', 'prior_vposer'), ('gmm', 'prior_gmm')):
+            e_ = (variants or {}).get(v_)
+            if e_ and args.prior == 'l2':
+                out['us_per_round'][k_] = round(1e3 * e_['ms_per_step'] / max(e_['closure_rounds_per_fit'], 1), 2)
         if demo:
+            out['demo_48_starts'] = demo_spread_timing(eng, g, stages)
             out['reference_fit'] = dict(final_loss_fp32=float(g['fit_final32']), final_loss_fp64=float(g['fit_final64']),
                                         closures_fp32=int(g['fit_ncl32'].sum()), closures_fp64=int(g['fit_ncl64'].sum()),
                                         final_loss_spread_fp32=[float(v) for v in g['fit_spread32']],

@@ -106,6 +106,10 @@ struct ClosureLds {
     float sdf_fac;                  // 2 w^2 S: factor on the S-adjoint (0 when the term is off)
     unsigned sh_sdf_ok;             // service rounds: the answer arrived (0: timed out)
     int sh_next;                    // work queue: the problem this workgroup takes next
+    int sh_prob;                    // the problem this workgroup is fitting (global index)
+    const unsigned* sdf_wait_tag;   // service rounds: the answer tag the loss's combining wave waits for before it reads S (or null)
+    unsigned sdf_wait_want;
+    unsigned* sdf_wait_stats;       // where a timed-out wait is counted (AsyncRing::stats + 3)
     double total;
     double red_d[STEP_NW + 2];      // per-wave partials of the data term; [5..7] priors; [STEP_NW] 3-D term
     float red_f[STEP_NW][4];        // per-wave partials: g_tau (3)
@@ -838,6 +842,10 @@ __device__ __forceinline__ void sparse_forward(const DevModel& M, ClosureLds& L,
 // the scalar terms of the loss out of the reduced sums (fixed order, float64 like the reference's float() of the tensors):
 // called by every thread (all get the total) or by one wave; `writer` stores the side results (L.total, L.loss_terms, the
 // dropped-prior flags, the SDF factor, the selected mixture)
+// SDFW (service launches of the single-launch fit only): S is the answer of the term's kernels to THIS round's request - the
+// combining wave waits for the answer tag here, i.e. the keypoint phase (E4) and E5 run under the term's kernels; a wait that
+// times out (200 ms) makes the loss NaN and is counted: the host fails the fit
+template <bool SDFW = false>
 __device__ __forceinline__ double loss_combine(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, bool writer) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const bool use_gmm = !use_vp && (W.flags & MVFIT_F_PRIOR_GMM);
@@ -877,7 +885,21 @@ __device__ __forceinline__ double loss_combine(const DevModel& M, ClosureLds& L,
     double l_coll = 0.0;
     float sdf_fac = 0.f;
     if (L.sdf_adj && W.coll_w > 0.f) {
-        const float S = sdf_ld(&L.sdf_adj->S);
+        bool answered = true;
+        if constexpr (SDFW) {
+            if (L.sdf_wait_tag) {
+                if (!L.sh_sdf_ok) answered = false;                  // (an earlier wait of this problem timed out: no more waiting)
+                else {
+                    const long long t0 = wall_clock64();
+                    while (__hip_atomic_load(L.sdf_wait_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < L.sdf_wait_want) {
+                        if (wall_clock64() - t0 > 20000000) { answered = false; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (!answered && writer) { atomicAdd(L.sdf_wait_stats, 1u); L.sh_sdf_ok = 0u; }
+                }
+            }
+        }
+        const float S = answered ? sdf_ld(&L.sdf_adj->S) : __builtin_nanf("");
         const double ws = (double)W.coll_w * (double)S;
         l_coll = ws * ws;
         sdf_fac = 2.f * W.coll_w * W.coll_w * S;
@@ -1038,7 +1060,7 @@ __device__ __forceinline__ double loss_and_keypoint_grad(const DevModel& M, Clos
     // the scalar terms are combined by every thread here (each then returns the total), or - DEFER - by one otherwise idle wave
     // inside the adjoint's first phase (closure_backward), which leaves the total in L.total
     double total = 0.0;
-    if constexpr (!DEFER) total = loss_combine(M, L, V, W, tid == 0);
+    if constexpr (!DEFER) total = loss_combine<false>(M, L, V, W, tid == 0);
     const bool use_3d = (W.flags & MVFIT_F_USE_3D) != 0;
     if (want_grad && tid < 3) {
         float s = 0.f;
@@ -1161,7 +1183,7 @@ __device__ __forceinline__ void contraction_backward(const DevModel& M, ClosureL
 // ---------------------------------------------------------------------------------------------
 // DEFER: the loss's scalar terms were left uncombined by loss_and_keypoint_grad<true>; the last wave - idle in E5 - combines
 // them here, under E5 (400 cycles that every thread used to spend between the loss's barrier and this function's first one)
-template <bool REMOTE = false, bool DEFER = false>
+template <bool REMOTE = false, bool DEFER = false, bool SDFW = false>
 __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& L, int V, const DevWeights& W, int tid) {
     const bool use_vp = (W.flags & MVFIT_F_VPOSER) != 0;
     const int ns = L.M.ns, nc = L.M.nc, nc_pad = L.M.nc_pad;
@@ -1169,7 +1191,7 @@ __device__ __forceinline__ void closure_backward(const DevModel& M, ClosureLds& 
     // ---- E5: g_x = Ksel^T g_kp ; g_vposed = Tr^T g_x ----
     if constexpr (DEFER) {
         static_assert(NC_MAX <= STEP_NT - 64, "E5's threads leave the last wave free");
-        if (tid >= STEP_NT - 64) loss_combine(M, L, V, W, tid == STEP_NT - 64);
+        if (tid >= STEP_NT - 64) loss_combine<SDFW>(M, L, V, W, tid == STEP_NT - 64);
     }
     if (tid < nc_pad) {
         float v = 0.f;
@@ -1464,9 +1486,10 @@ __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigne
 
 constexpr int PUBLISH_WAVE = 3;      // idle in the loss phase that follows (data term: waves 0-1 at <= 7 views; 3-D term and priors: waves 5-7)
 
-// b = the workgroup's ring row (sub-batch-relative), prob = the global index of the problem it is fitting (the passes write the
-// round's vertices there: rows take new problems when theirs has finished)
-__device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int prob, int tid) {
+// b = the workgroup's ring row (sub-batch-relative); L.sh_prob = the global index of the problem it is fitting (the passes write the
+// round's vertices there: rows take new problems when theirs has finished; read from LDS by the one lane that needs it - as a
+// register it was live through the whole round loop: 8 more spilled registers in the kernels without a queue)
+__device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRing& R, int slot, unsigned round, int b, int tid) {
     // All 129 words go out from ONE wave, which also stores the tag later: the hand-off needs no workgroup barrier.
     const int l = tid - 64 * PUBLISH_WAVE;
     if (l < 0 || l >= 64) return;
@@ -1527,7 +1550,7 @@ __device__ __forceinline__ void publish_pose_async(ClosureLds& L, const AsyncRin
         const unsigned word = (((unsigned)slot * (Bp >> 5) + chunk) * (KROWS / 16) + G) * 2 + hl;
         store16_sc1(rs_c, (word * 64 + 32 * h + ((unsigned)b & 31)) * 16, v);
     } else if (l == 56) {
-        store16_sc1(rs_t, ((unsigned)slot * Bp + (unsigned)b) * 16, make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], __builtin_bit_cast(float, prob)));
+        store16_sc1(rs_t, ((unsigned)slot * Bp + (unsigned)b) * 16, make_float4(L.opt.x[X_TR], L.opt.x[X_TR + 1], L.opt.x[X_TR + 2], __builtin_bit_cast(float, L.sh_prob)));
     }
 }
 
@@ -1547,7 +1570,8 @@ __device__ __forceinline__ void publish_tag(const AsyncRing& R, int slot, int b,
 // of the ring operands, the float32 coefficients the pull-back contracts with (the chained rounds' coefT layout) and the
 // problem's gate word, drains its stores and publishes the tag AT ONCE; the host has queued gate -> vertex pass -> SDF front
 // -> pull-back for the round on the pass stream; the pull-back's reducing workgroup publishes the answer tag behind its
-// write-through result, and the workgroup continues with the loss.  Per round: one memory hop to the gate kernel, three
+// write-through result; the workgroup goes on with the keypoint phase and waits for the answer where S is first needed
+// (loss_combine<true>, the wave that combines the loss's scalar terms under E5).  Per round: one memory hop to the gate kernel, three
 // launches, one hop back - no optimiser state reload, no step-kernel launch, the forward of the trial point already done.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void publish_sdf_request(const ClosureLds& L, const DevPose& P, int* gate, int b, int on, int tid) {
@@ -1558,23 +1582,6 @@ __device__ __forceinline__ void publish_sdf_request(const ClosureLds& L, const D
         for (int p = l; p < KROWS; p += 64) __hip_atomic_store(ct + p * 32, L.coef[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (l == 0) __hip_atomic_store(gate + b, on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Wait for the answer of round `want - 1` (the publishing wave polls with s_sleep, everybody else sleeps at the barrier).
-// Bounded by the wall clock (200 ms): returns false when the answer never came (the host stopped queueing rounds, a launch
-// failed) - the caller ends the problem with an error status, never with a silently missing term.
-__device__ __forceinline__ bool sdf_answer_wait(ClosureLds& L, const unsigned* tag, unsigned want, int tid) {
-    if ((tid >> 6) == PUBLISH_WAVE) {
-        unsigned ok = 1u;
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (wall_clock64() - t0 > 20000000) { ok = 0u; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if ((tid & 63) == 0) L.sh_sdf_ok = ok;
-    }
-    __syncthreads();
-    return L.sh_sdf_ok != 0u;
 }
 
 }  // namespace mvfit

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_init_kernel(DevModel M, const Obs
 // LEAN: the stage flags carry none of VPoser / GMM / 3-D term (the host checks) - said to the compiler as a fact about
 // the flag word, which lets it drop those branches from the round: 13 KB less code to stream through the instruction
 // cache every round (86 -> 73 KB), 1.2-1.6 % per fit (speed only: the result does not depend on it)
-// SDFS: the launch serves stages with the SDF term by asking for it (closure_device.h: publish_sdf_request / sdf_answer_wait);
+// SDFS: the launch serves stages with the SDF term by asking for it (closure_device.h: publish_sdf_request, loss_combine<true>);
 // sv = {pass operands of the chained layout (coefT), gate words, answer tags, global problem index, round offset of the launch}
 struct SdfService { const DevPose* P; int* gate; const unsigned* tag; int b; int round0; };
 template <bool REMOTE = false, bool REUSE = false, bool LEAN = false, bool COMPACT = false, bool SDFS = false, bool ROFF = SDFS>
@@ -260,26 +260,26 @@ __device__ __forceinline__ bool fit_round(const DevModel& M, ClosureLds& L, int 
     // rounds the row spent on earlier problems of the launch - refill)
     const unsigned a_round = use_ring ? (unsigned)(L.opt.lbS.n_closure - (ROFF ? sv.round0 : 0)) : 0u;
     const int a_slot = use_ring ? (int)(a_round % (unsigned)ring.nslots) : 0;
-    if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, sv.b, tid);
+    if (use_ring) publish_pose_async(L, ring, a_slot, a_round, pb, tid);
     bool sdf_round = false;
     if constexpr (SDFS) {
         // a stage that carries the interpenetration term: ask for S and its adjoint at this trial point (the tag goes out at
         // once: the round's passes and the term's kernels are queued behind it) and wait for the answer
         sdf_round = use_ring && L.sdf_adj != nullptr && W.coll_w > 0.f;           // block-uniform
         if (use_ring) publish_sdf_request(L, *sv.P, sv.gate, sv.b, sdf_round ? 1 : 0, tid);
-        if (sdf_round) {
-            publish_tag(ring, a_slot, pb, a_round, tid);
-            if (!sdf_answer_wait(L, sv.tag + sv.b, a_round + 1u, tid)) {
-                // never a silently missing term: the problem ends here (final loss NaN), the host fails the fit (stats[3])
-                if (tid == 0) { atomicAdd(ring.stats + 3, 1u); L.opt.lbS.status = 1; L.sh_status = 1; }
-                __syncthreads();
-                return true;
-            }
+        if (sdf_round) publish_tag(ring, a_slot, pb, a_round, tid);
+        // the answer is waited for where S is first needed: by the wave that combines the loss's scalar terms, under E5
+        // (closure_device.h: loss_combine<true>) - the keypoint phase overlaps the term's kernels.  Never a silently missing
+        // term: a wait that times out makes the loss NaN and is counted (stats[3]: the host fails the fit)
+        if (tid == 0) {
+            L.sdf_wait_tag = sdf_round ? sv.tag + sv.b : nullptr;
+            L.sdf_wait_want = a_round + 1u;
+            L.sdf_wait_stats = ring.stats + 3;
         }
     }
     loss_and_keypoint_grad<true>(M, L, nviews, W, true, tid);          // (scalar terms combined under the adjoint's first phase)
     PH_T(3);
-    closure_backward<REMOTE, true>(M, L, nviews, W, tid);
+    closure_backward<REMOTE, true, SDFS>(M, L, nviews, W, tid);
     const double total = L.total;
     if (trace) {                                           // (x_trial, loss) of this closure call (mvfit_fit_trace)
         const int k = L.opt.lbS.n_closure;                 // closures consumed so far = index of this one
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         }
         return;
     }
-    if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; }
+    if (tid == 0) { L.sh_stage = L.opt.lbS.stage; L.sh_status = 0; L.sh_sdf_ok = 1u; L.sh_prob = b; }
     if (tid == 64 * PUBLISH_WAVE) L.sh_pass_done = 0u;
     float* gd = F.dirs + (size_t)b * LB_HIST * LB_D;
     float* gs = F.stps + (size_t)b * LB_HIST * LB_D;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(STEP_NT) void fit_persistent_kernel(DevModel M, con
         done = fit_round<REMOTE, REUSE, LEAN, true, SDFS, SDFS || QUEUE>(M, L, nviews, H, false, false, F.stage_final + (size_t)b * MVFIT_MAX_STAGES, t, LbGramLds{nullptr, 0, 0},
                          F.trace ? F.trace + (size_t)b * F.trace_cap * (DV + 1) : nullptr, F.trace_cap,
                          ring, ring.tag != nullptr, (int)blockIdx.x,        // ring slots: sub-batch-relative problem index
-                         SdfService{&P, F.sdf_gate, F.sdf_tag, b, round0});      // (b: also the row's problem index for the passes)
+                         SdfService{SDFS ? &P : nullptr, SDFS ? F.sdf_gate : nullptr, SDFS ? F.sdf_tag : nullptr, b, round0});
         if (done) break;                                  // block-uniform
         if (L.sh_stage != stage_prev) {
             // a new stage starts with a fresh optimiser (non_linear_solver.py:172): its history is empty, and the branch-free

@@ -30,20 +30,36 @@ def _resolve_root() -> str:
     if os.path.isfile('/root/reference/code/utils/fitting.py') or not os.path.isfile(_STAGE):
         return '/root/reference'
     import hashlib
+    import shutil
     import tarfile
     import tempfile
     st = os.stat(_STAGE)
     key = hashlib.sha1(('%s:%d:%d' % (_STAGE, st.st_size, int(st.st_mtime))).encode()).hexdigest()[:12]
-    root = os.path.join(tempfile.gettempdir(), 'mvfit_reference_stage_' + key)
+    # a per-user directory (mode 0700), never a predictable world-writable path: the archive holds code that is imported and a
+    # checkpoint that is unpickled - on a shared box nobody else may be able to put their own tree where this one is expected
+    base = os.path.join(os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache'), 'mvfit_reference_stage')
+    try:
+        os.makedirs(base, mode=0o700, exist_ok=True)
+        if os.stat(base).st_uid != os.getuid() or (os.stat(base).st_mode & 0o077):
+            raise OSError('not ours')
+    except OSError:
+        base = tempfile.mkdtemp(prefix='mvfit_reference_stage_')          # (mode 0700, ours by construction; unpacked per process)
+    root = os.path.join(base, key)
     if not os.path.isfile(os.path.join(root, '.complete')):
-        tmp = tempfile.mkdtemp(prefix='mvfit_reference_stage_')
+        tmp = tempfile.mkdtemp(prefix='unpack_', dir=base)
         with tarfile.open(_STAGE) as tf:
-            tf.extractall(tmp)
+            try:
+                tf.extractall(tmp, filter='data')       # no absolute paths, no links out of the tree, no device files
+            except TypeError:                            # (a Python without extraction filters: validate the member paths ourselves)
+                for m in tf.getmembers():
+                    dest = os.path.realpath(os.path.join(tmp, m.name))
+                    if not (m.isfile() or m.isdir()) or not dest.startswith(os.path.realpath(tmp) + os.sep):
+                        raise RuntimeError('unexpected member in %s: %r' % (_STAGE, m.name))
+                tf.extractall(tmp)
         open(os.path.join(tmp, '.complete'), 'w').close()
         try:
             os.rename(tmp, root)
-        except OSError:                              # another process was faster: use its copy
-            import shutil
+        except OSError:                              # another process of this user was faster: use its copy
             shutil.rmtree(tmp, ignore_errors=True)
     return root
 
