@@ -74,7 +74,7 @@ __global__ void pass_gate_kernel(const unsigned* __restrict__ tag, const unsigne
         const bool ok = !mine || t >= want || d <= round;
         if (__all(ok)) break;
         if (wall_clock64() - t_start > 300000) { timed_out = true; break; }            // 3 ms at 100 MHz
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(8);                              // (round 6: 8 instead of 32 - measured in round 5: the round span 4.74 -> 4.6 us, closures/s unchanged)
     }
     const unsigned long long missed = __ballot(mine && d > round && t > want);
     if ((threadIdx.x & 63) == 0) {
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void resident_poll(const ResidentArgs& RA, unsigned r
         }
         if (__all(ok)) break;
         if (wall_clock64() - t0 > 2000000) { verdict = VR_TIMEOUT; break; }            // 20 ms at 100 MHz
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(8);                              // (round 6: 8 instead of 32 - measured in round 5: the round span 4.74 -> 4.6 us, closures/s unchanged)
     }
     unsigned mask = 0u;
     for (unsigned c = 0; c < nch; ++c) mask |= rows_live[c & 3u] != 0u ? (1u << c) : 0u;

@@ -2,7 +2,7 @@
 # Run on the MI355X box (gpurun): kernel stats of the bench command + PMC traffic of the vertex pass at 32 / 128
 # problems.  Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>/...  (copy the summaries into profiles/)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

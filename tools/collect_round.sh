@@ -2,7 +2,7 @@
 # Run on the MI355X box (gpurun): the bench lines of a round.  Usage: bash tools/collect_round.sh <tag> [quick]
 #   -> gpurun_out/<tag>/bench_*.json.log (copy what is to be judged into profiles/<tag>_*)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
