@@ -41,3 +41,22 @@ def test_header_constants_match_binding():
     assert int(c['MVFIT_F_FIX_SCALE'].rstrip('u')) == _lib.F_FIX_SCALE
     assert int(c['MVFIT_F_SPARSE_VERTS'].rstrip('u')) == _lib.F_SPARSE_VERTS
     assert int(c['MVFIT_F_USE_3D'].rstrip('u')) == _lib.F_USE_3D
+
+
+def test_options_struct_mirrors_the_header_and_the_defaults_are_the_documented_ones():
+    """mvfit_options (include/mvfit.h) field by field against the ctypes mirror, and mvfit_options_default - a host function, no
+    GPU needed - against the defaults the header documents (round 6: sdf_service and work_queue are on)."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, 'include', 'mvfit.h')).read()
+    body = hdr[hdr.index('typedef struct mvfit_options {'):hdr.index('} mvfit_options;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = re.findall(r'\b(?:u?int32_t)\s+([a-z_0-9]+)\s*;', body)
+    assert fields == [f[0] for f in _lib.Options._fields_], (fields, [f[0] for f in _lib.Options._fields_])
+    assert all(C.sizeof(f[1]) == 4 for f in _lib.Options._fields_)
+    lib = _lib.load()
+    o = _lib.Options()
+    lib.mvfit_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(_lib.Options)
+    got = {f[0]: int(getattr(o, f[0])) for f in _lib.Options._fields_ if f[0] != 'struct_size'}
+    assert got == dict(contraction=0, dense_skinning=0, round_mode=0, resident_pass=-1, sdf_two_phase=1, sdf_face_lists=1,
+                       vposer_helpers=1, vposer_sets=0, closure_vposer_helpers=0, pass_kernel=0, sdf_service=1, work_queue=1), got
