@@ -1181,6 +1181,12 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         else if (tid_k < 64) sj_l[t * 32 + tid_k - 32] = __builtin_bit_cast(i32x4, M.wsp_j[(size_t)tile * TILE_V + tid_k - 32]);
     }
     __syncthreads();
+    bool pair_same[TPW];                                         // the two vertices of this thread's pair hang on the same joints
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const i32x4 a = sj_l[t * 32 + 2 * (tid_k & 15)], b = sj_l[t * 32 + 2 * (tid_k & 15) + 1];
+        pair_same[t] = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+    }
 
     // requests of a chunk's operands: direct global -> LDS, sc1; spread over the eight waves (A: 36 x 1 KiB, coefficients 28);
     // Q = the buffer the transforms go to (compile-time: the destination is a named LDS object)
@@ -1347,6 +1353,9 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 // the tiles' basis sits in registers next to this
                 const int pt = t * (2 * 3 * 32 * 33);
                 Pending cur;
+                // (round 6: the pair's second vertex keeps the first one's twelve transform rows when it hangs on the same four
+                // joints - 93 % of the pairs -: half the LDS gathers of the blend, the same products in the same order)
+                f32x4 rows[4][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f32x4 spw = sw_l[t * 32 + 2 * vp2 + i];
@@ -1358,20 +1367,23 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) tr[k][e] = 0.f;
+                    if (i == 0 || !pair_same[t]) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int u = 2 * h; u < 2 * h + 2; ++u)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const f32x4 a = A_row(bb * (A_STRIDE / 4) + jq[u] * 3 + k);
-                                tr[k][0] = fmaf(wq[u], a.x, tr[k][0]);
-                                tr[k][1] = fmaf(wq[u], a.y, tr[k][1]);
-                                tr[k][2] = fmaf(wq[u], a.z, tr[k][2]);
-                                tr[k][3] = fmaf(wq[u], a.w, tr[k][3]);
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int k = 0; k < 3; ++k) rows[u][k] = A_row(bb * (A_STRIDE / 4) + jq[u] * 3 + k);
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const f32x4 a = rows[u][k];
+                            tr[k][0] = fmaf(wq[u], a.x, tr[k][0]);
+                            tr[k][1] = fmaf(wq[u], a.y, tr[k][1]);
+                            tr[k][2] = fmaf(wq[u], a.z, tr[k][2]);
+                            tr[k][3] = fmaf(wq[u], a.w, tr[k][3]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                     const int v = 2 * vp2 + i;
                     float vp[3];
 #pragma unroll
