@@ -1828,21 +1828,22 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     const int bb = q + 16 * e;
                     const float tau3[3] = {e ? tq1.x : tq0.x, e ? tq1.y : tq0.y, e ? tq1.z : tq0.z};
                     float o[6];
+                    // (the pair's two vertices are neighbours in a row of partials and are read side by side; the compiler keeps
+                    // single ds_read_b32 all the same - rows start at odd dword offsets - and the round measures the same)
+                    float vp[2][3];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int v = 2 * vp2 + i;
-                        float vp[3];
+                    for (int k = 0; k < 3; ++k) {
+                        const int p0 = pt + ((0 * 3 + k) * 32 + bb) * 33 + 2 * vp2, p1 = pt + ((1 * 3 + k) * 32 + bb) * 33 + 2 * vp2;
+                        const float a0 = part[p0], a1 = part[p0 + 1], b0 = part[p1], b1 = part[p1 + 1];
+                        vp[0][k] = (a0 + b0) * inv_scale;
+                        vp[1][k] = (a1 + b1) * inv_scale;
+                    }
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            float sm = part[pt + ((0 * 3 + k) * 32 + bb) * 33 + v];
-                            sm += part[pt + ((1 * 3 + k) * 32 + bb) * 33 + v];
-                            vp[k] = sm * inv_scale;
-                        }
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
-                            o[3 * i + k] = fmaf(tr[2 * t + e][i][k][0], vp[0], fmaf(tr[2 * t + e][i][k][1], vp[1],
-                                                fmaf(tr[2 * t + e][i][k][2], vp[2], tr[2 * t + e][i][k][3]))) + tau3[k];
-                    }
+                            o[3 * i + k] = fmaf(tr[2 * t + e][i][k][0], vp[i][0], fmaf(tr[2 * t + e][i][k][1], vp[i][1],
+                                                fmaf(tr[2 * t + e][i][k][2], vp[i][2], tr[2 * t + e][i][k][3]))) + tau3[k];
                     const float row_prob = e ? tq1.w : tq0.w;             // (a float rvalue first: see the kernel above)
                     store_item(o, t, e, wt, __builtin_bit_cast(int, row_prob));
                 }
