@@ -32,7 +32,7 @@ hipError_t launch_pass_gate(const DevPose& P, int b_lo, int B, hipStream_t strea
 hipError_t launch_vertex_pass_resident(const DevModel& M, const ResidentArgs& RA, int tpw, hipStream_t stream);
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
-                           void* cull, unsigned* answer_tag = nullptr, unsigned answer = 0u);
+                           void* cull, unsigned* answer_tag = nullptr, unsigned answer = 0u, const unsigned long long* box_parts = nullptr);
 size_t sdf_cull_bytes(int B, int num_faces);
 size_t sdf_op_ws_bytes(int B, int num_faces);
 bool sdf_op_uses_lists(int num_faces);
@@ -721,6 +721,7 @@ struct mvfit_ctx {
     float4* d_sdf_samp = nullptr;      // [B][nv]
     void* d_sdf_entries = nullptr;     // [B][nv] entry list
     SdfAdj* d_sdf_adj = nullptr;       // [B]
+    unsigned long long* d_sdf_boxpart = nullptr;   // [B][ntiles][6] the vertex pass's own per-tile keys of the term's bounding box (single-chunk split kernel)
     void* d_sdf_cull = nullptr;        // face lists of the all-faces term (sdf_term.hip), sized for (B, sdf_num_faces)
     void* d_sdf_op_ws = nullptr;       // face lists of the stand-alone op (mvfit_sdf), kept between calls of one shape
     int sdf_op_B = 0, sdf_op_F = 0;
@@ -1264,7 +1265,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     void* ps[] = {c->d_camR, c->d_camt, c->d_camf, c->d_camc, c->d_gt, c->d_wc, c->P.coefH, c->P.coefT, c->P.Amat, c->P.tau,
                   c->P.vposed_sel, c->P.xs_sel, c->d_verts, c->d_obs, c->F.opt, c->F.pose, c->F.dirs, c->F.stps,
                   c->F.grow, c->F.gcol, c->F.rinv, c->F.stage_final, c->F.n_done, c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries,
-                  c->d_sdf_adj, c->d_sdf_cull, c->F.sdf_gate, c->F.sdf_tag, c->F.vp, c->d_gt3d, c->d_c3d};
+                  c->d_sdf_adj, c->d_sdf_cull, c->d_sdf_boxpart, c->F.sdf_gate, c->F.sdf_tag, c->F.vp, c->d_gt3d, c->d_c3d};
     for (void* p : ps) if (p) hipFree(p);
     {
         void* rp[] = {c->ring.coefH, c->ring.Amat, c->ring.tau, c->ring.tag, c->ring.done_round, c->ring.stats, c->ring.pass_done};
@@ -1279,6 +1280,7 @@ static void free_problem_buffers(mvfit_ctx* c) {
     c->d_verts = nullptr;
     c->F = FitBuffers{};
     c->d_sdf_box = nullptr; c->d_sdf_samp = nullptr; c->d_sdf_entries = nullptr; c->d_sdf_adj = nullptr; c->d_sdf_cull = nullptr;
+    c->d_sdf_boxpart = nullptr;
     c->sdf_cull_refused = false;
 }
 
@@ -1447,7 +1449,15 @@ static int ensure_sdf_buffers(mvfit_ctx* c) {
     HIP_OK(c, hipMalloc(&c->d_sdf_entries, sdf_work_bytes(c->B, c->nv)));      // entry lists + slice partials + heads + tickets
     HIP_OK(c, hipMemset(reinterpret_cast<unsigned char*>(c->d_sdf_entries) + sdf_ticket_offset(c->B, c->nv), 0, (size_t)c->B * sizeof(int)));
     HIP_OK(c, hipMalloc(&c->d_sdf_adj, (size_t)c->B * sizeof(SdfAdj)));
+    HIP_OK(c, hipMalloc(&c->d_sdf_boxpart, (size_t)c->Bpad * c->M.ntiles * 6 * 8));
     return MVFIT_OK;
+}
+
+// the per-round pass over problems [b_lo, b_hi) runs as lbs_vertex_pass_split_kernel (which writes the tile keys of the term's box when
+// DevPose::box_part is set) when the split-fp16 basis exists and the launch is one 32-problem chunk per workgroup
+static bool pass_writes_box_parts(const mvfit_ctx* c, int b_lo, int b_hi) {
+    const int chunks = (b_hi + 31) / 32 - b_lo / 32;
+    return c->M.bs_h2 != nullptr && c->d_sdf_boxpart != nullptr && c->sdf_num_faces <= 128 && (chunks == 1 || c->opt.pass_kernel == 1);
 }
 
 static int run_sdf_term(mvfit_ctx* c, const float* verts, const int* gate, hipStream_t st) {
@@ -1639,11 +1649,15 @@ static int ensure_round_graph(mvfit_ctx* c, const StageWeights& SW, const LbOpts
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
+        // rounds with the SDF term: the pass writes its tiles' keys of the term's bounding box (single-chunk split kernel), the
+        // front kernel reduces the box from them
+        DevPose Pg = c->P;
+        if (c->F.sdf_adj && pass_writes_box_parts(c, 0, c->B)) Pg.box_part = c->d_sdf_boxpart;
         for (int r = 0; r < kGraphRounds && e == hipSuccess; ++r) {
-            e = launch_vertex_pass(c->M, c->P, c->B, c->d_verts, c->opt.pass_kernel, cs);
+            e = launch_vertex_pass(c->M, Pg, c->B, c->d_verts, c->opt.pass_kernel, cs);
             if (e == hipSuccess && c->F.sdf_adj)
                 e = launch_sdf_term(c->M, c->P, c->d_verts, c->B, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate,
-                                    c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs, c->d_sdf_cull);
+                                    c->d_sdf_box, c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, cs, c->d_sdf_cull, nullptr, 0u, Pg.box_part);
             hipLaunchKernelGGL(O.reuse_outer ? fit_step_kernel<true> : fit_step_kernel<false>, dim3(c->B), dim3(STEP_NT), step_gram_lds(), cs, c->M, (const ObsBlock*)c->d_obs, c->V, SW, O,
                                c->P, c->F);
         }
@@ -1928,6 +1942,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                 P.pad_ = (unsigned)debug_hook("MVFIT_DEBUG_NT_OFF");      // (hooks build only) bit 0 = plain basis loads, bit 1 = plain vertex stores
                 float* vout = c->d_verts;
                 if (c->capture_verts && (int)r == c->capture_round) vout = c->capture_verts;      // test hook
+                if (sdf_service && pass_writes_box_parts(c, b_lo, b_hi)) P.box_part = c->d_sdf_boxpart;      // (the term's box from the pass's tile keys)
                 hipError_t e = launch_pass_gate(P, b_lo, b_hi, c->pass_stream);
                 hipEvent_t ea = nullptr, eb = nullptr;
                 if (c->profile && c->ev_vp.size() < 4096) {            // mvfit_profile: the dispatch's own begin / end stamps
@@ -1942,7 +1957,7 @@ static int fit_async(mvfit_ctx* c, const StageWeights& SW, const LbOpts& O, int 
                     DevPose Ps = P;
                     Ps.coefT = c->P.coefT;
                     e = launch_sdf_term(c->M, Ps, vout, b_hi, c->d_sdf_faces, c->sdf_num_faces, c->sdf_grid, c->F.sdf_gate, c->d_sdf_box,
-                                        c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, c->pass_stream, c->d_sdf_cull, c->F.sdf_tag, r + 1u);
+                                        c->d_sdf_samp, c->d_sdf_entries, c->d_sdf_adj, c->pass_stream, c->d_sdf_cull, c->F.sdf_tag, r + 1u, P.box_part);
                     if (e != hipSuccess) return fail(c, MVFIT_E_HIP, "SDF term launch: %s", hipGetErrorString(e));
                 }
             }

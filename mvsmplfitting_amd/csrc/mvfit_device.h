@@ -169,6 +169,8 @@ struct DevPose {
     // this launch covers the 32-problem chunks from chunk0 on, up to the problem count it is given
     int chunk0;
     unsigned* pass_done;         // [1] rounds whose pass has completed (written by the gate of the next round)
+    unsigned long long* box_part; // [B][ntiles][6] min / max keys of the tile's vertices per axis (single-chunk split kernel; the SDF
+                                 // term's bounding box is reduced from them), or null
 };
 
 // Pose-operand ring of the asynchronous fit: slot (r % nslots) holds, per problem, the vertex-pass operands of the

@@ -33,26 +33,13 @@ namespace mvfit {
 constexpr int SDF_ADJ_NT = 512;
 constexpr int SDF_EB = 256;          // entries staged per batch in phase 2
 
-// order-preserving map float -> uint32 (total order of the finite values)
-__device__ __forceinline__ unsigned ord_bits(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord_float(unsigned o) {
-    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __builtin_bit_cast(float, u);
-}
+// (ord_bits / ord_float / dpp_u64 / row16_key: wave_ops.h - shared with the vertex pass, which reduces its tile's keys itself)
 typedef unsigned long long u64;
-template <int CTRL>
-__device__ __forceinline__ u64 dpp_u64(u64 v) { return __builtin_bit_cast(u64, dpp_mov<CTRL>(__builtin_bit_cast(double, v))); }
 // whole-wave min / max of 64-bit keys on the DPP path (wave_ops.h), same result in every lane
 template <bool MIN>
 __device__ __forceinline__ u64 wave64_key(u64 v) {
     auto pick = [](u64 p, u64 q) { return MIN ? (p < q ? p : q) : (p > q ? p : q); };
-    v = pick(v, dpp_u64<DPP_XOR1>(v));
-    v = pick(v, dpp_u64<DPP_XOR2>(v));
-    v = pick(v, dpp_u64<DPP_HALF_MIRROR>(v));
-    v = pick(v, dpp_u64<DPP_MIRROR>(v));
+    v = row16_key<MIN>(v);
     double p, q;
     swap_pair<false>(__builtin_bit_cast(double, v), p, q); v = pick(__builtin_bit_cast(u64, p), __builtin_bit_cast(u64, q));
     swap_pair<true>(__builtin_bit_cast(double, v), p, q);  v = pick(__builtin_bit_cast(u64, p), __builtin_bit_cast(u64, q));
@@ -63,8 +50,28 @@ __device__ __forceinline__ u64 wave64_key(u64 v) {
 // run on keys (ordered value << 32 | index) for the minima and (ordered value << 32 | ~index) for the maxima.
 // the reductions of one workgroup of 512 threads over all vertices of problem b; the result in *out (LDS or global), valid
 // for the whole workgroup after its next barrier
+// the tail of the reduction: a thread's keys -> wave keys -> the workgroup's box (512 threads)
+__device__ __forceinline__ void sdf_box_finish(u64 (&kmin)[3], u64 (&kmax)[3], int tid, u64 (*s_k)[6], SdfBox* out);
+
+// Round 6: the box from the vertex pass's own per-tile keys (vertex_pass.hip: vp_box_parts; [ntiles][6] per problem: min keys of
+// x, y, z, max keys of x, y, z) instead of from all 6890 vertices - min / max of keys are associative, the keys carry the vertex
+// index: the SAME box, arg indices included.  (The 16 workgroups of a problem each reduced the whole vertex list: ~5 us of the
+// front kernel's 16.7.)
+__device__ __forceinline__ void sdf_box_from_parts(const u64* __restrict__ parts, int ntiles, int b, int tid, u64 (*s_k)[6], SdfBox* out) {
+    u64 kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
+    for (int t = tid; t < ntiles; t += SDF_ADJ_NT) {
+        const u64* q = parts + ((size_t)b * ntiles + t) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const u64 lo = q[a], hi = q[3 + a];
+            kmin[a] = lo < kmin[a] ? lo : kmin[a];
+            kmax[a] = hi > kmax[a] ? hi : kmax[a];
+        }
+    }
+    sdf_box_finish(kmin, kmax, tid, s_k, out);
+}
+
 __device__ __forceinline__ void sdf_box_reduce(const float* __restrict__ verts, int nv, int b, int tid, u64 (*s_k)[6], SdfBox* out) {
-    const int lane = tid & 63, wave = tid >> 6;
     const float* vb = verts + (size_t)b * nv * 3;
     u64 kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
     for (int vbase = 0; vbase < nv; vbase += 512 * 16) {
@@ -89,6 +96,11 @@ __device__ __forceinline__ void sdf_box_reduce(const float* __restrict__ verts, 
             }
         }
     }
+    sdf_box_finish(kmin, kmax, tid, s_k, out);
+}
+
+__device__ __forceinline__ void sdf_box_finish(u64 (&kmin)[3], u64 (&kmax)[3], int tid, u64 (*s_k)[6], SdfBox* out) {
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { kmin[a] = wave64_key<true>(kmin[a]); kmax[a] = wave64_key<false>(kmax[a]); }
     if (lane == 0)
@@ -747,7 +759,8 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
                                                                  SdfBox* __restrict__ box, float4* __restrict__ samp,
                                                                  const int* __restrict__ gate,
                                                                  SdfEntry* __restrict__ entries, SdfChunk* __restrict__ chunks,
-                                                                 const int32_t* __restrict__ faces, int num_faces, int G) {
+                                                                 const int32_t* __restrict__ faces, int num_faces, int G,
+                                                                 const u64* __restrict__ box_parts, int ntiles) {
     __shared__ double sh_d[8][5];
     __shared__ int sh_cnt[8];
     __shared__ u64 s_k[FUSED ? 8 : 1][6];
@@ -765,7 +778,8 @@ __global__ __launch_bounds__(SDF_ADJ_NT) void sdf_entries_kernel(int nv, const f
                 const int vi = faces[3 * tid + m];
                 for (int a = 0; a < 3; ++a) fraw[m][a] = vb[3 * vi + a];
             }
-        sdf_box_reduce(verts, nv, b, tid, s_k, &sh_box);
+        if (box_parts) sdf_box_from_parts(box_parts, ntiles, b, tid, s_k, &sh_box);      // (uniform) the pass's own tile keys
+        else sdf_box_reduce(verts, nv, b, tid, s_k, &sh_box);
         __syncthreads();
     }
     const SdfBox bx = FUSED ? sh_box : box[b];
@@ -1040,7 +1054,7 @@ size_t sdf_work_bytes(int B, int nv) { return sdf_ticket_offset(B, nv) + (size_t
 
 hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* verts, int B, const int32_t* faces, int num_faces,
                            int G, const int* gate, SdfBox* box, float4* samp, void* entries, SdfAdj* adj, hipStream_t stream,
-                           void* cull, unsigned* answer_tag, unsigned answer) {
+                           void* cull, unsigned* answer_tag, unsigned answer, const unsigned long long* box_parts) {
     static_assert(SDF_ADJ_NT == KROWS + NJ * 12, "thread per output of the pull-back");
     unsigned char* wk = reinterpret_cast<unsigned char*>(entries);
     SdfAdj* part = reinterpret_cast<SdfAdj*>(wk + sdf_part_offset(B, M.nv));
@@ -1050,7 +1064,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
     const bool culled = cull && num_faces >= SDF_CULL_MIN_FACES;
     if (num_faces <= SDF_CH) {
         hipLaunchKernelGGL(sdf_entries_kernel<true>, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, box, samp, gate,
-                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G);
+                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G, box_parts, M.ntiles);
     } else {
         hipLaunchKernelGGL(sdf_bbox_kernel, dim3(B), dim3(512), 0, stream, verts, M.nv, gate, box,
                            culled ? cull_views(cull, B, num_faces).flag : (int*)nullptr);
@@ -1067,7 +1081,7 @@ hipError_t launch_sdf_term(const DevModel& M, const DevPose& P, const float* ver
                                (const SdfBox*)box, faces, num_faces, G, gate, samp);
         }
         hipLaunchKernelGGL(sdf_entries_kernel<false>, dim3(SDF_NC, B), dim3(SDF_ADJ_NT), 0, stream, M.nv, verts, box, samp, gate,
-                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G);
+                           reinterpret_cast<SdfEntry*>(entries), chunks, faces, num_faces, G, (const u64*)nullptr, 0);
     }
     hipLaunchKernelGGL(sdf_pullback_kernel, dim3(SDF_NS, B), dim3(SDF_ADJ_NT), 0, stream, M, P, gate, (const SdfBox*)box,
                        reinterpret_cast<const SdfEntry*>(entries), (const SdfChunk*)chunks, part, tickets, adj, answer_tag, answer);

@@ -242,6 +242,38 @@ __device__ __forceinline__ void vp_store_rows(float* __restrict__ verts, const f
     }
 }
 
+// Round 6, rounds with the SDF term: the min / max keys of the tile's stored vertices per problem and axis (the values the store path
+// writes: x + transl), reduced over the 16 lanes that share a problem row - the term's front kernel reduces the box from 216 x 6 keys
+// per problem instead of from 6890 vertices in each of its 16 workgroups (sdf_term.hip: sdf_box_from_parts; the same box: min / max
+// of keys are associative and carry the vertex index).  nv_t = vertices of the tile that exist.
+__device__ __forceinline__ void vp_box_parts(unsigned long long* __restrict__ parts, const float* out_l, const float* tau, int ntiles, int tile,
+                                             int nv_t, int b0, int B, int tid) {
+    const int b = tid >> 4, l = tid & 15;
+    unsigned long long kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int vv = l + 16 * h;
+        if (vv < nv_t) {
+            const unsigned v = (unsigned)(tile * TILE_V + vv);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = out_l[b * 96 + vv * 3 + a] + tau[b * 4 + a];         // (the store path's own addition)
+                const unsigned long long o = (unsigned long long)ord_bits(x) << 32;
+                const unsigned long long lo = o | v, hi = o | (unsigned)~v;
+                kmin[a] = lo < kmin[a] ? lo : kmin[a];
+                kmax[a] = hi > kmax[a] ? hi : kmax[a];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { kmin[a] = row16_key<true>(kmin[a]); kmax[a] = row16_key<false>(kmax[a]); }
+    if (l == 0 && b0 + b < B) {
+        unsigned long long* q = parts + ((size_t)(b0 + b) * ntiles + tile) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { q[a] = kmin[a]; q[3 + a] = kmax[a]; }
+    }
+}
+
 // side outputs for the vertices the objective reads (consumed by the step kernel of the chained mode)
 __device__ __forceinline__ void vp_side_outputs(const DevModel& M, const DevPose& P, const float* vps_l, const float* out_l,
                                                 int sel_s0, int sel_s1, int b0, int B, int tid) {
@@ -549,6 +581,7 @@ __global__ __launch_bounds__(VP_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 
     // ---- store x + transl, then (chained mode only) the side outputs for the step kernel ----
     vp_store_rows(verts, out_l, tau_l, M.nv, tile * TILE_V, min(TILE_V, M.nv - tile * TILE_V) * 3, b0, B, tid, store_nt);
+    if (P.box_part) vp_box_parts(P.box_part, out_l, tau_l, M.ntiles, tile, min(TILE_V, M.nv - tile * TILE_V), b0, B, tid);      // (uniform)
     if (!P.tag) vp_side_outputs(M, P, vps_l, out_l, sel_s0, sel_s1, b0, B, tid);
     VP_T(6, t_start);
 #ifdef MVFIT_TIMING

@@ -45,6 +45,31 @@ constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7 - i within each 8
 constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15 - i within each 16
 
+// 64-bit keys (ordered value << 32 | index) of the SDF term's bounding box (sdf_term.hip: sdf_box_reduce; round 6: the vertex pass
+// reduces its tile's keys itself, vertex_pass.hip: vp_box_parts).  Order-preserving map float -> uint32 (total order of the finite
+// values) and its inverse; min / max of keys over a 16-lane DPP row (the same result in every lane of the row)
+__device__ __forceinline__ unsigned ord_bits(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __builtin_bit_cast(float, u);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    return __builtin_bit_cast(unsigned long long, dpp_mov<CTRL>(__builtin_bit_cast(double, v)));
+}
+template <bool MIN>
+__device__ __forceinline__ unsigned long long row16_key(unsigned long long v) {
+    auto pick = [](unsigned long long p, unsigned long long q) { return MIN ? (p < q ? p : q) : (p > q ? p : q); };
+    v = pick(v, dpp_u64<DPP_XOR1>(v));
+    v = pick(v, dpp_u64<DPP_XOR2>(v));
+    v = pick(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    v = pick(v, dpp_u64<DPP_MIRROR>(v));
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T row16_sum(T v) {      // every lane of a 16-lane row gets the row total
     v += dpp_mov<DPP_XOR1>(v);
