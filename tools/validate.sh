@@ -1,4 +1,4 @@
-# Scratch driver for `gpurun -- 'bash tools/_call.sh'`: the standard validation sequence (GPU suite, smoke, default bench).
+# Developer tool for `gpurun -- "bash tools/validate.sh"`: the standard validation sequence (GPU suite, smoke, default bench, VPoser bench).
 set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/validate; rm -rf $O; mkdir -p $O
