@@ -233,15 +233,17 @@ def test_two_phase_fit_hands_over_to_the_chained_rounds(use_vp):
 
 def test_service_rounds_return_the_closure_values_and_do_not_depend_on_the_batch():
     """The SDF term as a service (round 6) under the yaml's four stages (coll_loss_weights 0, 0, 1000, 4500) at 5 and at 37
-    problems (two chunks, ragged): (a) every traced round of a stage with the term returned what mvfit_closure returns at that
-    trial point (the same term kernels; the objective's 69 vertices from the optimiser kernel instead of the pass: 1e-5), with
-    S > 0 in some of them; (b) the fit of a problem is the same bits whether 5 or 37 problems are fitted with it (independent
-    problems, one ring); (c) no pass lost, nothing timed out."""
+    problems (two chunks, ragged) and at 165 (two sub-batches of the service launch, [0, 96) and [96, 165): the gates of the
+    problems outside a sub-batch stay shut, tags and answers start over): (a) every traced round of a stage with the term
+    returned what mvfit_closure returns at that trial point (the same term kernels; the objective's 69 vertices from the optimiser
+    kernel instead of the pass: 1e-5), with S > 0 in some of them; (b) the fit of a problem is the same bits whether 5, 37 or
+    165 problems are fitted with it (independent problems, one ring; problem i >= 37 of the large batch is problem i % 37 again);
+    (c) no pass lost, nothing timed out."""
     cfg, g, model, vpw, gmm, wts, cams = load_case('l2_s3_v6')
     t = dict(np.load(os.path.join(GOLD, 'sdf_term_ref.npz')))
     x_hit = to118(t['l2_s3_v6/x'], False).astype(np.float32)          # a body with a vertex in the triangle's shadow
     res = {}
-    for B in (5, 37):
+    for B in (5, 37, 165):
         eng = make_engine(model)
         gt = np.repeat(t['l2_s3_v6/gt_xy'][None], B, 0)
         conf = np.repeat(t['l2_s3_v6/conf'][None], B, 0)
@@ -249,7 +251,7 @@ def test_service_rounds_return_the_closure_values_and_do_not_depend_on_the_batch
         eng.set_problems(camsB, gt, conf)
         eng.set_sdf(model['faces'], num_faces=1, grid_size=128)
         x0 = np.repeat(x_hit[None], B, 0)
-        x0[:, :86] += (1e-3 * np.random.default_rng(7).normal(0, 1, (37, 86))[:B]).astype(np.float32)
+        x0[:, :86] += (1e-3 * np.random.default_rng(7).normal(0, 1, (37, 86))[np.arange(B) % 37]).astype(np.float32)
         stages = eng_stage_weights(1536.0, coll_w=[0.0, 0.0, 1000.0, 4500.0])
         tr = eng.fit_trace(400)
         xf, st = eng.fit(x0, stages)
@@ -277,6 +279,9 @@ def test_service_rounds_return_the_closure_values_and_do_not_depend_on_the_batch
         res[B] = (xf.cpu().numpy(), ncl, st['final_loss'].cpu().numpy())
         eng.close()
     assert np.array_equal(res[5][0], res[37][0][:5]) and np.array_equal(res[5][1], res[37][1][:5]), (res[5][1], res[37][1][:5])
+    idx = np.arange(165) % 37
+    assert np.array_equal(res[165][1], res[37][1][idx]), (res[165][1], res[37][1][idx])
+    assert np.array_equal(res[165][0], res[37][0][idx]) and np.array_equal(res[165][2], res[37][2][idx])
 
 
 def test_sdf_adjoint_is_the_same_bits_in_every_run():
